@@ -1,0 +1,398 @@
+/* ref_dump.c -- golden-vector generator that RUNS THE REFERENCE rtlib.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Our own code; it links against oracle/_ref/libref_rtlib.so (the
+ * reference compiled from /root/reference by oracle/Makefile) and uses the reference's internal
+ * headers.  Its JSON output is committed under tests/golden/ (data, not source).  It also has a
+ * "bench" mode used by bench.py's cpu_baseline leg (kind "reference").
+ *
+ *   ref_dump params N L q0 sf dnum            -> primes, psi, CRT tables
+ *   ref_dump ops    N L q0 sf dnum level seed -> per-op input/output vectors (full if N<=64,
+ *                                                checksums otherwise)
+ *   ref_dump bench  N L q0 sf dnum level reps -> timings of the reference ops (JSON)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "common/rt_config.h"
+#include "common/rt_api.h"
+#include "poly/poly_arith.h"
+#include "util/ckks_parameters.h"
+#include "util/crt.h"
+#include "util/ntt.h"
+#include "util/number_theory.h"
+#include "util/polynomial.h"
+
+/* generated-code callbacks the rtlib expects from the program it is linked into */
+CKKS_PARAMS*  Get_context_params() { return NULL; }
+RT_DATA_INFO* Get_rt_data_info() { return NULL; }
+int           Get_input_count() { return 0; }
+int           Get_output_count() { return 0; }
+DATA_SCHEME*  Get_encode_scheme(int idx) { return NULL; }
+DATA_SCHEME*  Get_decode_scheme(int idx) { return NULL; }
+bool          Main_graph() { return true; }
+
+typedef unsigned long long u64;
+
+static u64 splitmix64(u64 seed, u64 i) {
+  u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static u64 sum64(const int64_t* v, size_t n) { u64 s = 0; for (size_t i = 0; i < n; i++) s += (u64)v[i]; return s; }
+static u64 xorw(const int64_t* v, size_t n) { u64 s = 0; for (size_t i = 0; i < n; i++) s ^= (u64)v[i] * (2 * (u64)i + 1); return s; }
+
+static int Full = 0;
+static void emit_vec(const char* name, const int64_t* v, size_t n, int last) {
+  printf("  \"%s\": {\"n\": %zu, \"sum64\": %llu, \"xorw\": %llu, \"first\": %llu, \"last\": %llu", name, n,
+         sum64(v, n), xorw(v, n), (u64)v[0], (u64)v[n - 1]);
+  if (Full) {
+    printf(", \"data\": [");
+    for (size_t i = 0; i < n; i++) printf("%s%llu", i ? "," : "", (u64)v[i]);
+    printf("]");
+  }
+  printf("}%s\n", last ? "" : ",");
+}
+static void emit_list(const char* name, const int64_t* v, size_t n, int last) {
+  printf("  \"%s\": [", name);
+  for (size_t i = 0; i < n; i++) printf("%s%llu", i ? "," : "", (u64)v[i]);
+  printf("]%s\n", last ? "" : ",");
+}
+
+static CKKS_PARAMETER* make_param(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum) {
+  CKKS_PARAMETER* p = Alloc_ckks_parameter();
+  Set_num_q_parts(p, dnum);
+  Init_ckks_parameters_with_prime_size(p, N, HE_STD_NOT_SET, L, q0, sf, 192);
+  return p;
+}
+static int64_t prime_val(CRT_CONTEXT* crt, size_t gi) {
+  size_t L = Get_primes_cnt(Get_q(crt));
+  return gi < L ? Get_modulus_val(Get_prime_at(Get_q(crt), gi)) : Get_modulus_val(Get_prime_at(Get_p(crt), gi - L));
+}
+static CRT_PRIME* prime_at(CRT_CONTEXT* crt, size_t gi) {
+  size_t L = Get_primes_cnt(Get_q(crt));
+  return gi < L ? Get_prime_at(Get_q(crt), gi) : Get_prime_at(Get_p(crt), gi - L);
+}
+static void fill_uniform(CRT_CONTEXT* crt, int64_t* out, size_t n_limbs, size_t level, uint32_t N, u64 seed) {
+  /* limb l < level uses q_l; limbs >= level use p_{l-level} */
+  size_t L = Get_primes_cnt(Get_q(crt));
+  for (size_t l = 0; l < n_limbs; l++) {
+    u64 q = (u64)prime_val(crt, l < level ? l : L + (l - level));
+    for (uint32_t i = 0; i < N; i++) out[l * N + i] = (int64_t)(splitmix64(seed, (u64)l * N + i) % q);
+  }
+}
+
+static int do_params(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CRT_CONTEXT*    crt = p->_crt_context;
+  size_t          K = p->_num_p_primes;
+  size_t          alpha = Get_per_part_size(Get_qpart(crt));
+  size_t          dnum_req = dnum;
+  dnum = p->_num_q_parts; /* 0 -> Get_default_num_q_parts */
+  printf("{\n  \"N\": %u, \"L\": %zu, \"q0_bits\": %zu, \"sf_bits\": %zu, \"dnum\": %zu, \"dnum_req\": %zu, \"K\": %zu, \"alpha\": %zu,\n",
+         N, L, q0, sf, dnum, dnum_req, K, alpha);
+  int64_t* tmp = malloc(sizeof(int64_t) * (L + K) * (L + K + 4));
+  for (size_t i = 0; i < L + K; i++) tmp[i] = prime_val(crt, i);
+  emit_list("primes", tmp, L + K, 0);
+  for (size_t i = 0; i < L + K; i++) { /* psi = rou[bitrev(1)] = rou[N/2] */
+    NTT_CONTEXT* ntt = Get_ntt(prime_at(crt, i));
+    tmp[i] = Get_i64_value_at(ntt->_rou, N >> 1);
+  }
+  emit_list("psi", tmp, L + K, 0);
+  for (size_t i = 0; i < L + K; i++) tmp[i] = Get_ntt(prime_at(crt, i))->_degree_inv;
+  emit_list("n_inv", tmp, L + K, 0);
+  for (size_t i = 0; i < L + K; i++) tmp[i] = Get_ntt(prime_at(crt, i))->_degree_inv_prec;
+  emit_list("n_inv_prec", tmp, L + K, 0);
+  for (size_t i = 0; i < L + K; i++) tmp[i] = (int64_t)(uint64_t)Get_prec128(Get_modulus(prime_at(crt, i)));
+  emit_list("prec128_lo", tmp, L + K, 0);
+  for (size_t i = 0; i < L + K; i++) tmp[i] = (int64_t)(uint64_t)(Get_prec128(Get_modulus(prime_at(crt, i))) >> 64);
+  emit_list("prec128_hi", tmp, L + K, 0);
+  /* twiddle table checksums per prime (+ full tables for tiny N) */
+  printf("  \"rou\": [\n");
+  for (size_t i = 0; i < L + K; i++) {
+    NTT_CONTEXT* ntt = Get_ntt(prime_at(crt, i));
+    printf("   {\"sum64\": %llu, \"xorw\": %llu, \"prec_xorw\": %llu, \"inv_xorw\": %llu, \"inv_prec_xorw\": %llu}%s\n",
+           sum64(Get_i64_values(ntt->_rou), N), xorw(Get_i64_values(ntt->_rou), N),
+           xorw((int64_t*)Get_ui64_values(ntt->_rou_prec), N), xorw(Get_i64_values(ntt->_rou_inv), N),
+           xorw((int64_t*)Get_ui64_values(ntt->_rou_inv_prec), N), i + 1 < L + K ? "," : "");
+  }
+  printf("  ],\n");
+  /* ModDown tables */
+  emit_list("phat_inv_modp", Get_i64_values(Get_phatinvmodp(Get_p(crt))), K, 0);
+  emit_list("phat_inv_modp_prec", Get_i64_values(Get_phatinvmodp_prec(Get_p(crt))), K, 0);
+  for (size_t i = 0; i < L; i++)
+    for (size_t j = 0; j < K; j++) tmp[i * K + j] = Get_i64_value_at(Get_phatmodq_at(Get_p(crt), i), j);
+  emit_list("phat_modq", tmp, L * K, 0);
+  emit_list("pinv_modq", Get_i64_values(Get_pinvmodq(Get_p(crt))), L, 0);
+  /* rescale tables: rows k = 0..L-2, columns i <= k */
+  printf("  \"rescale\": [\n");
+  for (size_t k = 0; k + 1 < L; k++) {
+    printf("   {\"ql_inv\": [");
+    for (size_t i = 0; i <= k; i++) printf("%s%llu", i ? "," : "", (u64)Get_i64_value_at(Get_ql_inv_mod_qi_at(Get_q(crt), k), i));
+    printf("], \"ql_inv_prec\": [");
+    for (size_t i = 0; i <= k; i++) printf("%s%llu", i ? "," : "", (u64)Get_i64_value_at(Get_ql_inv_mod_qi_prec_at(Get_q(crt), k), i));
+    printf("], \"qlql\": [");
+    for (size_t i = 0; i <= k; i++) printf("%s%llu", i ? "," : "", (u64)Get_i64_value_at(Get_ql_ql_inv_mod_ql_div_ql_mod_qi_at(Get_q(crt), k), i));
+    printf("], \"qlql_prec\": [");
+    for (size_t i = 0; i <= k; i++) printf("%s%llu", i ? "," : "", (u64)Get_i64_value_at(Get_ql_ql_inv_mod_ql_div_ql_mod_qi_prec_at(Get_q(crt), k), i));
+    printf("]}%s\n", k + 2 < L ? "," : "");
+  }
+  printf("  ],\n");
+  /* ModUp tables for every (level, digit) */
+  printf("  \"modup\": [\n");
+  int first = 1;
+  for (size_t level = 1; level <= L; level++) {
+    size_t nd = (level + alpha - 1) / alpha;
+    if (nd > dnum) nd = dnum;
+    for (size_t d = 0; d < nd; d++) {
+      size_t       n2 = level - alpha * d < alpha ? level - alpha * d : alpha;
+      VL_CRTPRIME* compl = Get_qpart_compl_at(Get_qpart_compl(crt), level - 1, d);
+      VALUE_LIST*  hinv = VL_L2_VALUE_AT(Get_qlhatinvmodq(Get_qpart(crt)), d, n2 - 1);
+      VL_VL_I64*   hmod = VL_L2_VALUE_AT(Get_qlhatmodp(Get_qpart(crt)), level - 1, d);
+      size_t       nc = LIST_LEN(compl);
+      printf("%s   {\"level\": %zu, \"digit\": %zu, \"n2\": %zu, \"hat_inv\": [", first ? "" : ",\n", level, d, n2);
+      first = 0;
+      for (size_t i = 0; i < n2; i++) printf("%s%llu", i ? "," : "", (u64)I64_VALUE_AT(hinv, i));
+      printf("], \"compl\": [");
+      for (size_t j = 0; j < nc; j++) printf("%s%llu", j ? "," : "", (u64)Get_modulus_val(Get_vlprime_at(compl, j)));
+      if (L > 12) { /* large sets: checksums only (flat index i*nc + j) */
+        u64 s = 0, x = 0;
+        for (size_t i = 0; i < n2; i++)
+          for (size_t j = 0; j < nc; j++) {
+            u64 v = (u64)Get_i64_value_at(VL_VALUE_AT(hmod, i), j);
+            s += v;
+            x ^= v * (2 * (u64)(i * nc + j) + 1);
+          }
+        printf("], \"hat_mod_sum64\": %llu, \"hat_mod_xorw\": %llu}", s, x);
+      } else {
+        printf("], \"hat_mod\": [");
+        for (size_t i = 0; i < n2; i++)
+          for (size_t j = 0; j < nc; j++)
+            printf("%s%llu", (i || j) ? "," : "", (u64)Get_i64_value_at(VL_VALUE_AT(hmod, i), j));
+        printf("]}");
+      }
+    }
+  }
+  printf("\n  ]\n}\n");
+  return 0;
+}
+
+/* the generated Rotate()/Relinearize() key-switch core, spelled with the reference's functions
+ * exactly as the checked-in generated code does (dataset/resnet20_cifar10_pre.onnx.inc:6996-7040) */
+static void ref_key_switch(CRT_CONTEXT* crt, POLYNOMIAL* out0, POLYNOMIAL* out1, POLYNOMIAL* in, int64_t* key,
+                           size_t level, size_t L, size_t K, uint32_t N) {
+  POLYNOMIAL swk0, swk1, ext, tmp;
+  Alloc_poly_data(&swk0, N, level, K); Set_is_ntt(&swk0, TRUE);
+  Alloc_poly_data(&swk1, N, level, K); Set_is_ntt(&swk1, TRUE);
+  Alloc_poly_data(&ext, N, level, K);  Set_is_ntt(&ext, TRUE);
+  Alloc_poly_data(&tmp, N, 1, 0);
+  size_t nd = Get_num_decomp_poly(in, crt);
+  for (size_t part = 0; part < nd; part++) {
+    Decompose_modup(&ext, in, crt, nd, part);
+    int64_t* key0 = key + (part * 2 + 0) * (L + K) * N;
+    int64_t* key1 = key + (part * 2 + 1) * (L + K) * N;
+    MODULUS* m = Get_q_modulus_head(crt);
+    for (size_t i = 0; i < level; i++, m++) {
+      Hw_modmul(tmp._data, key0 + i * N, ext._data + i * N, m, N);
+      Hw_modadd(swk0._data + i * N, swk0._data + i * N, tmp._data, m, N);
+      Hw_modmul(tmp._data, key1 + i * N, ext._data + i * N, m, N);
+      Hw_modadd(swk1._data + i * N, swk1._data + i * N, tmp._data, m, N);
+    }
+    m = Get_p_modulus_head(crt);
+    size_t p_ofst = Get_num_alloc_primes(&ext) - K; /* Num_alloc - Num_p */
+    for (size_t i = 0; i < K; i++, m++) {
+      size_t pi = i + p_ofst, ki = i + L; /* key P-limbs start at Poly_level(key) = L */
+      Hw_modmul(tmp._data, key0 + ki * N, ext._data + pi * N, m, N);
+      Hw_modadd(swk0._data + pi * N, swk0._data + pi * N, tmp._data, m, N);
+      Hw_modmul(tmp._data, key1 + ki * N, ext._data + pi * N, m, N);
+      Hw_modadd(swk1._data + pi * N, swk1._data + pi * N, tmp._data, m, N);
+    }
+  }
+  Reduce_rns_base(out0, &swk0, crt);
+  Reduce_rns_base(out1, &swk1, crt);
+  Free_poly_data(&swk0); Free_poly_data(&swk1); Free_poly_data(&ext); Free_poly_data(&tmp);
+}
+
+static int do_ops(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, u64 seed) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CRT_CONTEXT*    crt = p->_crt_context;
+  size_t          K = p->_num_p_primes;
+  size_t          dnum_req = dnum;
+  dnum = p->_num_q_parts;
+  Full = N <= 64;
+  Set_rtlib_config(CONF_OP_FUSION_DECOMP_MODUP, 1);
+  printf("{\n  \"N\": %u, \"L\": %zu, \"q0_bits\": %zu, \"sf_bits\": %zu, \"dnum\": %zu, \"dnum_req\": %zu, \"K\": %zu, \"level\": %zu, \"seed\": %llu,\n",
+         N, L, q0, sf, dnum, dnum_req, K, level, seed);
+
+  /* input a: level q-limbs, uniform, flagged NTT-domain */
+  POLYNOMIAL a;
+  Alloc_poly_data(&a, N, level, 0);
+  fill_uniform(crt, a._data, level, level, N, seed);
+  Set_is_ntt(&a, TRUE);
+  emit_vec("a", a._data, level * N, 0);
+
+  /* NTT / iNTT of every limb of a (treated as raw data), incl. p-limbs of a second input */
+  {
+    int64_t* f = malloc(sizeof(int64_t) * (level + K) * N);
+    int64_t* g = malloc(sizeof(int64_t) * (level + K) * N);
+    fill_uniform(crt, f, level + K, level, N, seed + 1);
+    emit_vec("x_ext", f, (level + K) * N, 0);
+    memcpy(g, f, sizeof(int64_t) * (level + K) * N);
+    size_t Lq = Get_primes_cnt(Get_q(crt));
+    for (size_t l = 0; l < level + K; l++) {
+      VALUE_LIST vl;
+      Init_i64_value_list_no_copy(&vl, N, f + l * N);
+      Ftt_fwd(&vl, Get_ntt(prime_at(crt, l < level ? l : Lq + (l - level))), &vl);
+      Init_i64_value_list_no_copy(&vl, N, g + l * N);
+      Ftt_inv(&vl, Get_ntt(prime_at(crt, l < level ? l : Lq + (l - level))), &vl);
+    }
+    emit_vec("ntt_fwd_x_ext", f, (level + K) * N, 0);
+    emit_vec("ntt_inv_x_ext", g, (level + K) * N, 0);
+
+    /* Mod_down of x_ext interpreted as an NTT-domain extended poly */
+    POLYNOMIAL ext, dn;
+    Alloc_poly_data(&ext, N, level, K);
+    fill_uniform(crt, ext._data, level + K, level, N, seed + 1);
+    Set_is_ntt(&ext, TRUE);
+    Alloc_poly_data(&dn, N, level, 0);
+    Reduce_rns_base(&dn, &ext, crt);
+    emit_vec("mod_down_x_ext", dn._data, level * N, 0);
+    Free_poly_data(&ext); Free_poly_data(&dn);
+    free(f); free(g);
+  }
+
+  /* Hw_modadd / Hw_modmul / Hw_rotate on limbs of a and b */
+  {
+    POLYNOMIAL b, r;
+    Alloc_poly_data(&b, N, level, 0);
+    Alloc_poly_data(&r, N, level, 0);
+    fill_uniform(crt, b._data, level, level, N, seed + 2);
+    emit_vec("b", b._data, level * N, 0);
+    MODULUS* m = Get_q_modulus_head(crt);
+    for (size_t l = 0; l < level; l++, m++) Hw_modadd(r._data + l * N, a._data + l * N, b._data + l * N, m, N);
+    emit_vec("hw_modadd_a_b", r._data, level * N, 0);
+    m = Get_q_modulus_head(crt);
+    for (size_t l = 0; l < level; l++, m++) Hw_modmul(r._data + l * N, a._data + l * N, b._data + l * N, m, N);
+    emit_vec("hw_modmul_a_b", r._data, level * N, 0);
+    int32_t rots[] = {1, -1, 5, (int32_t)(N / 4)};
+    MODULUS two_n;
+    Init_modulus(&two_n, 2 * (int64_t)N);
+    printf("  \"rotate\": [\n");
+    for (int ri = 0; ri < 5; ri++) {
+      uint32_t k = ri < 4 ? Find_automorphism_index(rots[ri], &two_n) : 2 * N - 1; /* conj */
+      VALUE_LIST* pre = Alloc_value_list(I64_TYPE, N);
+      Precompute_automorphism_order(pre, k, N, TRUE);
+      m = Get_q_modulus_head(crt);
+      for (size_t l = 0; l < level; l++, m++) Hw_rotate(r._data + l * N, a._data + l * N, Get_i64_values(pre), m, N);
+      printf("   {\"rot_idx\": %d, \"k\": %u, \"perm_sum64\": %llu, \"perm_xorw\": %llu, \"perm_head\": [%lld,%lld,%lld,%lld], \"out_sum64\": %llu, \"out_xorw\": %llu",
+             ri < 4 ? rots[ri] : 0, k, sum64(Get_i64_values(pre), N), xorw(Get_i64_values(pre), N),
+             (long long)I64_VALUE_AT(pre, 0), (long long)I64_VALUE_AT(pre, 1), (long long)I64_VALUE_AT(pre, 2),
+             (long long)I64_VALUE_AT(pre, 3), sum64(r._data, level * N), xorw(r._data, level * N));
+      if (Full) {
+        printf(", \"perm\": [");
+        for (size_t i = 0; i < N; i++) printf("%s%lld", i ? "," : "", (long long)I64_VALUE_AT(pre, i));
+        printf("]");
+      }
+      printf("}%s\n", ri < 4 ? "," : "");
+      Free_value_list(pre);
+    }
+    printf("  ],\n");
+    Free_poly_data(&b); Free_poly_data(&r);
+  }
+
+  /* Decomp_modup for every digit */
+  {
+    size_t nd = Get_num_decomp_poly(&a, crt);
+    printf("  \"num_decomp\": %zu,\n", nd);
+    for (size_t d = 0; d < nd; d++) {
+      POLYNOMIAL raised;
+      Alloc_poly_data(&raised, N, level, K);
+      Decompose_modup(&raised, &a, crt, nd, d);
+      char name[64];
+      snprintf(name, sizeof(name), "decomp_modup_%zu", d);
+      emit_vec(name, raised._data, (level + K) * N, 0);
+      Free_poly_data(&raised);
+    }
+  }
+
+  /* Rescale_poly */
+  if (level > 1) {
+    POLYNOMIAL rs;
+    Alloc_poly_data(&rs, N, level, 0);
+    Rescale_poly(&rs, &a, crt);
+    emit_vec("rescale_a", rs._data, (level - 1) * N, 0);
+    Free_poly_data(&rs);
+  }
+
+  /* full key-switch core with a uniformly random "key" [dnum][2][L+K][N] */
+  {
+    size_t   key_n = dnum * 2 * (L + K) * N;
+    int64_t* key = malloc(sizeof(int64_t) * key_n);
+    for (size_t d = 0; d < dnum * 2; d++) fill_uniform(crt, key + d * (L + K) * N, L + K, L, N, seed + 100 + d);
+    printf("  \"key_seed_base\": %llu,\n", seed + 100);
+    POLYNOMIAL o0, o1;
+    Alloc_poly_data(&o0, N, level, 0);
+    Alloc_poly_data(&o1, N, level, 0);
+    ref_key_switch(crt, &o0, &o1, &a, key, level, L, K, N);
+    emit_vec("key_switch_c0", o0._data, level * N, 0);
+    emit_vec("key_switch_c1", o1._data, level * N, 1);
+    Free_poly_data(&o0); Free_poly_data(&o1);
+    free(key);
+  }
+  printf("}\n");
+  return 0;
+}
+
+static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+/* CPU baseline: the reference rtlib timed on this host (single thread, as published: README.md:94) */
+static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, int reps) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CRT_CONTEXT*    crt = p->_crt_context;
+  size_t          K = p->_num_p_primes;
+  dnum = p->_num_q_parts;
+  Set_rtlib_config(CONF_OP_FUSION_DECOMP_MODUP, 1);
+  POLYNOMIAL a, o0, o1;
+  Alloc_poly_data(&a, N, level, 0);
+  fill_uniform(crt, a._data, level, level, N, 1);
+  Set_is_ntt(&a, TRUE);
+  Alloc_poly_data(&o0, N, level, 0);
+  Alloc_poly_data(&o1, N, level, 0);
+  size_t   key_n = dnum * 2 * (L + K) * N;
+  int64_t* key = malloc(sizeof(int64_t) * key_n);
+  for (size_t d = 0; d < dnum * 2; d++) fill_uniform(crt, key + d * (L + K) * N, L + K, L, N, 101 + d);
+  /* NTT fwd+inv on limb 0 */
+  VALUE_LIST vl;
+  int64_t*   buf = malloc(sizeof(int64_t) * N);
+  memcpy(buf, a._data, sizeof(int64_t) * N);
+  Init_i64_value_list_no_copy(&vl, N, buf);
+  int    ntt_reps = reps * 20;
+  double t0 = now_s();
+  for (int r = 0; r < ntt_reps; r++) Ftt_fwd(&vl, Get_ntt(prime_at(crt, 0)), &vl);
+  double t_fwd = (now_s() - t0) / ntt_reps;
+  t0 = now_s();
+  for (int r = 0; r < ntt_reps; r++) Ftt_inv(&vl, Get_ntt(prime_at(crt, 0)), &vl);
+  double t_inv = (now_s() - t0) / ntt_reps;
+  t0 = now_s();
+  for (int r = 0; r < reps; r++) ref_key_switch(crt, &o0, &o1, &a, key, level, L, K, N);
+  double t_ks = (now_s() - t0) / reps;
+  printf("{\"kind\": \"reference\", \"N\": %u, \"L\": %zu, \"dnum\": %zu, \"K\": %zu, \"level\": %zu, \"reps\": %d, "
+         "\"ntt_fwd_s\": %.9f, \"ntt_inv_s\": %.9f, \"key_switch_s\": %.9f, \"ks_sum64\": %llu}\n",
+         N, L, dnum, K, level, reps, t_fwd, t_inv, t_ks, sum64(o0._data, level * N));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 7) {
+    fprintf(stderr, "usage: %s params|ops|bench N L q0 sf dnum [level seed|reps]\n", argv[0]);
+    return 2;
+  }
+  uint32_t N = (uint32_t)atoi(argv[2]);
+  size_t   L = atoi(argv[3]), q0 = atoi(argv[4]), sf = atoi(argv[5]), dnum = atoi(argv[6]);
+  if (!strcmp(argv[1], "params")) return do_params(N, L, q0, sf, dnum);
+  if (!strcmp(argv[1], "ops")) return do_ops(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
+  if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1);
+  return 2;
+}
