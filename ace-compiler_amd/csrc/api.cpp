@@ -1,0 +1,488 @@
+// api.cpp -- C ABI (include/acehip.h) over the HIP kernels: context/table upload, workspace, and the
+// host-side sequencing of Decomp_modup / Mod_down / Rescale / key-switch.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/acehip.h"
+#include "host_params.hpp"
+#include "kernels.hpp"
+
+using namespace acehip;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(ACEHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static_assert(sizeof(PrimeConsts) == sizeof(DevPrime), "host/device prime layout mismatch");
+
+namespace {
+
+struct DevModUp {
+  u32 n2 = 0, nc = 0, start = 0;
+  u64 *hat_inv = nullptr, *hat_inv_prec = nullptr, *hat_mod = nullptr;
+  u32 *src_gi = nullptr, *out_gi = nullptr, *out_pos = nullptr;
+};
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+  T* d = nullptr;
+  if (v.empty()) return nullptr;
+  if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return d;
+}
+
+}  // namespace
+
+struct acehip_ctx {
+  HostParams hp;
+  bool on_device = false;
+  int device = -1;
+  DevCtx dc{};
+  std::vector<void*> owned;  // device allocations freed at destroy
+  // device CRT tables
+  u64 *phat_inv = nullptr, *phat_inv_prec = nullptr, *phat_modq_t = nullptr, *pinv = nullptr, *pinv_prec = nullptr;
+  u64 *ql_inv = nullptr, *ql_inv_prec = nullptr, *qlql = nullptr, *qlql_prec = nullptr;
+  u32 *p_gi = nullptr;                     // [K] global indices of the p primes
+  u32 *q_gi = nullptr, *q_pos = nullptr;   // [L] identity lists for ModDown targets
+  std::mutex mu;
+  std::map<std::pair<u32, u32>, DevModUp> modup;
+  std::map<u32, u32*> auto_tabs;
+  // workspace (one per context; launches of one context are expected on one stream at a time)
+  u64* ws = nullptr;
+  size_t ws_words = 0;
+
+  template <typename T>
+  T* up(const std::vector<T>& v) {
+    T* d = upload(v);
+    if (d) owned.push_back(d);
+    return d;
+  }
+};
+
+extern "C" {
+
+const char* acehip_last_error(void) { return g_err.c_str(); }
+
+int acehip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+acehip_ctx* acehip_ctx_create_host(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum) {
+  try {
+    auto* ctx = new acehip_ctx();
+    ctx->hp = make_params(N, L, q0_bits, sf_bits, dnum);
+    return ctx;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum, int device) {
+  if (acehip_device_count() <= device || device < 0) {
+    g_err = "acehip_ctx_create: no such GPU device (the HIP path has no CPU fallback)";
+    return nullptr;
+  }
+  acehip_ctx* ctx = acehip_ctx_create_host(N, L, q0_bits, sf_bits, dnum);
+  if (!ctx) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) {
+    g_err = "hipSetDevice failed";
+    delete ctx;
+    return nullptr;
+  }
+  ctx->device = device;
+  const HostParams& hp = ctx->hp;
+  const u32 T = hp.L + hp.K;
+  std::vector<DevPrime> dp(T);
+  std::memcpy(dp.data(), hp.primes.data(), T * sizeof(DevPrime));
+  ctx->dc.primes = ctx->up(dp);
+  ctx->dc.rou = ctx->up(hp.rou);
+  ctx->dc.rou_prec = ctx->up(hp.rou_prec);
+  ctx->dc.rou_inv = ctx->up(hp.rou_inv);
+  ctx->dc.rou_inv_prec = ctx->up(hp.rou_inv_prec);
+  ctx->dc.N = hp.N;
+  ctx->dc.logN = hp.logN;
+  ctx->dc.L = hp.L;
+  ctx->dc.K = hp.K;
+  ctx->phat_inv = ctx->up(hp.phat_inv_modp);
+  ctx->phat_inv_prec = ctx->up(hp.phat_inv_modp_prec);
+  // base_conv wants hat[i_src][j_dst]: transpose phat_modq[L][K] -> [K][L]
+  std::vector<u64> tr((size_t)hp.K * hp.L);
+  for (u32 i = 0; i < hp.L; ++i)
+    for (u32 j = 0; j < hp.K; ++j) tr[(size_t)j * hp.L + i] = hp.phat_modq[(size_t)i * hp.K + j];
+  ctx->phat_modq_t = ctx->up(tr);
+  ctx->pinv = ctx->up(hp.pinv_modq);
+  ctx->pinv_prec = ctx->up(hp.pinv_modq_prec);
+  ctx->ql_inv = ctx->up(hp.ql_inv);
+  ctx->ql_inv_prec = ctx->up(hp.ql_inv_prec);
+  ctx->qlql = ctx->up(hp.qlql);
+  ctx->qlql_prec = ctx->up(hp.qlql_prec);
+  std::vector<u32> pgi(hp.K), qgi(hp.L);
+  for (u32 j = 0; j < hp.K; ++j) pgi[j] = hp.L + j;
+  for (u32 i = 0; i < hp.L; ++i) qgi[i] = i;
+  ctx->p_gi = ctx->up(pgi);
+  ctx->q_gi = ctx->up(qgi);
+  ctx->q_pos = ctx->q_gi;
+  // workspace: ext (L+K) + two accumulators (L+K each) + scratch (L+K) limbs
+  ctx->ws_words = (size_t)4 * T * hp.N;
+  if (hipMalloc(&ctx->ws, ctx->ws_words * sizeof(u64)) != hipSuccess || !ctx->dc.primes || !ctx->dc.rou_inv_prec) {
+    g_err = "acehip_ctx_create: device allocation/upload failed";
+    acehip_ctx_destroy(ctx);
+    return nullptr;
+  }
+  ctx->owned.push_back(ctx->ws);
+  ctx->on_device = true;
+  return ctx;
+}
+
+void acehip_ctx_destroy(acehip_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  for (void* p : ctx->owned) (void)hipFree(p);
+  delete ctx;
+}
+
+uint32_t acehip_degree(const acehip_ctx* c) { return c->hp.N; }
+uint32_t acehip_num_q(const acehip_ctx* c) { return c->hp.L; }
+uint32_t acehip_num_p(const acehip_ctx* c) { return c->hp.K; }
+uint32_t acehip_num_q_parts(const acehip_ctx* c) { return c->hp.dnum; }
+uint32_t acehip_part_size(const acehip_ctx* c) { return c->hp.alpha; }
+uint32_t acehip_num_decomp(const acehip_ctx* c, uint32_t level) { return c->hp.num_decomp(level); }
+uint64_t acehip_prime(const acehip_ctx* c, uint32_t gi) { return gi < c->hp.L + c->hp.K ? c->hp.primes[gi].q : 0; }
+
+int64_t acehip_get_table(const acehip_ctx* c, int what, uint32_t gi, uint64_t* out, size_t cap) {
+  const HostParams& hp = c->hp;
+  const u32 T = hp.L + hp.K;
+  auto copy = [&](const u64* src, size_t n) -> int64_t {
+    if (cap < n) return fail(ACEHIP_EINVAL, "acehip_get_table: buffer too small");
+    std::memcpy(out, src, n * sizeof(u64));
+    return (int64_t)n;
+  };
+  if (what >= 0 && what <= 4) {
+    if (cap < T) return fail(ACEHIP_EINVAL, "acehip_get_table: buffer too small");
+    for (u32 i = 0; i < T; ++i) {
+      const PrimeConsts& p = hp.primes[i];
+      out[i] = what == 0 ? p.psi : what == 1 ? p.n_inv : what == 2 ? p.n_inv_prec : what == 3 ? p.prec128_lo : p.prec128_hi;
+    }
+    return T;
+  }
+  if (what >= 10 && what <= 13) {
+    if (gi >= T) return fail(ACEHIP_EINVAL, "acehip_get_table: bad prime index");
+    const std::vector<u64>& v = what == 10 ? hp.rou : what == 11 ? hp.rou_prec : what == 12 ? hp.rou_inv : hp.rou_inv_prec;
+    return copy(v.data() + (size_t)gi * hp.N, hp.N);
+  }
+  switch (what) {
+    case 20: return copy(hp.phat_inv_modp.data(), hp.K);
+    case 21: return copy(hp.phat_inv_modp_prec.data(), hp.K);
+    case 22: return copy(hp.phat_modq.data(), (size_t)hp.L * hp.K);
+    case 23: return copy(hp.pinv_modq.data(), hp.L);
+    case 30: return copy(hp.ql_inv.data(), (size_t)hp.L * hp.L);
+    case 31: return copy(hp.ql_inv_prec.data(), (size_t)hp.L * hp.L);
+    case 32: return copy(hp.qlql.data(), (size_t)hp.L * hp.L);
+    case 33: return copy(hp.qlql_prec.data(), (size_t)hp.L * hp.L);
+  }
+  return fail(ACEHIP_EINVAL, "acehip_get_table: unknown table id");
+}
+
+int acehip_get_modup_tables(const acehip_ctx* c, uint32_t level, uint32_t digit, uint64_t* hat_inv,
+                            uint32_t* compl_idx, uint64_t* hat_mod, uint32_t* nc_out) {
+  if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "bad level/digit");
+  HostParams::ModUp t = c->hp.modup(level, digit);
+  std::memcpy(hat_inv, t.hat_inv.data(), t.n2 * sizeof(u64));
+  std::memcpy(compl_idx, t.compl_idx.data(), t.nc * sizeof(u32));
+  std::memcpy(hat_mod, t.hat_mod.data(), (size_t)t.n2 * t.nc * sizeof(u64));
+  *nc_out = t.nc;
+  return (int)t.n2;
+}
+
+uint32_t acehip_auto_index(const acehip_ctx* c, int32_t rot_idx) { return find_automorphism_index(rot_idx, c->hp.N); }
+
+int acehip_auto_order_host(const acehip_ctx* c, uint32_t k, uint32_t* out_perm) {
+  if ((k & 1) == 0 || k >= 2 * c->hp.N) return fail(ACEHIP_EINVAL, "automorphism index must be odd and < 2N");
+  automorphism_order_ntt(out_perm, k, c->hp.N);
+  return ACEHIP_OK;
+}
+
+const uint32_t* acehip_auto_order(acehip_ctx* c, uint32_t k) {
+  if (!c->on_device) {
+    g_err = "acehip_auto_order: context has no device";
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto it = c->auto_tabs.find(k);
+  if (it != c->auto_tabs.end()) return it->second;
+  std::vector<u32> perm(c->hp.N);
+  if (acehip_auto_order_host(c, k, perm.data()) != ACEHIP_OK) return nullptr;
+  (void)hipSetDevice(c->device);
+  u32* d = c->up(perm);
+  if (!d) {
+    g_err = "acehip_auto_order: upload failed";
+    return nullptr;
+  }
+  c->auto_tabs[k] = d;
+  return d;
+}
+
+// ---- memory helpers ----
+void* acehip_malloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    g_err = "hipMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+int acehip_free(void* p) {
+  HIP_TRY(hipFree(p));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_h2d(void* d, const void* h, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_d2h(void* h, const void* d, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_d2d(void* d, const void* s_, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_memset(void* d, int v, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemsetAsync(d, v, n, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_stream_sync(acehip_stream s) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+void* acehip_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) {
+    g_err = "hipEventCreate failed";
+    return nullptr;
+  }
+  return (void*)e;
+}
+int acehip_event_record(void* e, acehip_stream s) {
+  HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_event_elapsed_ms(void* a, void* b, float* ms) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return ACEHIP_OK;
+}
+int acehip_event_destroy(void* e) {
+  HIP_TRY(hipEventDestroy((hipEvent_t)e));
+  return ACEHIP_OK;
+}
+
+}  // extern "C"
+
+// ---- argument checks shared by the launch entry points ----
+static int check_dev(acehip_ctx* c) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if (!c->on_device) return fail(ACEHIP_ENODEV, "context was created without a GPU; the HIP path has no CPU fallback");
+  return ACEHIP_OK;
+}
+static int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n) {
+  if (int e = check_dev(c)) return e;
+  if (level > c->hp.L) return fail(ACEHIP_EINVAL, "level exceeds the number of q primes");
+  if (pos0 + n > level + c->hp.K) return fail(ACEHIP_EINVAL, "limb range exceeds level + K");
+  return ACEHIP_OK;
+}
+static int post_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ACEHIP_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return ACEHIP_OK;
+}
+
+static const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto key = std::make_pair(level, digit);
+  auto it = c->modup.find(key);
+  if (it != c->modup.end()) return &it->second;
+  HostParams::ModUp t = c->hp.modup(level, digit);
+  DevModUp d;
+  d.n2 = t.n2;
+  d.nc = t.nc;
+  d.start = t.start;
+  std::vector<u32> src_gi(t.n2), pos(t.nc);
+  for (u32 i = 0; i < t.n2; ++i) src_gi[i] = t.start + i;
+  for (u32 j = 0; j < t.nc; ++j) pos[j] = t.compl_idx[j] < c->hp.L ? t.compl_idx[j] : level + (t.compl_idx[j] - c->hp.L);
+  d.hat_inv = c->up(t.hat_inv);
+  d.hat_inv_prec = c->up(t.hat_inv_prec);
+  d.hat_mod = c->up(t.hat_mod);
+  d.src_gi = c->up(src_gi);
+  d.out_gi = c->up(t.compl_idx);
+  d.out_pos = c->up(pos);
+  if (!d.hat_inv || !d.hat_mod || !d.out_pos) return nullptr;
+  return &(c->modup[key] = d);
+}
+
+// workspace carving (in limbs of N words)
+static u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
+
+static int do_decomp_modup(acehip_ctx* c, u64* out, const u64* in, u32 level, u32 digit, u64* scratch, hipStream_t s) {
+  const HostParams& hp = c->hp;
+  const DevModUp* t = get_modup(c, level, digit);
+  if (!t) return fail(ACEHIP_EHIP, "ModUp table upload failed");
+  const size_t N = hp.N;
+  // digit limbs pass through unchanged (polynomial.c:1265-1273)
+  HIP_TRY(hipMemcpyAsync(out + t->start * N, in + t->start * N, t->n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  // iNTT of the digit limbs in scratch, scaled by (Q_d/q_i)^-1 mod q_i (polynomial.c:1276-1301)
+  HIP_TRY(hipMemcpyAsync(scratch, in + t->start * N, t->n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  // scratch limb i has prime start+i: run the iNTT as "positions [start, start+n2) of a level-L poly"
+  launch_ntt(c->dc, scratch, hp.L, t->start, t->n2, true, s, t->start);
+  launch_mul_const(c->dc, scratch, scratch, t->hat_inv, t->hat_inv_prec, t->src_gi, t->n2, s);
+  // exact 128-bit sums + reduction into the complement limbs (polynomial.c:1302-1320)
+  launch_base_conv(c->dc, out, scratch, t->hat_mod, t->out_gi, t->out_pos, t->n2, t->nc, t->nc, s);
+  // NTT of the complement limbs (polynomial.c:1322-1329)
+  launch_ntt(c->dc, out, level, 0, t->start, false, s);
+  launch_ntt(c->dc, out, level, t->start + t->n2, level + hp.K - (t->start + t->n2), false, s);
+  return post_launch();
+}
+
+static int do_mod_down(acehip_ctx* c, u64* out, const u64* in, u32 level, u64* scratch, hipStream_t s) {
+  const HostParams& hp = c->hp;
+  const size_t N = hp.N;
+  // P part -> coefficient domain, times (P/p_j)^-1 mod p_j  (polynomial.c:941-945, 779-790)
+  HIP_TRY(hipMemcpyAsync(scratch, in + level * N, hp.K * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  launch_ntt(c->dc, scratch, 0, 0, hp.K, true, s);  // level 0: position j -> prime p_j
+  launch_mul_const(c->dc, scratch, scratch, c->phat_inv, c->phat_inv_prec, c->p_gi, hp.K, s);
+  // conv P -> Q (polynomial.c:791-803); phat_modq_t is [K][L]: use its first `level` columns via n_out = L stride
+  launch_base_conv(c->dc, out, scratch, c->phat_modq_t, c->q_gi, c->q_pos, hp.K, level, hp.L, s);
+  launch_ntt(c->dc, out, level, 0, level, false, s);
+  launch_moddown_tail(c->dc, out, in, c->pinv, c->pinv_prec, level, s);
+  return post_launch();
+}
+
+extern "C" {
+
+int acehip_ntt_forward(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  launch_ntt(c->dc, d, level, pos0, n, false, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  launch_ntt(c->dc, d, level, pos0, n, true, (hipStream_t)s);
+  return post_launch();
+}
+
+static int ew(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  launch_ew(c->dc, op, r, a, b, level, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_modadd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) { return ew(c, EwOp::Add, r, a, b, level, pos0, n, s); }
+int acehip_modsub(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) { return ew(c, EwOp::Sub, r, a, b, level, pos0, n, s); }
+int acehip_modmul(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) { return ew(c, EwOp::Mul, r, a, b, level, pos0, n, s); }
+int acehip_modmuladd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) { return ew(c, EwOp::MulAdd, r, a, b, level, pos0, n, s); }
+
+int acehip_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32_t* perm, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (r == a) return fail(ACEHIP_EINVAL, "acehip_rotate: in-place rotation is not supported");
+  launch_rotate(c->dc, r, a, perm, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+
+// single-limb forms: the limb pointers are used directly; prime_gi selects the modulus
+static int hw(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 gi, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  const u32 L = c->hp.L;
+  if (gi >= L + c->hp.K) return fail(ACEHIP_EINVAL, "prime index out of range");
+  if (gi < L) launch_ew(c->dc, op, r, a, b, L, gi, 1, (hipStream_t)s, gi);
+  else launch_ew(c->dc, op, r, a, b, 0, gi - L, 1, (hipStream_t)s, gi - L);
+  return post_launch();
+}
+int acehip_hw_modadd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t gi, acehip_stream s) { return hw(c, EwOp::Add, r, a, b, gi, s); }
+int acehip_hw_modmul(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t gi, acehip_stream s) { return hw(c, EwOp::Mul, r, a, b, gi, s); }
+int acehip_hw_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32_t* perm, uint32_t gi, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (gi >= c->hp.L + c->hp.K) return fail(ACEHIP_EINVAL, "prime index out of range");
+  if (r == a) return fail(ACEHIP_EINVAL, "acehip_hw_rotate: in-place rotation is not supported");
+  launch_rotate(c->dc, r, a, perm, 0, 1, (hipStream_t)s);
+  return post_launch();
+}
+
+int acehip_decomp_modup(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, uint32_t digit, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp_modup: bad level/digit");
+  (void)hipSetDevice(c->device);
+  return do_decomp_modup(c, out, in, level, digit, ws_at(c, 0), (hipStream_t)s);
+}
+
+int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down: bad level");
+  if (out == in) return fail(ACEHIP_EINVAL, "acehip_mod_down: out must not alias in");
+  return do_mod_down(c, out, in, level, ws_at(c, 0), (hipStream_t)s);
+}
+
+int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale: level must be in [2, L]");
+  const HostParams& hp = c->hp;
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = hp.N;
+  u64* last = ws_at(c, 0);
+  u64* t = ws_at(c, 1);
+  HIP_TRY(hipMemcpyAsync(last, in + (size_t)(level - 1) * N, N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1);
+  const size_t row = (size_t)(level - 2) * hp.L;
+  launch_rescale_spread(c->dc, t, last, c->qlql + row, c->qlql_prec + row, level, s);
+  launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s);
+  launch_rescale_tail(c->dc, out, in, t, c->ql_inv + row, c->ql_inv_prec + row, level, s);
+  return post_launch();
+}
+
+int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key,
+                      uint32_t level, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_switch: bad level");
+  const HostParams& hp = c->hp;
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = hp.N, T = hp.L + hp.K;
+  u64* scratch = ws_at(c, 0);
+  u64* ext = ws_at(c, T);
+  u64* acc0 = ws_at(c, 2 * T);
+  u64* acc1 = ws_at(c, 3 * T);
+  const u32 nd = hp.num_decomp(level);
+  for (u32 d = 0; d < nd; ++d) {
+    if (int e = do_decomp_modup(c, ext, in, level, d, scratch, s)) return e;
+    const u64* k0 = key + ((size_t)d * 2 + 0) * T * N;
+    const u64* k1 = key + ((size_t)d * 2 + 1) * T * N;
+    launch_key_mac(c->dc, acc0, acc1, k0, k1, ext, level, d != 0, s);
+  }
+  if (int e = do_mod_down(c, out0, acc0, level, scratch, s)) return e;
+  if (int e = do_mod_down(c, out1, acc1, level, scratch, s)) return e;
+  return post_launch();
+}
+
+uint64_t acehip_key_switch_bytes(const acehip_ctx* c, uint32_t level) {
+  const HostParams& hp = c->hp;
+  const u64 b = hp.num_decomp(level);
+  return 8ull * hp.N * (level + 2 * b * (level + hp.K) + 2 * level);
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// device_arith.hpp -- 64-bit modular arithmetic for gfx950 (wave64, no MFMA: integer work).
+//
+// All routines return canonical residues in [0, q), so they are bit-identical to the reference's
+// Barrett / Shoup code (fhe_utils.h:241-318) whatever the reduction strategy.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace acehip {
+
+using u64 = uint64_t;
+using u32 = uint32_t;
+
+// Per-prime constants in HBM (layout shared with host_params.hpp::PrimeConsts)
+struct DevPrime {
+  u64 q;
+  u64 barrett_mu;
+  u32 nbits;
+  u32 pad;
+  u64 prec128_lo, prec128_hi;
+  u64 psi;
+  u64 n_inv, n_inv_prec;
+  u64 inv_w1_ninv, inv_w1_ninv_prec;
+};
+
+__device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+
+__device__ __forceinline__ u64 add_mod(u64 a, u64 b, u64 q) {
+  u64 s = a + b;
+  return s >= q ? s - q : s;
+}
+__device__ __forceinline__ u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+
+// Shoup multiplication by a constant w with companion wp = floor(w*2^64/q); a may be any 64-bit
+// value, result canonical (reference Fast_mul_const_with_mod, fhe_utils.h:311-318).
+__device__ __forceinline__ u64 mul_shoup(u64 a, u64 w, u64 wp, u64 q) {
+  u64 hi = mulhi64(a, wp);
+  u64 r  = a * w - hi * q;
+  return r >= q ? r - q : r;
+}
+// lazy variant: result in [0, 2q)
+__device__ __forceinline__ u64 mul_shoup_lazy(u64 a, u64 w, u64 wp, u64 q) {
+  u64 hi = mulhi64(a, wp);
+  return a * w - hi * q;
+}
+
+// a*b mod q for a,b < q < 2^61: single-word Barrett on the shifted product.
+//   x = a*b < 2^(2n); x1 = x >> (n-1); qhat = mulhi(x1, mu << (63-n)) = floor(x1*mu / 2^(n+1));
+//   x - qhat*q in [0, 3q)
+__device__ __forceinline__ u64 mul_mod(u64 a, u64 b, u64 q, u64 mu, u32 nbits) {
+  u64 lo = a * b, hi = mulhi64(a, b);
+  u32 sh = nbits - 1;
+  u64 x1 = (hi << (64 - sh)) | (lo >> sh);
+  u64 qh = mulhi64(x1, mu);
+  u64 r  = lo - qh * q;
+  r = r >= 2 * q ? r - 2 * q : r;
+  return r >= q ? r - q : r;
+}
+__device__ __forceinline__ u64 mul_mod(u64 a, u64 b, const DevPrime& p) {
+  return mul_mod(a, b, p.q, p.barrett_mu, p.nbits);
+}
+
+// 128-bit accumulator for the base-conversion sums
+struct U128 {
+  u64 lo, hi;
+};
+__device__ __forceinline__ void mac128(U128& acc, u64 a, u64 b) {
+  u64 plo = a * b, phi = mulhi64(a, b);
+  u64 lo = acc.lo + plo;
+  acc.hi += phi + (lo < plo ? 1 : 0);
+  acc.lo = lo;
+}
+
+// (hi:lo) mod q with mu = floor(2^128/q) = (mh:ml); same quotient estimate as the reference's
+// Mod_barrett_128 (fhe_utils.h:241-280); the estimate is at most 2 below the true quotient.
+__device__ __forceinline__ u64 reduce128(U128 v, u64 q, u64 ml, u64 mh) {
+  u64 left_h = mulhi64(v.lo, ml);
+  u64 mid_l = v.lo * mh, mid_h = mulhi64(v.lo, mh);
+  u64 t1 = mid_l + left_h;
+  u64 t2 = mid_h + (t1 < left_h ? 1 : 0);
+  u64 m2_l = v.hi * ml, m2_h = mulhi64(v.hi, ml);
+  u64 carry = (m2_l + t1) < t1 ? 1 : 0;
+  u64 qhat = v.hi * mh + t2 + m2_h + carry;
+  u64 r = v.lo - qhat * q;
+  while (r >= q) r -= q;
+  return r;
+}
+
+// Switch_modulus (fhe_utils.h:349-375): centred lift of v in [0,old_q) to [0,new_q)
+__device__ __forceinline__ u64 switch_modulus(u64 v, u64 old_q, u64 new_q) {
+  u64 half = old_q >> 1;
+  if (new_q > old_q) return v > half ? v + (new_q - old_q) : v;
+  u64 diff = new_q - (old_q % new_q);
+  u64 r = v > half ? v + diff : v;
+  return r >= new_q ? r % new_q : r;
+}
+
+}  // namespace acehip

@@ -1,0 +1,362 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): negacyclic NTT/iNTT, limb-wise modular
+// ops, RNS base conversion, ModDown/Rescale tails, key inner product.
+//
+// Everything here is 64-bit integer modular arithmetic (no MFMA).  The kernels are HBM-bandwidth
+// bound by design: limb-major [limb][N] layout, 16-byte per-lane accesses, LDS-staged butterflies.
+// Reference algorithms: fhe-cmplr/rtlib/ant/src/util/{ntt.c,polynomial.c}, src/poly/poly_arith.c.
+#include "kernels.hpp"
+
+namespace acehip {
+
+// ------------------------------------------------------------------------------------------------
+// NTT passes.
+//
+// A pass performs `r` consecutive radix-2 stages [s0, s0+r) of the length-N transform on a tile held
+// in LDS.  At stage s (m = 2^s butterfly groups, half-distance t = N / 2^(s+1)) the butterfly pairs
+// differ in bit (logN-1-s) of the coefficient index j, and the twiddle is W[m + (j >> (logN-s))]
+// (reference ntt.c:206-236: omega = rous[i + m], i = block index).  So a pass touches index bits
+// [logN-s0-r, logN-s0): "rows"; the bits above are the outer block `o`, the bits below the column.
+//   STRIDED tile : R = 2^r rows x C adjacent columns (C <= S = 2^(logN-s0-r)), LDS index row*C + col
+//   CONTIG  tile : S = 1; C consecutive outer blocks of R contiguous elements, LDS index col*R + row
+// Forward (Cooley-Tukey, natural -> bit-reversed): stages ascending.  Inverse (Gentleman-Sande,
+// bit-reversed -> natural): stages descending, N^-1 folded into the last stage (s = 0).  All values
+// stay canonical in [0,q), hence bit-identical to the reference whatever the stage grouping.
+// ------------------------------------------------------------------------------------------------
+template <bool CONTIG, bool INVERSE>
+__global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict__ poly, u32 level, u32 pos0, u32 pos_off,
+                                                       u32 s0, u32 r, u32 log_c) {
+  extern __shared__ u64 tile[];
+  const u32 pos = pos0 + blockIdx.y;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime P = c.primes[gi];
+  const u64 q = P.q;
+  u64* x = poly + (size_t)(pos - pos_off) * c.N;
+  const u64* W = (INVERSE ? c.rou_inv : c.rou) + (size_t)gi * c.N;
+  const u64* WP = (INVERSE ? c.rou_inv_prec : c.rou_prec) + (size_t)gi * c.N;
+  const u32 R = 1u << r, C = 1u << log_c;
+  const u32 log_s = c.logN - s0 - r;
+  const u32 chunk = blockIdx.x, tid = threadIdx.x;
+  const u32 tile_elems = R * C;
+  const u32 o_strided = (chunk << log_c) >> log_s;  // C <= S: one outer block per tile
+  const u32 ci0 = (chunk << log_c) & ((1u << log_s) - 1);
+
+  for (u32 e = tid; e < tile_elems; e += 256) {
+    size_t j;
+    if (CONTIG) {
+      j = (size_t)chunk * tile_elems + e;
+    } else {
+      u32 row = e >> log_c, cc = e & (C - 1);
+      j = ((size_t)o_strided << (r + log_s)) | ((size_t)row << log_s) | (ci0 + cc);
+    }
+    tile[e] = x[j];
+  }
+  __syncthreads();
+
+  const u32 n_bfly = tile_elems >> 1;
+  for (u32 step = 0; step < r; ++step) {
+    const u32 ss = INVERSE ? (r - 1 - step) : step;  // stage offset inside the pass
+    const u32 s = s0 + ss;
+    const u32 log_half = r - 1 - ss, half = 1u << log_half;
+    for (u32 b = tid; b < n_bfly; b += 256) {
+      u32 col, pr, o;
+      if (CONTIG) {
+        pr = b & ((R >> 1) - 1);
+        col = b >> (r - 1);
+        o = chunk * C + col;
+      } else {
+        col = b & (C - 1);
+        pr = b >> log_c;
+        o = o_strided;
+      }
+      const u32 grp = pr >> log_half, k = pr & (half - 1);
+      const u32 row_lo = (grp << (log_half + 1)) | k;
+      u32 i_lo, i_hi;
+      if (CONTIG) {
+        i_lo = col * R + row_lo;
+        i_hi = i_lo + half;
+      } else {
+        i_lo = row_lo * C + col;
+        i_hi = i_lo + half * C;
+      }
+      const u32 tw = (1u << s) + (o << ss) + grp;
+      const u64 u = tile[i_lo], v = tile[i_hi];
+      if (!INVERSE) {
+        const u64 wv = mul_shoup(v, W[tw], WP[tw], q);
+        tile[i_lo] = add_mod(u, wv, q);
+        tile[i_hi] = sub_mod(u, wv, q);
+      } else if (s != 0) {
+        tile[i_lo] = add_mod(u, v, q);
+        tile[i_hi] = mul_shoup(sub_mod(u, v, q), W[tw], WP[tw], q);
+      } else {  // last inverse stage: fold N^-1 (reference folds it into its first stage, ntt.c:282-317)
+        tile[i_lo] = mul_shoup(add_mod(u, v, q), P.n_inv, P.n_inv_prec, q);
+        tile[i_hi] = mul_shoup(sub_mod(u, v, q), P.inv_w1_ninv, P.inv_w1_ninv_prec, q);
+      }
+    }
+    __syncthreads();
+  }
+
+  for (u32 e = tid; e < tile_elems; e += 256) {
+    size_t j;
+    if (CONTIG) {
+      j = (size_t)chunk * tile_elems + e;
+    } else {
+      u32 row = e >> log_c, cc = e & (C - 1);
+      j = ((size_t)o_strided << (r + log_s)) | ((size_t)row << log_s) | (ci0 + cc);
+    }
+    x[j] = tile[e];
+  }
+}
+
+template <bool CONTIG, bool INVERSE>
+static void launch_pass(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 pos_off, u32 n_limbs, u32 s0, u32 r,
+                        u32 log_c, hipStream_t s) {
+  const u32 tiles = c.N >> (r + log_c);
+  dim3 grid(tiles, n_limbs), block(256);
+  size_t lds = sizeof(u64) << (r + log_c);
+  hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, level, pos0, pos_off, s0, r, log_c);
+}
+
+void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off) {
+  if (n_limbs == 0) return;
+  const u32 logN = c.logN;
+  if (logN <= 12) {  // whole limb in LDS (<= 32 KiB): one pass
+    if (!inverse) launch_pass<true, false>(c, poly, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
+    else          launch_pass<true, true>(c, poly, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
+    return;
+  }
+  // two passes: r1 strided stages (column tiles of 16 x 128 B row segments), then 8 contiguous stages
+  const u32 r2 = 8, r1 = logN - r2, log_c = 4;
+  if (!inverse) {
+    launch_pass<false, false>(c, poly, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
+    launch_pass<true, false>(c, poly, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
+  } else {
+    launch_pass<true, true>(c, poly, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
+    launch_pass<false, true>(c, poly, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// limb-wise elementwise ops (Hw_modadd / Hw_modmul poly_arith.c:14-39, Multiply_add polynomial.c:148)
+// grid: (ceil(N/512), n_limbs); each lane handles 2 coefficients (16-byte accesses)
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
+                                                 const u64* __restrict__ b, u32 level, u32 pos0, u32 pos_off) {
+  const u32 pos = pos0 + blockIdx.y;
+  const DevPrime P = c.primes[limb_prime(pos, level, c.L)];
+  const size_t base = (size_t)(pos - pos_off) * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const ulong2 va = *reinterpret_cast<const ulong2*>(a + base + i);
+  const ulong2 vb = *reinterpret_cast<const ulong2*>(b + base + i);
+  ulong2 vr;
+  if (OP == 0) {
+    vr.x = add_mod(va.x, vb.x, P.q);
+    vr.y = add_mod(va.y, vb.y, P.q);
+  } else if (OP == 1) {
+    vr.x = sub_mod(va.x, vb.x, P.q);
+    vr.y = sub_mod(va.y, vb.y, P.q);
+  } else if (OP == 2) {
+    vr.x = mul_mod(va.x, vb.x, P);
+    vr.y = mul_mod(va.y, vb.y, P);
+  } else {
+    const ulong2 acc = *reinterpret_cast<const ulong2*>(r + base + i);
+    vr.x = add_mod(acc.x, mul_mod(va.x, vb.x, P), P.q);
+    vr.y = add_mod(acc.y, mul_mod(va.y, vb.y, P), P.q);
+  }
+  *reinterpret_cast<ulong2*>(r + base + i) = vr;
+}
+
+void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs,
+               hipStream_t s, u32 pos_off) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  switch (op) {
+    case EwOp::Add: hipLaunchKernelGGL(ew_kernel<0>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
+    case EwOp::Sub: hipLaunchKernelGGL(ew_kernel<1>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
+    case EwOp::Mul: hipLaunchKernelGGL(ew_kernel<2>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
+    case EwOp::MulAdd: hipLaunchKernelGGL(ew_kernel<3>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
+  }
+}
+
+// Hw_rotate (poly_arith.c:41-56) with an NTT-domain table: pure gather r[j] = a[perm[j]]
+__global__ __launch_bounds__(256) void rotate_kernel(u32 N, u64* __restrict__ r, const u64* __restrict__ a,
+                                                     const u32* __restrict__ perm, u32 pos0) {
+  const size_t base = (size_t)(pos0 + blockIdx.y) * N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= N) return;
+  const uint2 p = *reinterpret_cast<const uint2*>(perm + i);
+  ulong2 v;
+  v.x = a[base + p.x];
+  v.y = a[base + p.y];
+  *reinterpret_cast<ulong2*>(r + base + i) = v;
+}
+
+void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 pos0, u32 n_limbs, hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(rotate_kernel, grid, block, 0, s, c.N, r, a, perm, pos0);
+}
+
+// r[l][n] = a[l][n] * w[l] mod prime(gi[l])   (Shoup; per-limb constants in HBM)
+__global__ __launch_bounds__(256) void mul_const_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
+                                                        const u64* __restrict__ w, const u64* __restrict__ wp,
+                                                        const u32* __restrict__ gi) {
+  const u32 l = blockIdx.y;
+  const u64 q = c.primes[gi[l]].q, wl = w[l], wpl = wp[l];
+  const size_t base = (size_t)l * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  ulong2 v = *reinterpret_cast<const ulong2*>(a + base + i);
+  v.x = mul_shoup(v.x, wl, wpl, q);
+  v.y = mul_shoup(v.y, wl, wpl, q);
+  *reinterpret_cast<ulong2*>(r + base + i) = v;
+}
+
+void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const u64* wp, const u32* gi, u32 n_limbs,
+                      hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(mul_const_kernel, grid, block, 0, s, c, r, a, w, wp, gi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNS base conversion (Fast_base_conv polynomial.c:755-807, Decompose_modup :1297-1320):
+//   out[pos_j][n] = ( sum_i in[i][n] * hat[i][j] ) mod t_j,  exact 128-bit sum then one reduction.
+// One lane per coefficient; the n_in source residues stay in registers and are reused for the
+// JG output limbs of this workgroup (blockIdx.y selects the group).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxConvIn = 16;  // alpha and K are <= 12 for every parameter set of the reference
+constexpr int kConvGroup = 4;
+
+__global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ in,
+                                                        const u64* __restrict__ hat, const u32* __restrict__ out_gi,
+                                                        const u32* __restrict__ out_pos, u32 n_in, u32 n_out,
+                                                        u32 hat_ld) {
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= c.N) return;
+  u64 y[kMaxConvIn];
+#pragma unroll
+  for (int i = 0; i < kMaxConvIn; ++i) y[i] = (u32)i < n_in ? in[(size_t)i * c.N + n] : 0;
+  const u32 j0 = blockIdx.y * kConvGroup;
+  for (u32 j = j0; j < j0 + kConvGroup && j < n_out; ++j) {
+    const DevPrime P = c.primes[out_gi[j]];
+    U128 acc{0, 0};
+#pragma unroll
+    for (int i = 0; i < kMaxConvIn; ++i)
+      if ((u32)i < n_in) mac128(acc, y[i], hat[(size_t)i * hat_ld + j]);
+    out[(size_t)out_pos[j] * c.N + n] = reduce128(acc, P.q, P.prec128_lo, P.prec128_hi);
+  }
+}
+
+void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, const u32* out_gi, const u32* out_pos,
+                      u32 n_in, u32 n_out, u32 hat_ld, hipStream_t s) {
+  if (n_out == 0) return;
+  dim3 grid((c.N + 255) / 256, (n_out + kConvGroup - 1) / kConvGroup), block(256);
+  hipLaunchKernelGGL(base_conv_kernel, grid, block, 0, s, c, out, in, hat, out_gi, out_pos, n_in, n_out, hat_ld);
+}
+
+// ModDown tail (Reduce_rns_base polynomial.c:956-965): out = (x - out) * P^-1 mod q_i
+__global__ __launch_bounds__(256) void moddown_tail_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ x,
+                                                           const u64* __restrict__ pinv,
+                                                           const u64* __restrict__ pinv_prec) {
+  const u32 l = blockIdx.y;
+  const u64 q = c.primes[l].q, w = pinv[l], wp = pinv_prec[l];
+  const size_t base = (size_t)l * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
+  ulong2 vo = *reinterpret_cast<const ulong2*>(out + base + i);
+  vo.x = mul_shoup(sub_mod(vx.x, vo.x, q), w, wp, q);
+  vo.y = mul_shoup(sub_mod(vx.y, vo.y, q), w, wp, q);
+  *reinterpret_cast<ulong2*>(out + base + i) = vo;
+}
+
+void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level,
+                         hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level), block(256);
+  hipLaunchKernelGGL(moddown_tail_kernel, grid, block, 0, s, c, out, x, pinv, pinv_prec);
+}
+
+// Rescale (Rescale_poly polynomial.c:1132-1144): spread the iNTT'd last limb to every remaining limb
+__global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* __restrict__ t, const u64* __restrict__ last,
+                                                             const u64* __restrict__ c1, const u64* __restrict__ c1p,
+                                                             u32 level) {
+  const u32 l = blockIdx.y;
+  const u64 q = c.primes[l].q, ql = c.primes[level - 1].q, w = c1[l], wp = c1p[l];
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  ulong2 v = *reinterpret_cast<const ulong2*>(last + i);
+  v.x = mul_shoup(switch_modulus(v.x, ql, q), w, wp, q);
+  v.y = mul_shoup(switch_modulus(v.y, ql, q), w, wp, q);
+  *reinterpret_cast<ulong2*>(t + (size_t)l * c.N + i) = v;
+}
+
+void launch_rescale_spread(const DevCtx& c, u64* t, const u64* last, const u64* c1, const u64* c1p, u32 level,
+                           hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level - 1), block(256);
+  hipLaunchKernelGGL(rescale_spread_kernel, grid, block, 0, s, c, t, last, c1, c1p, level);
+}
+
+// Rescale tail (polynomial.c:1145-1158): out = x * q_l^-1 + t
+__global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ x,
+                                                           const u64* __restrict__ t, const u64* __restrict__ inv,
+                                                           const u64* __restrict__ invp) {
+  const u32 l = blockIdx.y;
+  const u64 q = c.primes[l].q, w = inv[l], wp = invp[l];
+  const size_t base = (size_t)l * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
+  const ulong2 vt = *reinterpret_cast<const ulong2*>(t + base + i);
+  ulong2 vo;
+  vo.x = add_mod(mul_shoup(vx.x, w, wp, q), vt.x, q);
+  vo.y = add_mod(mul_shoup(vx.y, w, wp, q), vt.y, q);
+  *reinterpret_cast<ulong2*>(out + base + i) = vo;
+}
+
+void launch_rescale_tail(const DevCtx& c, u64* out, const u64* x, const u64* t, const u64* inv, const u64* invp,
+                         u32 level, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level - 1), block(256);
+  hipLaunchKernelGGL(rescale_tail_kernel, grid, block, 0, s, c, out, x, t, inv, invp);
+}
+
+// key inner product for one digit (generated code inc:7011-7036 == Multiply_add polynomial.c:148-183)
+template <bool ACC>
+__global__ __launch_bounds__(256) void key_mac_kernel(DevCtx c, u64* __restrict__ acc0, u64* __restrict__ acc1,
+                                                      const u64* __restrict__ key0, const u64* __restrict__ key1,
+                                                      const u64* __restrict__ ext, u32 level) {
+  const u32 pos = blockIdx.y;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime P = c.primes[gi];
+  const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const ulong2 e = *reinterpret_cast<const ulong2*>(ext + pb + i);
+  const ulong2 k0 = *reinterpret_cast<const ulong2*>(key0 + kb + i);
+  const ulong2 k1 = *reinterpret_cast<const ulong2*>(key1 + kb + i);
+  ulong2 r0, r1;
+  r0.x = mul_mod(k0.x, e.x, P);
+  r0.y = mul_mod(k0.y, e.y, P);
+  r1.x = mul_mod(k1.x, e.x, P);
+  r1.y = mul_mod(k1.y, e.y, P);
+  if (ACC) {
+    const ulong2 a0 = *reinterpret_cast<const ulong2*>(acc0 + pb + i);
+    const ulong2 a1 = *reinterpret_cast<const ulong2*>(acc1 + pb + i);
+    r0.x = add_mod(r0.x, a0.x, P.q);
+    r0.y = add_mod(r0.y, a0.y, P.q);
+    r1.x = add_mod(r1.x, a1.x, P.q);
+    r1.y = add_mod(r1.y, a1.y, P.q);
+  }
+  *reinterpret_cast<ulong2*>(acc0 + pb + i) = r0;
+  *reinterpret_cast<ulong2*>(acc1 + pb + i) = r1;
+}
+
+void launch_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext, u32 level,
+                    bool accumulate, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  if (accumulate) hipLaunchKernelGGL(key_mac_kernel<true>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);
+  else            hipLaunchKernelGGL(key_mac_kernel<false>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);
+}
+
+}  // namespace acehip

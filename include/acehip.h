@@ -1,0 +1,134 @@
+/* acehip.h -- C ABI of the MI355X-native RNS-CKKS polynomial layer (libacehip.so).
+ *
+ * This is the drop-in boundary for the hot path of ACE's rt_ant runtime library: each entry point
+ * replaces one reference function (cited per declaration; paths relative to
+ * /root/reference/fhe-cmplr/rtlib/ant) and lands in hand-written HIP kernels for gfx950.
+ * Plain pointers and sizes only; every `d_*` pointer is a DEVICE pointer (HBM).  Residues are
+ * int64 in the reference API and are treated as uint64 canonical values in [0, q) here.
+ *
+ * Data layout (same as the reference POLYNOMIAL, include/util/polynomial.h:35-44): limb-major,
+ * limb l of a polynomial at d_poly + l*N.  An "extended" polynomial at level l has l q-limbs
+ * followed directly by the K p-limbs (reference Alloc_poly(N, l, extend_p=1)).  The prime of the
+ * limb at position `pos` of a polynomial extended at `level` is q_pos if pos < level, else
+ * p_{pos-level}.  Switch keys are stored at full level: L q-limbs then K p-limbs per key polynomial.
+ *
+ * Error convention: functions return 0 on success, a negative ACEHIP_E* code otherwise;
+ * acehip_last_error() returns a message for the calling thread.  (The reference aborts via
+ * FMT_ASSERT, include/common/error.h:23-29; the rt_ant shim on top of this ABI does the same.)
+ * All launches are asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ */
+#ifndef ACEHIP_H
+#define ACEHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct acehip_ctx acehip_ctx;
+typedef void*             acehip_stream; /* hipStream_t */
+
+#define ACEHIP_OK 0
+#define ACEHIP_EINVAL (-1)   /* bad argument (level, limb range, N ...) */
+#define ACEHIP_EHIP (-2)     /* a HIP runtime call failed */
+#define ACEHIP_ENODEV (-3)   /* no GPU / extension not usable */
+
+const char* acehip_last_error(void);
+int         acehip_device_count(void);
+
+/* ---- context: Prepare_context -> Init_ckks_parameters_with_prime_size (src/rtlib/context.c:29-86,
+ * src/util/ckks_parameters.c:60-101, src/util/crt.c:574-585).  Generates the q/p prime chains, psi,
+ * twiddles and CRT tables exactly as the reference and uploads them to HBM of `device`.
+ * dnum = 0 selects the reference default number of q parts. ---- */
+acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum, int device);
+void        acehip_ctx_destroy(acehip_ctx* ctx);
+/* host-only variant (tables are generated but nothing is uploaded; no GPU needed).  Used to test the
+ * host logic; every launch on such a context fails with ACEHIP_ENODEV. */
+acehip_ctx* acehip_ctx_create_host(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum);
+
+uint32_t acehip_degree(const acehip_ctx* ctx);      /* Degree()            context.c:140 */
+uint32_t acehip_num_q(const acehip_ctx* ctx);       /* L                                   */
+uint32_t acehip_num_p(const acehip_ctx* ctx);       /* Get_p_cnt()         context.c:156 */
+uint32_t acehip_num_q_parts(const acehip_ctx* ctx); /* Get_q_parts()       context.c:148 */
+uint32_t acehip_part_size(const acehip_ctx* ctx);   /* alpha, crt.c:386 */
+uint32_t acehip_num_decomp(const acehip_ctx* ctx, uint32_t level); /* Num_decomp, polynomial.h:158-168 */
+/* prime of global index gi (0..L-1: q, L..L+K-1: p)   Q_modulus()/P_modulus() context.c:158-160 */
+uint64_t acehip_prime(const acehip_ctx* ctx, uint32_t gi);
+/* host copies of generated tables, for table-parity tests (what: 0 psi, 1 n_inv, 2 n_inv_prec,
+ * 3 prec128_lo, 4 prec128_hi -> out[L+K]; 10 rou, 11 rou_prec, 12 rou_inv, 13 rou_inv_prec -> out[N] of
+ * prime gi; 20 phat_inv_modp[K], 21 phat_inv_modp_prec[K], 22 phat_modq[L*K], 23 pinv_modq[L];
+ * 30 ql_inv[L*L], 31 ql_inv_prec, 32 qlql, 33 qlql_prec).  Returns number of words written. */
+int64_t acehip_get_table(const acehip_ctx* ctx, int what, uint32_t gi, uint64_t* out, size_t cap);
+/* ModUp tables of (level, digit): hat_inv[n2], compl_idx[nc], hat_mod[n2*nc]; returns n2 (crt.c:426-533) */
+int acehip_get_modup_tables(const acehip_ctx* ctx, uint32_t level, uint32_t digit, uint64_t* hat_inv,
+                            uint32_t* compl_idx, uint64_t* hat_mod, uint32_t* nc_out);
+/* rotation index -> automorphism index k (Find_automorphism_index number_theory.c:187-199; Auto_idx
+ * key_gen.h:28) and the NTT-domain gather table uploaded to HBM (Auto_order key_gen.h:41,
+ * Precompute_automorphism_order number_theory.c:201-214).  The returned device pointer (N uint32
+ * entries) is owned by the context and cached per k. */
+uint32_t        acehip_auto_index(const acehip_ctx* ctx, int32_t rot_idx);
+const uint32_t* acehip_auto_order(acehip_ctx* ctx, uint32_t k);
+int             acehip_auto_order_host(const acehip_ctx* ctx, uint32_t k, uint32_t* out_perm);
+
+/* ---- device memory helpers (thin wrappers so a C caller needs no HIP headers) ---- */
+void* acehip_malloc(size_t bytes);
+int   acehip_free(void* d_ptr);
+int   acehip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, acehip_stream stream);
+int   acehip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, acehip_stream stream);
+int   acehip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, acehip_stream stream);
+int   acehip_memset(void* d_ptr, int value, size_t bytes, acehip_stream stream);
+int   acehip_stream_sync(acehip_stream stream);
+/* HIP events on the launch stream (bench.py times kernels with these, not with host clocks) */
+void* acehip_event_create(void);
+int   acehip_event_record(void* event, acehip_stream stream);
+int   acehip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* synchronises on `stop` */
+int   acehip_event_destroy(void* event);
+
+/* ---- NTT.  In-place over limbs [pos0, pos0+n_limbs) of the polynomial at d_poly extended at `level`.
+ * forward: natural -> bit-reversed evaluation order  (Forward_transform ntt.c:190-264, Ftt_fwd :163,
+ *          Conv_poly2ntt_inplace* polynomial.c:532-631)
+ * inverse: bit-reversed -> natural, scaled by N^-1   (Inverse_transform ntt.c:268-353, Ftt_inv :177,
+ *          Conv_ntt2poly_inplace* polynomial.c:633-731) ---- */
+int acehip_ntt_forward(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+int acehip_ntt_inverse(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+
+/* ---- limb-wise ops over limbs [pos0, pos0+n_limbs) (each operand has its own base pointer; the
+ * limb at position pos of every operand is at base + pos*N).
+ * Hw_modadd / Hw_modmul / Hw_rotate: src/poly/poly_arith.c:14-56 (one limb per call there;
+ * n_limbs = 1 reproduces that call exactly).  d_perm: table from acehip_auto_order(). ---- */
+int acehip_modadd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+int acehip_modsub(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+int acehip_modmul(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* res += a*b   (Multiply_add polynomial.c:148-183) */
+int acehip_modmuladd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+int acehip_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint32_t* d_perm, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* single-limb forms with an explicit prime index, the exact shape of the generated code's calls
+ * Hw_modadd(res, a, b, modulus, degree) where modulus = Q_modulus()+i or P_modulus()+i */
+int acehip_hw_modadd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t prime_gi, acehip_stream stream);
+int acehip_hw_modmul(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t prime_gi, acehip_stream stream);
+int acehip_hw_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint32_t* d_perm, uint32_t prime_gi, acehip_stream stream);
+
+/* ---- RNS basis operations (NTT-domain in, NTT-domain out) ----
+ * Decomp_modup (src/poly/poly_eval.c:28 -> Decompose_modup polynomial.c:1241-1335): digit `digit` of
+ *   d_in (level q-limbs) raised to the level+K limbs of d_out.
+ * Mod_down (poly_eval.c:36 -> Reduce_rns_base polynomial.c:928-967): d_in has level+K limbs, d_out level.
+ * Rescale (poly_eval.c:43 -> Rescale_poly polynomial.c:1097-1163): d_in level limbs -> d_out level-1. */
+int acehip_decomp_modup(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, uint32_t digit, acehip_stream stream);
+int acehip_mod_down(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
+int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
+
+/* ---- key-switch core of the generated Rotate()/Relinearize()
+ * (dataset/resnet20_cifar10_pre.onnx.inc:6972-7146; Fast_switch_key ckks_evaluator.c:391-416):
+ *   out0 = Mod_down(sum_d key0[d] * Decomp_modup(in, d)),  out1 likewise with key1.
+ * d_key: [num_q_parts][2][L+K][N] (Pk0_at/Pk1_at key_gen.h:66-73); d_in: level limbs; outs: level limbs. */
+int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in,
+                      const uint64_t* d_key, uint32_t level, acehip_stream stream);
+
+/* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
+uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACEHIP_H */

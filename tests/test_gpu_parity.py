@@ -1,0 +1,222 @@
+"""GPU parity tests (-m gpu): every HIP entry point of include/acehip.h against the CPU oracle on the
+same seeded inputs (bit-exact), against the reference-generated golden fixtures, and -- at the full
+BASELINE sizes -- through size-independent properties (NTT round trip, linearity, ModDown(ModUp))."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ace_compiler_amd as A
+import _oracle as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SETS = [  # N, L, q0, sf, dnum, levels
+    (8, 4, 60, 56, 2, [4, 3, 1]),
+    (16, 3, 60, 50, 2, [3, 2]),
+    (16, 10, 60, 59, 3, [10, 5, 4]),
+    (32, 5, 33, 30, 0, [5, 2]),
+    (64, 7, 60, 51, 3, [7, 4]),
+    (1024, 7, 60, 51, 3, [6]),
+    (4096, 4, 60, 50, 2, [4]),
+    (8192, 4, 60, 50, 2, [4, 3]),
+    (16384, 4, 60, 50, 2, [4]),
+]
+
+
+@pytest.fixture(scope="module", params=SETS, ids=lambda s: "n%d_l%d_d%d" % (s[0], s[1], s[4]))
+def pair(request):
+    N, L, q0, sf, dnum, levels = request.param
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    yield o, rt, levels
+    rt.close()
+    o.close()
+
+
+def test_context_matches(pair):
+    o, rt, _ = pair
+    assert rt.primes == o.primes and (rt.K, rt.alpha, rt.dnum) == (o.K, o.alpha, o.dnum)
+
+
+def test_ntt(pair):
+    o, rt, levels = pair
+    level = levels[0]
+    x = o.uniform(level + o.K, level, 21)
+    gis = [o.gidx(l, level) for l in range(level + o.K)]
+    f = rt.ntt(x, level)
+    assert np.array_equal(f, o.ntt_fwd(x, gis))
+    assert np.array_equal(rt.ntt(x, level, inverse=True), o.ntt_inv(x, gis))
+    assert np.array_equal(rt.ntt(f, level, inverse=True), x)
+    # a sub-range of limbs (positions 1..) and the p-limbs alone
+    if level > 1:
+        assert np.array_equal(rt.ntt(x[1:3], level, pos0=1), o.ntt_fwd(x[1:3], gis[1:3]))
+    assert np.array_equal(rt.ntt(x[level:], level, pos0=level), o.ntt_fwd(x[level:], gis[level:]))
+
+
+def test_elementwise_and_rotate(pair):
+    o, rt, levels = pair
+    level = levels[0]
+    n = level + o.K
+    gis = [o.gidx(l, level) for l in range(n)]
+    a, b, c = o.uniform(n, level, 31), o.uniform(n, level, 32), o.uniform(n, level, 33)
+    add = o.hw_modadd(a, b, gis)
+    mul = o.hw_modmul(a, b, gis)
+    assert np.array_equal(rt.ew("modadd", a, b, level), add)
+    assert np.array_equal(rt.ew("modmul", a, b, level), mul)
+    assert np.array_equal(rt.ew("modmuladd", a, b, level, acc=c), o.hw_modadd(c, mul, gis))
+    # modsub: (a+b)-b == a
+    assert np.array_equal(rt.ew("modsub", add, b, level), a)
+    # edge values: 0 and q-1
+    e = np.zeros_like(a)
+    for l, gi in enumerate(gis):
+        e[l, ::2] = o.primes[gi] - 1
+    assert np.array_equal(rt.ew("modmul", e, e, level), o.hw_modmul(e, e, gis))
+    assert np.array_equal(rt.ew("modadd", e, e, level), o.hw_modadd(e, e, gis))
+    for rot in (1, -1, 3, o.N // 4):
+        k = rt.auto_index(rot)
+        assert np.array_equal(rt.rotate(a, k, level), o.hw_rotate(a, o.automorphism(k), gis))
+    k = 2 * o.N - 1
+    assert np.array_equal(rt.rotate(a, k, level), o.hw_rotate(a, o.automorphism(k), gis))
+
+
+def test_single_limb_hw_calls(pair):
+    """acehip_hw_*: the exact per-limb call shape of the generated code (poly_arith.c:14-56)."""
+    o, rt, levels = pair
+    N = o.N
+    for gi in (0, o.L - 1, o.L, o.L + o.K - 1):
+        q = o.primes[gi]
+        rng = np.random.default_rng(gi)
+        a = rng.integers(0, q, size=(1, N), dtype=np.uint64)
+        b = rng.integers(0, q, size=(1, N), dtype=np.uint64)
+        da, db, dr = rt.to_device(a), rt.to_device(b), rt.buf(N)
+        rt.check(rt.lib.acehip_hw_modmul(rt.h, dr.ptr, da.ptr, db.ptr, gi, None))
+        assert np.array_equal(dr.download((1, N)), o.hw_modmul(a, b, [gi]))
+        rt.check(rt.lib.acehip_hw_modadd(rt.h, dr.ptr, da.ptr, db.ptr, gi, None))
+        assert np.array_equal(dr.download((1, N)), o.hw_modadd(a, b, [gi]))
+        k = rt.auto_index(1)
+        rt.check(rt.lib.acehip_hw_rotate(rt.h, dr.ptr, da.ptr, rt.lib.acehip_auto_order(rt.h, k), gi, None))
+        assert np.array_equal(dr.download((1, N)), o.hw_rotate(a, o.automorphism(k), [gi]))
+        for d in (da, db, dr):
+            d.free()
+
+
+def test_decomp_modup_moddown_rescale(pair):
+    o, rt, levels = pair
+    for level in levels:
+        a = o.uniform(level, level, 41 + level)
+        for d in range(o.num_decomp(level)):
+            assert np.array_equal(rt.decomp_modup(a, level, d), o.decomp_modup(a, level, d)), (level, d)
+        x = o.uniform(level + o.K, level, 51 + level)
+        assert np.array_equal(rt.mod_down(x, level), o.mod_down(x, level)), level
+        if level > 1:
+            assert np.array_equal(rt.rescale(a, level), o.rescale(a, level)), level
+
+
+def test_key_switch(pair):
+    o, rt, levels = pair
+    key = o.make_key(1000)
+    for level in levels:
+        a = o.uniform(level, level, 61 + level)
+        c0, c1 = rt.key_switch(a, key, level)
+        e0, e1 = o.key_switch(a, key, level)
+        assert np.array_equal(c0, e0) and np.array_equal(c1, e1), level
+
+
+def test_argument_errors(pair):
+    o, rt, levels = pair
+    buf = rt.buf(o.N)
+    assert rt.lib.acehip_ntt_forward(rt.h, buf.ptr, o.L + 1, 0, 1, None) == -1
+    assert rt.lib.acehip_ntt_forward(rt.h, buf.ptr, o.L, o.L + o.K, 1, None) == -1
+    assert rt.lib.acehip_rescale(rt.h, buf.ptr, buf.ptr, 1, None) == -1
+    assert rt.lib.acehip_decomp_modup(rt.h, buf.ptr, buf.ptr, o.L, o.dnum, None) == -1
+    assert rt.lib.acehip_hw_modmul(rt.h, buf.ptr, buf.ptr, buf.ptr, o.L + o.K, None) == -1
+    buf.free()
+
+
+# ---- golden fixtures produced by the reference itself ----
+OPS_FILES = sorted(glob.glob(os.path.join(GOLDEN, "ref_ops_*.json")))
+
+
+def _chk(vec, g, name):
+    assert vec.size == g["n"], name
+    if "data" in g:
+        assert vec.reshape(-1).tolist() == g["data"], name
+    assert O.sum64(vec) == g["sum64"] and O.xorw(vec) == g["xorw"], name
+
+
+@pytest.mark.parametrize("path", OPS_FILES, ids=[os.path.basename(p)[8:-5] for p in OPS_FILES])
+def test_against_reference_golden(path):
+    g = json.load(open(path))
+    N, L, K, level, seed = g["N"], g["L"], g["K"], g["level"], g["seed"]
+    o = O.Oracle(N, L, g["q0_bits"], g["sf_bits"], g["dnum_req"])  # only used to rebuild the seeded inputs
+    rt = A.AceHip(N, L, g["q0_bits"], g["sf_bits"], g["dnum_req"])
+    try:
+        a = o.uniform(level, level, seed)
+        x = o.uniform(level + K, level, seed + 1)
+        b = o.uniform(level, level, seed + 2)
+        _chk(rt.ntt(x, level), g["ntt_fwd_x_ext"], "ntt_fwd")
+        _chk(rt.ntt(x, level, inverse=True), g["ntt_inv_x_ext"], "ntt_inv")
+        _chk(rt.mod_down(x, level), g["mod_down_x_ext"], "mod_down")
+        _chk(rt.ew("modadd", a, b, level), g["hw_modadd_a_b"], "modadd")
+        _chk(rt.ew("modmul", a, b, level), g["hw_modmul_a_b"], "modmul")
+        for r in g["rotate"]:
+            if r["rot_idx"] != 0:
+                assert rt.auto_index(r["rot_idx"]) == r["k"]
+            out = rt.rotate(a, r["k"], level)
+            assert O.sum64(out) == r["out_sum64"] and O.xorw(out) == r["out_xorw"]
+        for d in range(g["num_decomp"]):
+            _chk(rt.decomp_modup(a, level, d), g["decomp_modup_%d" % d], "decomp_modup")
+        if level > 1:
+            _chk(rt.rescale(a, level), g["rescale_a"], "rescale")
+        key = o.make_key(g["key_seed_base"])
+        c0, c1 = rt.key_switch(a, key, level)
+        _chk(c0, g["key_switch_c0"], "ks0")
+        _chk(c1, g["key_switch_c1"], "ks1")
+    finally:
+        rt.close()
+        o.close()
+
+
+# ---- full BASELINE sizes: properties that need no oracle run ----
+def test_full_size_properties():
+    N, L, dnum = 65536, 25, 4
+    rt = A.AceHip(N, L, 60, 56, dnum)
+    o = O.Oracle(N, L, 60, 56, dnum)  # input generation + q values only
+    try:
+        level = L
+        x = o.uniform(level + rt.K, level, 5)
+        y = o.uniform(level + rt.K, level, 6)
+        gis = [o.gidx(l, level) for l in range(level + rt.K)]
+        fx = rt.ntt(x, level)
+        assert np.array_equal(rt.ntt(fx, level, inverse=True), x)  # round trip
+        # linearity: NTT(x + y) == NTT(x) + NTT(y)
+        s = rt.ew("modadd", x, y, level)
+        assert np.array_equal(rt.ntt(s, level), rt.ew("modadd", fx, rt.ntt(y, level), level))
+        # convolution theorem on one limb: iNTT(NTT(x) * NTT(e1)) is the negacyclic shift of x by one
+        e1 = np.zeros((1, N), dtype=np.uint64)
+        e1[0, 1] = 1
+        prod = rt.ew("modmul", fx[:1], rt.ntt(e1, level), level)
+        sh = rt.ntt(prod, level, inverse=True)
+        q0 = o.primes[0]
+        exp = np.roll(x[:1], 1, axis=1)
+        exp[0, 0] = (q0 - int(x[0, N - 1])) % q0
+        assert np.array_equal(sh, exp)
+        # ModDown(ModUp(a, digit)) == NTT(-v) with v the small overshoot of the uncorrected fast base
+        # conversion: every coefficient of the centred iNTT is in [-alpha, 0]
+        a = x[:level]
+        ext = rt.decomp_modup(a, level, 0)
+        dn = rt.mod_down(ext, level)
+        co = rt.ntt(dn, level, inverse=True)
+        alpha = rt.alpha
+        for l in range(level):
+            q = np.uint64(o.primes[l])
+            v = co[l]
+            neg = (q - v) % q
+            assert int(neg.max()) <= alpha, (l, int(neg.max()))
+    finally:
+        rt.close()
+        o.close()

@@ -1,0 +1,93 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol of include/acehip.h, the
+host-side table generation of the product (csrc/host_params.cpp) equals the oracle's and the
+reference-generated golden tables, and launches on a GPU-less context fail loudly (no CPU fallback)."""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ace_compiler_amd as A
+import _oracle as O
+from conftest import GOLDEN, ROOT
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "acehip.h")).read()
+    declared = set(re.findall(r"\b(acehip_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"acehip_ctx", "acehip_stream"}
+    bound = {s[0] for s in A.binding.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    lib = A.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+PARAM_FILES = sorted(glob.glob(os.path.join(GOLDEN, "ref_params_*.json")))
+
+
+@pytest.mark.parametrize("path", PARAM_FILES, ids=[os.path.basename(p)[11:-5] for p in PARAM_FILES])
+def test_host_tables_match_reference(path):
+    g = json.load(open(path))
+    N, L, K = g["N"], g["L"], g["K"]
+    rt = A.AceHip(N, L, g["q0_bits"], g["sf_bits"], g["dnum_req"], host_only=True)
+    try:
+        assert (rt.K, rt.alpha, rt.dnum) == (K, g["alpha"], g["dnum"])
+        assert rt.primes == g["primes"]
+        assert rt.table(0).tolist() == g["psi"]
+        assert rt.table(1).tolist() == g["n_inv"]
+        assert rt.table(2).tolist() == g["n_inv_prec"]
+        assert rt.table(3).tolist() == g["prec128_lo"]
+        assert rt.table(4).tolist() == g["prec128_hi"]
+        for gi in range(L + K):
+            r = g["rou"][gi]
+            rou = rt.table(10, gi)
+            assert O.sum64(rou) == r["sum64"] and O.xorw(rou) == r["xorw"]
+            assert O.xorw(rt.table(11, gi)) == r["prec_xorw"]
+            assert O.xorw(rt.table(12, gi)) == r["inv_xorw"]
+            assert O.xorw(rt.table(13, gi)) == r["inv_prec_xorw"]
+        assert rt.table(20).tolist() == g["phat_inv_modp"]
+        assert rt.table(21).tolist() == g["phat_inv_modp_prec"]
+        assert rt.table(22).tolist() == g["phat_modq"]
+        assert rt.table(23).tolist() == g["pinv_modq"]
+        for what, key in ((30, "ql_inv"), (31, "ql_inv_prec"), (32, "qlql"), (33, "qlql_prec")):
+            t = rt.table(what).reshape(L, L)
+            for k, row in enumerate(g["rescale"]):
+                assert t[k, : k + 1].tolist() == row[key]
+        for e in g["modup"]:
+            n2, hat_inv, compl, hat_mod = rt.modup_tables(e["level"], e["digit"])
+            assert n2 == e["n2"] and hat_inv.tolist() == e["hat_inv"]
+            assert [rt.primes[i] for i in compl] == e["compl"]
+            if "hat_mod" in e:
+                assert hat_mod.reshape(-1).tolist() == e["hat_mod"]
+            else:
+                assert O.sum64(hat_mod) == e["hat_mod_sum64"] and O.xorw(hat_mod) == e["hat_mod_xorw"]
+    finally:
+        rt.close()
+
+
+def test_automorphism_tables_match_oracle():
+    o = O.Oracle(64, 3, 60, 50, 2)
+    rt = A.AceHip(64, 3, 60, 50, 2, host_only=True)
+    for rot in (1, -1, 5, 16, -7):
+        k = rt.auto_index(rot)
+        assert k == o.lib.orc_find_automorphism_index(rot, 64)
+        assert rt.auto_order_host(k).tolist() == o.automorphism(k).tolist()
+    assert rt.auto_order_host(127).tolist() == o.automorphism(127).tolist()  # conjugation
+    rt.close()
+    o.close()
+
+
+def test_no_cpu_fallback():
+    rt = A.AceHip(16, 3, 60, 50, 2, host_only=True)
+    x = np.zeros(16, dtype=np.uint64)
+    rc = rt.lib.acehip_ntt_forward(rt.h, x.ctypes.data, 3, 0, 1, None)
+    assert rc == -3 and "no CPU fallback" in rt.err()
+    rc = rt.lib.acehip_key_switch(rt.h, None, None, None, None, 3, None)
+    assert rc == -3
+    rt.close()
+    if A.load_library().acehip_device_count() == 0:
+        with pytest.raises(A.AceHipError):
+            A.AceHip(16, 3, 60, 50, 2)
