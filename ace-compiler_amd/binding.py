@@ -46,6 +46,7 @@ SYMBOLS = [
     ("acehip_event_destroy", C.c_int, [_vp]),
     ("acehip_ntt_forward", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_ntt_inverse", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_ntt_batch", C.c_int, [_vp, _vp, C.c_size_t, _u32, _u32, _u32, _u32, C.c_int, _vp]),
     ("acehip_modadd", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_modsub", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_modmul", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),

@@ -389,6 +389,15 @@ int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0
   return post_launch();
 }
 
+int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_polys, uint32_t level, uint32_t pos0,
+                     uint32_t n, int inverse, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (n_polys == 0) return ACEHIP_OK;
+  if (n_polys > 65535) return fail(ACEHIP_EINVAL, "acehip_ntt_batch: at most 65535 polynomials per launch");
+  launch_ntt(c->dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+  return post_launch();
+}
+
 static int ew(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
   launch_ew(c->dc, op, r, a, b, level, pos0, n, (hipStream_t)s);

@@ -23,14 +23,14 @@ namespace acehip {
 // stay canonical in [0,q), hence bit-identical to the reference whatever the stage grouping.
 // ------------------------------------------------------------------------------------------------
 template <bool CONTIG, bool INVERSE>
-__global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict__ poly, u32 level, u32 pos0, u32 pos_off,
+__global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0, u32 pos_off,
                                                        u32 s0, u32 r, u32 log_c) {
   extern __shared__ u64 tile[];
   const u32 pos = pos0 + blockIdx.y;
   const u32 gi = limb_prime(pos, level, c.L);
   const DevPrime P = c.primes[gi];
   const u64 q = P.q;
-  u64* x = poly + (size_t)(pos - pos_off) * c.N;
+  u64* x = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N;
   const u64* W = (INVERSE ? c.rou_inv : c.rou) + (size_t)gi * c.N;
   const u64* WP = (INVERSE ? c.rou_inv_prec : c.rou_prec) + (size_t)gi * c.N;
   const u32 R = 1u << r, C = 1u << log_c;
@@ -108,30 +108,31 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
 }
 
 template <bool CONTIG, bool INVERSE>
-static void launch_pass(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 pos_off, u32 n_limbs, u32 s0, u32 r,
+static void launch_pass(const DevCtx& c, u64* poly, size_t poly_stride, u32 n_polys, u32 level, u32 pos0, u32 pos_off, u32 n_limbs, u32 s0, u32 r,
                         u32 log_c, hipStream_t s) {
   const u32 tiles = c.N >> (r + log_c);
-  dim3 grid(tiles, n_limbs), block(256);
+  dim3 grid(tiles, n_limbs, n_polys), block(256);
   size_t lds = sizeof(u64) << (r + log_c);
-  hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, level, pos0, pos_off, s0, r, log_c);
+  hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, poly_stride, level, pos0, pos_off, s0, r, log_c);
 }
 
-void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off) {
+void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                u32 n_polys, size_t poly_stride) {
   if (n_limbs == 0) return;
   const u32 logN = c.logN;
   if (logN <= 12) {  // whole limb in LDS (<= 32 KiB): one pass
-    if (!inverse) launch_pass<true, false>(c, poly, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
-    else          launch_pass<true, true>(c, poly, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
+    if (!inverse) launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
+    else          launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
     return;
   }
   // two passes: r1 strided stages (column tiles of 16 x 128 B row segments), then 8 contiguous stages
   const u32 r2 = 8, r1 = logN - r2, log_c = 4;
   if (!inverse) {
-    launch_pass<false, false>(c, poly, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
-    launch_pass<true, false>(c, poly, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
+    launch_pass<false, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
+    launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
   } else {
-    launch_pass<true, true>(c, poly, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
-    launch_pass<false, true>(c, poly, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
+    launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
+    launch_pass<false, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
   }
 }
 

@@ -23,7 +23,9 @@ enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 
 // NTT over limb positions [pos0, pos0+n) of poly at `level`
 // the limb at position pos lives at poly + (pos - pos_off)*N
-void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off = 0);
+// n_polys polynomials poly_stride words apart are transformed in the same launch
+void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off = 0,
+                u32 n_polys = 1, size_t poly_stride = 0);
 // elementwise over limb positions
 void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs, hipStream_t s,
                u32 pos_off = 0);

@@ -92,6 +92,10 @@ int   acehip_event_destroy(void* event);
  *          Conv_ntt2poly_inplace* polynomial.c:633-731) ---- */
 int acehip_ntt_forward(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
 int acehip_ntt_inverse(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* the same transform on n_polys polynomials that lie poly_stride words apart (c0/c1 of a ciphertext,
+ * the digits of a key-switch, a batch of ciphertexts): one launch, limbs x polys workgroup grid */
+int acehip_ntt_batch(acehip_ctx* ctx, uint64_t* d_polys, size_t poly_stride, uint32_t n_polys, uint32_t level,
+                     uint32_t pos0, uint32_t n_limbs, int inverse, acehip_stream stream);
 
 /* ---- limb-wise ops over limbs [pos0, pos0+n_limbs) (each operand has its own base pointer; the
  * limb at position pos of every operand is at base + pos*N).

@@ -8,7 +8,7 @@
  *   ref_dump params N L q0 sf dnum            -> primes, psi, CRT tables
  *   ref_dump ops    N L q0 sf dnum level seed -> per-op input/output vectors (full if N<=64,
  *                                                checksums otherwise)
- *   ref_dump bench  N L q0 sf dnum level reps -> timings of the reference ops (JSON)
+ *   ref_dump bench  N L q0 sf dnum level ks_reps ntt_reps -> timings of the reference ops (JSON)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -348,7 +348,7 @@ static int do_ops(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_
 static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 /* CPU baseline: the reference rtlib timed on this host (single thread, as published: README.md:94) */
-static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, int reps) {
+static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, int reps, int ntt_reps) {
   CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
   CRT_CONTEXT*    crt = p->_crt_context;
   size_t          K = p->_num_p_primes;
@@ -368,7 +368,6 @@ static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, siz
   int64_t*   buf = malloc(sizeof(int64_t) * N);
   memcpy(buf, a._data, sizeof(int64_t) * N);
   Init_i64_value_list_no_copy(&vl, N, buf);
-  int    ntt_reps = reps * 20;
   double t0 = now_s();
   for (int r = 0; r < ntt_reps; r++) Ftt_fwd(&vl, Get_ntt(prime_at(crt, 0)), &vl);
   double t_fwd = (now_s() - t0) / ntt_reps;
@@ -377,10 +376,10 @@ static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, siz
   double t_inv = (now_s() - t0) / ntt_reps;
   t0 = now_s();
   for (int r = 0; r < reps; r++) ref_key_switch(crt, &o0, &o1, &a, key, level, L, K, N);
-  double t_ks = (now_s() - t0) / reps;
-  printf("{\"kind\": \"reference\", \"N\": %u, \"L\": %zu, \"dnum\": %zu, \"K\": %zu, \"level\": %zu, \"reps\": %d, "
+  double t_ks = reps > 0 ? (now_s() - t0) / reps : 0.0;
+  printf("{\"kind\": \"reference\", \"N\": %u, \"L\": %zu, \"dnum\": %zu, \"K\": %zu, \"level\": %zu, \"reps\": %d, \"ntt_reps\": %d, "
          "\"ntt_fwd_s\": %.9f, \"ntt_inv_s\": %.9f, \"key_switch_s\": %.9f, \"ks_sum64\": %llu}\n",
-         N, L, dnum, K, level, reps, t_fwd, t_inv, t_ks, sum64(o0._data, level * N));
+         N, L, dnum, K, level, reps, ntt_reps, t_fwd, t_inv, t_ks, sum64(o0._data, level * N));
   return 0;
 }
 
@@ -393,6 +392,6 @@ int main(int argc, char** argv) {
   size_t   L = atoi(argv[3]), q0 = atoi(argv[4]), sf = atoi(argv[5]), dnum = atoi(argv[6]);
   if (!strcmp(argv[1], "params")) return do_params(N, L, q0, sf, dnum);
   if (!strcmp(argv[1], "ops")) return do_ops(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
-  if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1);
+  if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1, argc > 9 ? atoi(argv[9]) : 20);
   return 2;
 }
