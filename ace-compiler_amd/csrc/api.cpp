@@ -47,6 +47,12 @@ T* upload(const std::vector<T>& v) {
 
 }  // namespace
 
+// Per-level plan of the batched key-switch: one ConvDesc per digit (ModUp) and one for ModDown.
+struct KsPlan {
+  ConvDesc* d_descs = nullptr;  // [nd] ModUp problems, then [1] ModDown problem
+  u32 nd = 0, max_nc = 0;
+};
+
 struct acehip_ctx {
   HostParams hp;
   bool on_device = false;
@@ -61,6 +67,7 @@ struct acehip_ctx {
   std::mutex mu;
   std::map<std::pair<u32, u32>, DevModUp> modup;
   std::map<u32, u32*> auto_tabs;
+  std::map<u32, KsPlan> ks_plans;
   // workspace (one per context; launches of one context are expected on one stream at a time)
   u64* ws = nullptr;
   size_t ws_words = 0;
@@ -112,10 +119,13 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   std::vector<DevPrime> dp(T);
   std::memcpy(dp.data(), hp.primes.data(), T * sizeof(DevPrime));
   ctx->dc.primes = ctx->up(dp);
-  ctx->dc.rou = ctx->up(hp.rou);
-  ctx->dc.rou_prec = ctx->up(hp.rou_prec);
-  ctx->dc.rou_inv = ctx->up(hp.rou_inv);
-  ctx->dc.rou_inv_prec = ctx->up(hp.rou_inv_prec);
+  {  // interleave {w, Shoup companion} so that a twiddle is one 16-byte load
+    std::vector<ulong2> tw((size_t)T * hp.N);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = ulong2{hp.rou[i], hp.rou_prec[i]};
+    ctx->dc.tw_fwd = ctx->up(tw);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = ulong2{hp.rou_inv[i], hp.rou_inv_prec[i]};
+    ctx->dc.tw_inv = ctx->up(tw);
+  }
   ctx->dc.N = hp.N;
   ctx->dc.logN = hp.logN;
   ctx->dc.L = hp.L;
@@ -139,9 +149,9 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   ctx->p_gi = ctx->up(pgi);
   ctx->q_gi = ctx->up(qgi);
   ctx->q_pos = ctx->q_gi;
-  // workspace: ext (L+K) + two accumulators (L+K each) + scratch (L+K) limbs
-  ctx->ws_words = (size_t)4 * T * hp.N;
-  if (hipMalloc(&ctx->ws, ctx->ws_words * sizeof(u64)) != hipSuccess || !ctx->dc.primes || !ctx->dc.rou_inv_prec) {
+  // workspace of the batched key-switch: coef (L) + ext[dnum] + two accumulators (L+K each) + tmp (2L)
+  ctx->ws_words = ((size_t)hp.L * 3 + (size_t)(hp.dnum + 2) * T) * hp.N;
+  if (hipMalloc(&ctx->ws, ctx->ws_words * sizeof(u64)) != hipSuccess || !ctx->dc.primes || !ctx->dc.tw_inv) {
     g_err = "acehip_ctx_create: device allocation/upload failed";
     acehip_ctx_destroy(ctx);
     return nullptr;
@@ -465,26 +475,82 @@ int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t le
   return post_launch();
 }
 
+static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->ks_plans.find(level);
+    if (it != c->ks_plans.end()) return &it->second;
+  }
+  const HostParams& hp = c->hp;
+  KsPlan plan;
+  plan.nd = hp.num_decomp(level);
+  std::vector<ConvDesc> descs;
+  for (u32 d = 0; d < plan.nd; ++d) {
+    const DevModUp* t = get_modup(c, level, d);
+    if (!t) return nullptr;
+    ConvDesc cd{};
+    cd.hat = t->hat_mod;
+    cd.scale = t->hat_inv;
+    cd.scale_prec = t->hat_inv_prec;
+    cd.src_gi = t->src_gi;
+    cd.out_gi = t->out_gi;
+    cd.out_pos = t->out_pos;
+    cd.src_pos0 = t->start;
+    cd.n_in = t->n2;
+    cd.n_out = t->nc;
+    cd.hat_ld = t->nc;
+    plan.max_nc = std::max(plan.max_nc, t->nc);
+    descs.push_back(cd);
+  }
+  ConvDesc md{};  // ModDown: K p-limbs at positions level.. -> level q-limbs (polynomial.c:755-807)
+  md.hat = c->phat_modq_t;
+  md.scale = c->phat_inv;
+  md.scale_prec = c->phat_inv_prec;
+  md.src_gi = c->p_gi;
+  md.out_gi = c->q_gi;
+  md.out_pos = c->q_pos;
+  md.src_pos0 = level;
+  md.n_in = hp.K;
+  md.n_out = level;
+  md.hat_ld = hp.L;
+  descs.push_back(md);
+  std::lock_guard<std::mutex> lk(c->mu);
+  plan.d_descs = c->up(descs);
+  if (!plan.d_descs) return nullptr;
+  return &(c->ks_plans[level] = plan);
+}
+
 int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key,
                       uint32_t level, acehip_stream s_) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_switch: bad level");
   const HostParams& hp = c->hp;
   hipStream_t s = (hipStream_t)s_;
-  const size_t N = hp.N, T = hp.L + hp.K;
-  u64* scratch = ws_at(c, 0);
-  u64* ext = ws_at(c, T);
-  u64* acc0 = ws_at(c, 2 * T);
-  u64* acc1 = ws_at(c, 3 * T);
-  const u32 nd = hp.num_decomp(level);
-  for (u32 d = 0; d < nd; ++d) {
-    if (int e = do_decomp_modup(c, ext, in, level, d, scratch, s)) return e;
-    const u64* k0 = key + ((size_t)d * 2 + 0) * T * N;
-    const u64* k1 = key + ((size_t)d * 2 + 1) * T * N;
-    launch_key_mac(c->dc, acc0, acc1, k0, k1, ext, level, d != 0, s);
-  }
-  if (int e = do_mod_down(c, out0, acc0, level, scratch, s)) return e;
-  if (int e = do_mod_down(c, out1, acc1, level, scratch, s)) return e;
+  const KsPlan* plan = get_ks_plan(c, level);
+  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
+  const size_t N = hp.N, E = (size_t)(level + hp.K) * N;  // words per extended polynomial
+  const u32 nd = plan->nd;
+  // workspace: coef (level limbs) | ext[nd] | acc0 | acc1 | tmp[2] (level limbs each)
+  u64* coef = c->ws;
+  u64* ext = coef + (size_t)level * N;
+  u64* acc0 = ext + nd * E;
+  u64* acc1 = acc0 + E;
+  u64* tmp = acc1 + E;
+  // 1. all digit limbs to the coefficient domain in one launch (polynomial.c:1276-1283 for every part)
+  HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the load), one launch
+  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
+  // 3. NTT of every digit's complement limbs, one launch (own digit limbs are skipped)
+  launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E,
+             hp.alpha);
+  // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
+  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
+  // 5. ModDown of both accumulators together (polynomial.c:928-967)
+  launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
+  launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s);
+  launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
+  launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
   return post_launch();
 }
 

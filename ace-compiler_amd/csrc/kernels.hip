@@ -24,15 +24,15 @@ namespace acehip {
 // ------------------------------------------------------------------------------------------------
 template <bool CONTIG, bool INVERSE>
 __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0, u32 pos_off,
-                                                       u32 s0, u32 r, u32 log_c) {
+                                                       u32 s0, u32 r, u32 log_c, u32 skip_alpha) {
   extern __shared__ u64 tile[];
-  const u32 pos = pos0 + blockIdx.y;
+  u32 pos;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
   const u32 gi = limb_prime(pos, level, c.L);
   const DevPrime P = c.primes[gi];
   const u64 q = P.q;
   u64* x = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N;
-  const u64* W = (INVERSE ? c.rou_inv : c.rou) + (size_t)gi * c.N;
-  const u64* WP = (INVERSE ? c.rou_inv_prec : c.rou_prec) + (size_t)gi * c.N;
+  const ulong2* W = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
   const u32 R = 1u << r, C = 1u << log_c;
   const u32 log_s = c.logN - s0 - r;
   const u32 chunk = blockIdx.x, tid = threadIdx.x;
@@ -80,13 +80,14 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
       }
       const u32 tw = (1u << s) + (o << ss) + grp;
       const u64 u = tile[i_lo], v = tile[i_hi];
+      const ulong2 w = W[tw];
       if (!INVERSE) {
-        const u64 wv = mul_shoup(v, W[tw], WP[tw], q);
+        const u64 wv = mul_shoup(v, w.x, w.y, q);
         tile[i_lo] = add_mod(u, wv, q);
         tile[i_hi] = sub_mod(u, wv, q);
       } else if (s != 0) {
         tile[i_lo] = add_mod(u, v, q);
-        tile[i_hi] = mul_shoup(sub_mod(u, v, q), W[tw], WP[tw], q);
+        tile[i_hi] = mul_shoup(sub_mod(u, v, q), w.x, w.y, q);
       } else {  // last inverse stage: fold N^-1 (reference folds it into its first stage, ntt.c:282-317)
         tile[i_lo] = mul_shoup(add_mod(u, v, q), P.n_inv, P.n_inv_prec, q);
         tile[i_hi] = mul_shoup(sub_mod(u, v, q), P.inv_w1_ninv, P.inv_w1_ninv_prec, q);
@@ -109,30 +110,34 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
 
 template <bool CONTIG, bool INVERSE>
 static void launch_pass(const DevCtx& c, u64* poly, size_t poly_stride, u32 n_polys, u32 level, u32 pos0, u32 pos_off, u32 n_limbs, u32 s0, u32 r,
-                        u32 log_c, hipStream_t s) {
+                        u32 log_c, hipStream_t s, u32 skip_alpha) {
   const u32 tiles = c.N >> (r + log_c);
   dim3 grid(tiles, n_limbs, n_polys), block(256);
   size_t lds = sizeof(u64) << (r + log_c);
-  hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, poly_stride, level, pos0, pos_off, s0, r, log_c);
+  hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, poly_stride, level, pos0, pos_off, s0, r, log_c, skip_alpha);
 }
 
 void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
-                u32 n_polys, size_t poly_stride) {
+                u32 n_polys, size_t poly_stride, u32 skip_alpha) {
   if (n_limbs == 0) return;
   const u32 logN = c.logN;
   if (logN <= 12) {  // whole limb in LDS (<= 32 KiB): one pass
-    if (!inverse) launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
-    else          launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s);
+    if (!inverse) launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s, skip_alpha);
+    else          launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s, skip_alpha);
     return;
   }
-  // two passes: r1 strided stages (column tiles of 16 x 128 B row segments), then 8 contiguous stages
-  const u32 r2 = 8, r1 = logN - r2, log_c = 4;
+  if (logN == 16) {  // two register-tiled passes of 8 stages (ntt_fast.hip)
+    launch_ntt_fast(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha);
+    return;
+  }
+  // leading logN-8 stages: LDS radix-2 pass on column tiles; trailing 8 stages: register-tiled contig pass
+  const u32 r1 = logN - 8, log_c = 4;
   if (!inverse) {
-    launch_pass<false, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
-    launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
+    launch_pass<false, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s, skip_alpha);
+    launch_ntt_contig8(c, poly, level, pos0, n_limbs, false, s, pos_off, n_polys, poly_stride, skip_alpha);
   } else {
-    launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, r1, r2, log_c, s);
-    launch_pass<false, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s);
+    launch_ntt_contig8(c, poly, level, pos0, n_limbs, true, s, pos_off, n_polys, poly_stride, skip_alpha);
+    launch_pass<false, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, r1, log_c, s, skip_alpha);
   }
 }
 

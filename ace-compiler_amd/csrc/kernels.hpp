@@ -9,15 +9,41 @@ namespace acehip {
 // Tables resident in HBM for one context (passed by value to kernels).
 struct DevCtx {
   const DevPrime* primes;  // [L+K]
-  const u64* rou;          // [L+K][N]
-  const u64* rou_prec;
-  const u64* rou_inv;
-  const u64* rou_inv_prec;
+  const ulong2* tw_fwd;    // [L+K][N] {rou[bitrev], Shoup companion}
+  const ulong2* tw_inv;    // [L+K][N] {rou_inv[bitrev], Shoup companion}
   u32 N, logN, L, K;
 };
 
 // prime (global index) of the limb at position pos of a polynomial extended at `level`
 __host__ __device__ inline u32 limb_prime(u32 pos, u32 level, u32 L) { return pos < level ? pos : L + (pos - level); }
+
+// limb position handled by this workgroup (blockIdx.y) of polynomial blockIdx.z.  With skip_alpha != 0
+// the launch covers the key-switch digits: polynomial z skips its own digit limbs
+// [alpha*z, alpha*z + n2) (they are not produced by ModUp), pos0 must be 0.
+#ifdef __HIPCC__
+__device__ __forceinline__ bool ntt_limb_pos(u32& pos, u32 pos0, u32 level, u32 K, u32 skip_alpha) {
+  pos = pos0 + blockIdx.y;
+  if (skip_alpha) {
+    const u32 start = skip_alpha * blockIdx.z;
+    const u32 n2 = min(skip_alpha, level - start);
+    if (pos >= start) pos += n2;
+    return pos < level + K;
+  }
+  return true;
+}
+#endif
+
+// One base-conversion problem (a key-switch digit, or the P->Q conversion of ModDown); lives in HBM.
+struct ConvDesc {
+  const u64* hat;         // [n_in][hat_ld]  (Q_d/q_i) mod t_j
+  const u64* scale;       // [n_in] per-source constant applied on load (Shoup), or nullptr
+  const u64* scale_prec;  // [n_in]
+  const u32* src_gi;      // [n_in] prime of each source limb
+  const u32* out_gi;      // [n_out] prime of each output limb
+  const u32* out_pos;     // [n_out] limb position of each output
+  u32 src_pos0;           // first source limb position in the input polynomial
+  u32 n_in, n_out, hat_ld;
+};
 
 enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 
@@ -25,7 +51,12 @@ enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 // the limb at position pos lives at poly + (pos - pos_off)*N
 // n_polys polynomials poly_stride words apart are transformed in the same launch
 void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off = 0,
-                u32 n_polys = 1, size_t poly_stride = 0);
+                u32 n_polys = 1, size_t poly_stride = 0, u32 skip_alpha = 0);
+// register-tiled passes (ntt_fast.hip)
+void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                     u32 n_polys, size_t poly_stride, u32 skip_alpha);
+void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                        u32 n_polys, size_t poly_stride, u32 skip_alpha);
 // elementwise over limb positions
 void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs, hipStream_t s,
                u32 pos_off = 0);
@@ -35,6 +66,17 @@ void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const
 // base conversion: out[pos[j]][n] = (sum_i in[i][n] * hat[i*hat_ld + j]) mod prime(out_gi[j])
 void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, const u32* out_gi, const u32* out_pos,
                       u32 n_in, u32 n_out, u32 hat_ld, hipStream_t s);
+// batched form: problem z = blockIdx.z uses descs[z*desc_step], reads in + z*in_stride (coefficient domain
+// limbs at positions src_pos0..), writes out + z*out_stride
+void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
+                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s);
+// fused key inner product over all digits (generated code inc:7011-7036 for every part):
+//   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
+void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
+                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s);
+// ModDown tail for two polynomials: out_z = shoup(x_z - t_z, pinv), z in {0,1}
+void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
+                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s);
 // ModDown tail: out[i] = shoup(x[i] - out[i], pinv[i]) for i < level
 void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s);
 // Rescale: t[i][n] = shoup(switch_modulus(last[n], q_last, q_i), c1[i]) for i < level-1

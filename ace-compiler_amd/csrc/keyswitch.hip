@@ -1,0 +1,111 @@
+// keyswitch.hip -- batched kernels of the hybrid key-switch: base conversion over all digits in one
+// launch, the key inner product fused over digits, and the two-polynomial ModDown tail.
+// Reference algorithm: Decompose_modup polynomial.c:1241-1335, Multiply_add :148-183,
+// Reduce_rns_base :928-967 (generated Rotate()/Relinearize(), resnet20_cifar10_pre.onnx.inc:6972-7146).
+#include "kernels.hpp"
+
+namespace acehip {
+
+constexpr int kMaxIn = 16;   // alpha, K <= 12 for the reference parameter sets
+constexpr int kGroup = 4;    // output limbs per workgroup row (sources stay in registers)
+
+// out[pos_j][n] = ( sum_i y_i[n] * hat[i][j] ) mod t_j,  y_i = in[src_pos0+i][n] (* scale_i mod q_i)
+__global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
+                                                              const u64* __restrict__ in, size_t in_stride,
+                                                              const ConvDesc* __restrict__ descs, u32 desc_step) {
+  const ConvDesc d = descs[blockIdx.z * desc_step];
+  const u32 j0 = blockIdx.y * kGroup;
+  if (j0 >= d.n_out) return;
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= c.N) return;
+  const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + n;
+  u64* dst = out + blockIdx.z * out_stride + n;
+  u64 y[kMaxIn];
+#pragma unroll
+  for (int i = 0; i < kMaxIn; ++i) {
+    y[i] = 0;
+    if ((u32)i < d.n_in) {
+      u64 v = src[(size_t)i * c.N];
+      if (d.scale) v = mul_shoup(v, d.scale[i], d.scale_prec[i], c.primes[d.src_gi[i]].q);
+      y[i] = v;
+    }
+  }
+  for (u32 j = j0; j < j0 + kGroup && j < d.n_out; ++j) {
+    const DevPrime& P = c.primes[d.out_gi[j]];
+    U128 acc{0, 0};
+#pragma unroll
+    for (int i = 0; i < kMaxIn; ++i)
+      if ((u32)i < d.n_in) mac128(acc, y[i], d.hat[(size_t)i * d.hat_ld + j]);
+    dst[(size_t)d.out_pos[j] * c.N] = reduce128(acc, P.q, P.prec128_lo, P.prec128_hi);
+  }
+}
+
+void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
+                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s) {
+  if (n_problems == 0 || max_n_out == 0) return;
+  dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems), block(256);
+  hipLaunchKernelGGL(base_conv_batch_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
+}
+
+// acc{0,1}[pos][n] = sum_d key{0,1}[d][gi][n] * e_d[pos][n];  key layout [nd][2][L+K][N]
+__global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __restrict__ acc0, u64* __restrict__ acc1,
+                                                            const u64* __restrict__ key, const u64* __restrict__ ext,
+                                                            size_t ext_stride, const u64* __restrict__ in, u32 level,
+                                                            u32 nd, u32 alpha) {
+  const u32 pos = blockIdx.y;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime P = c.primes[gi];
+  const size_t T = c.L + c.K;
+  const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const u32 own = pos < level ? pos / alpha : 0xffffffffu;  // digit whose ModUp passes this limb through
+  ulong2 r0{0, 0}, r1{0, 0};
+  for (u32 d = 0; d < nd; ++d) {
+    const u64* e_src = (d == own) ? in + pb : ext + d * ext_stride + pb;
+    const ulong2 e = *reinterpret_cast<const ulong2*>(e_src + i);
+    const u64* k0p = key + ((size_t)d * 2) * T * c.N + kb;
+    const ulong2 k0 = *reinterpret_cast<const ulong2*>(k0p + i);
+    const ulong2 k1 = *reinterpret_cast<const ulong2*>(k0p + T * c.N + i);
+    r0.x = add_mod(r0.x, mul_mod(k0.x, e.x, P), P.q);
+    r0.y = add_mod(r0.y, mul_mod(k0.y, e.y, P), P.q);
+    r1.x = add_mod(r1.x, mul_mod(k1.x, e.x, P), P.q);
+    r1.y = add_mod(r1.y, mul_mod(k1.y, e.y, P), P.q);
+  }
+  *reinterpret_cast<ulong2*>(acc0 + pb + i) = r0;
+  *reinterpret_cast<ulong2*>(acc1 + pb + i) = r1;
+}
+
+void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
+                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha);
+}
+
+__global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __restrict__ out0, u64* __restrict__ out1,
+                                                            const u64* __restrict__ x0, const u64* __restrict__ x1,
+                                                            const u64* __restrict__ t0, const u64* __restrict__ t1,
+                                                            const u64* __restrict__ pinv,
+                                                            const u64* __restrict__ pinv_prec) {
+  const u32 l = blockIdx.y;
+  const u64 q = c.primes[l].q, w = pinv[l], wp = pinv_prec[l];
+  const size_t base = (size_t)l * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const u64* x = blockIdx.z ? x1 : x0;
+  const u64* t = blockIdx.z ? t1 : t0;
+  u64* o = blockIdx.z ? out1 : out0;
+  const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
+  ulong2 vt = *reinterpret_cast<const ulong2*>(t + base + i);
+  vt.x = mul_shoup(sub_mod(vx.x, vt.x, q), w, wp, q);
+  vt.y = mul_shoup(sub_mod(vx.y, vt.y, q), w, wp, q);
+  *reinterpret_cast<ulong2*>(o + base + i) = vt;
+}
+
+void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
+                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level, 2), block(256);
+  hipLaunchKernelGGL(moddown_tail2_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t0, t1, pinv, pinv_prec);
+}
+
+}  // namespace acehip

@@ -1,0 +1,278 @@
+// ntt_fast.hip -- register-tiled negacyclic NTT passes for gfx950.
+//
+// One pass = 8 radix-2 stages = two rounds of radix-16 held in registers (16 coefficients per lane,
+// 4 stages per round) with one LDS transpose in between; 256 lanes x 16 = 4096 coefficients (32 KiB)
+// per workgroup.  N = 2^16 is exactly two passes:
+//   STRIDED pass: stages [0,8)          rows = index bits [logN-8, logN), 16 adjacent columns/tile
+//   CONTIG  pass: stages [logN-8,logN)  16 consecutive 256-coefficient blocks per tile
+// Butterflies are Harvey-style lazy (values in [0,4q) forward, [0,2q) inverse; q < 2^61) with Shoup
+// twiddle multiplication; the last pass writes canonical residues in [0,q), so results are
+// bit-identical to the reference (ntt.c:190-353), which keeps every intermediate canonical.
+// Twiddles come from the interleaved {w, floor(w*2^64/q)} tables (16-byte loads).
+//
+// Integer-multiply throughput (v_mad_u64_u32 at half rate, v_mul_lo/hi_u32 at quarter rate:
+// tools/ubench_int.hip) is the VALU ceiling of these kernels; see DESIGN.md.
+#include "kernels.hpp"
+
+namespace acehip {
+
+struct Tw {
+  u64 w, p;
+};
+
+__device__ __forceinline__ Tw ldtw(const ulong2* __restrict__ t, u32 idx) {
+  const ulong2 v = t[idx];
+  return Tw{v.x, v.y};
+}
+
+// a*w mod q in [0,2q) for any 64-bit a
+__device__ __forceinline__ u64 shoup_lazy(u64 a, Tw t, u64 q) { return a * t.w - mulhi64(a, t.p) * q; }
+
+// forward (Cooley-Tukey) lazy butterfly: X,Y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, u64 q, u64 q2) {
+  const u64 x = X >= q2 ? X - q2 : X;
+  const u64 m = shoup_lazy(Y, t, q);
+  X = x + m;
+  Y = x + q2 - m;
+}
+// inverse (Gentleman-Sande) lazy butterfly: X,Y in [0,2q) -> [0,2q)
+__device__ __forceinline__ void bf_inv(u64& X, u64& Y, Tw t, u64 q, u64 q2) {
+  const u64 s = X + Y;
+  const u64 d = X + q2 - Y;
+  X = s >= q2 ? s - q2 : s;
+  Y = shoup_lazy(d, t, q);
+}
+
+// 4 forward stages on 16 registers; stage u pairs (k, k + (8>>u)), twiddle T_u[k / (16>>u)]
+__device__ __forceinline__ void radix16_fwd(u64 (&x)[16], const Tw& t0, const Tw (&t1)[2], const Tw (&t2)[4],
+                                            const Tw (&t3)[8], u64 q, u64 q2) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bf_fwd(x[k], x[k + 8], t0, q, q2);
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bf_fwd(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q2);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) bf_fwd(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q2);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bf_fwd(x[2 * g], x[2 * g + 1], t3[g], q, q2);
+}
+
+// 4 inverse stages (u = 3..1); stage u = 0 is handled by the caller (it may carry the N^-1 fold)
+__device__ __forceinline__ void radix16_inv_321(u64 (&x)[16], const Tw (&t1)[2], const Tw (&t2)[4], const Tw (&t3)[8],
+                                                u64 q, u64 q2) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bf_inv(x[2 * g], x[2 * g + 1], t3[g], q, q2);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) bf_inv(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q2);
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bf_inv(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q2);
+}
+__device__ __forceinline__ void radix16_inv_0(u64 (&x)[16], const Tw& t0, u64 q, u64 q2) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bf_inv(x[k], x[k + 8], t0, q, q2);
+}
+
+// twiddles of the 16-group with index `prefix` at stage `sbase`: T_u[i] = TW[2^(sbase+u) + (prefix<<u) + i]
+__device__ __forceinline__ void load_tw(const ulong2* __restrict__ TW, u32 sbase, u32 prefix, Tw& t0, Tw (&t1)[2],
+                                        Tw (&t2)[4], Tw (&t3)[8]) {
+  t0 = ldtw(TW, (1u << sbase) + prefix);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) t1[i] = ldtw(TW, (2u << sbase) + (prefix << 1) + i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t2[i] = ldtw(TW, (4u << sbase) + (prefix << 2) + i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t3[i] = ldtw(TW, (8u << sbase) + (prefix << 3) + i);
+}
+
+constexpr u32 kRowPitch = 17;        // strided tile: 256 rows x 16 cols, row pitch 17 words
+constexpr u32 kBlkPitch = 272;       // contig tile: 16 blocks x (256 + 16 pad) words
+__device__ __forceinline__ u32 cpad(u32 rho) { return rho + (rho >> 4); }
+
+// ------------------------------------------------------------------------------------------------
+// STRIDED pass (stages 0..7): tile = rows rho in [0,256) (coefficient index bits [logN-8,logN)),
+// columns col = chunk*16 + cc.  Round A lanes (g = tid>>4, cc = tid&15) hold rows 16k+g;
+// round B lanes (h = tid>>4, cc) hold rows 16h+g'.
+// ------------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha) {
+  __shared__ u64 lds[256 * kRowPitch];
+  u32 pos;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, q2 = 2 * q;
+  u64* __restrict__ X = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
+  const u32 log_s = c.logN - 8;
+  const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
+  const u32 col = blockIdx.x * 16 + cc;
+  u64 x[16];
+  Tw t0, t1[2], t2[4], t3[8];
+
+  if (!INVERSE) {
+    // round A: stages 0..3 (uniform twiddles TW[1..15])
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * k + hg) << log_s) + col];
+    load_tw(TW, 0, 0, t0, t1, t2, t3);
+    radix16_fwd(x, t0, t1, t2, t3, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[(16 * k + hg) * kRowPitch + cc] = x[k];
+    load_tw(TW, 4, hg, t0, t1, t2, t3);
+    __syncthreads();
+    // round B: stages 4..7
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[(16 * hg + k) * kRowPitch + cc];
+    radix16_fwd(x, t0, t1, t2, t3, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[((size_t)(16 * hg + k) << log_s) + col] = x[k];  // lazy [0,4q)
+  } else {
+    // round B first: stages 7..4 on rows 16h+g'
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * hg + k) << log_s) + col];
+    load_tw(TW, 4, hg, t0, t1, t2, t3);
+    radix16_inv_321(x, t1, t2, t3, q, q2);
+    radix16_inv_0(x, t0, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
+    load_tw(TW, 0, 0, t0, t1, t2, t3);
+    __syncthreads();
+    // round A: stages 3..1, then stage 0 with N^-1 folded in, canonical output
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
+    radix16_inv_321(x, t1, t2, t3, q, q2);
+    const Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 s = x[k] + x[k + 8];            // [0,4q)
+      const u64 d = x[k] + q2 - x[k + 8];       // (0,4q)
+      u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);
+      x[k] = a >= q ? a - q : a;
+      x[k + 8] = b >= q ? b - q : b;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[((size_t)(16 * k + hg) << log_s) + col] = x[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CONTIG pass (stages logN-8 .. logN-1): tile = 16 consecutive blocks o = chunk*16 + b of 256
+// contiguous coefficients, rho = index within the block.  Round A lanes (g = tid&15, b = tid>>4)
+// hold rho = 16k+g (each load instruction reads whole 128-byte lines); round B lanes (h = tid&15, b)
+// hold the 16 contiguous rho = 16h+g'.  The contiguous side goes through LDS so that global accesses
+// stay 16 bytes per lane, 1 KiB contiguous per wave instruction.
+// CANON_OUT (inverse only): write canonical values instead of lazy [0,2q) (needed when a generic
+// pass follows instead of the strided fast pass).
+// ------------------------------------------------------------------------------------------------
+template <bool INVERSE, bool CANON_OUT>
+__global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+                                                          u32 level, u32 pos0, u32 pos_off, u32 skip_alpha) {
+  __shared__ u64 lds[16 * kBlkPitch];
+  u32 pos;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, q2 = 2 * q;
+  u64* __restrict__ X = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N + (size_t)blockIdx.x * 4096;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
+  const u32 s8 = c.logN - 8;
+  const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
+  const u32 o = blockIdx.x * 16 + b;
+  u64 x[16];
+  Tw t0, t1[2], t2[4], t3[8];
+
+  if (!INVERSE) {
+    // round A: stages s8..s8+3 on rho = 16k + g
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = X[b * 256 + 16 * k + lo4];
+    load_tw(TW, s8, o, t0, t1, t2, t3);
+    radix16_fwd(x, t0, t1, t2, t3, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
+    load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+    __syncthreads();
+    // round B: stages s8+4..s8+7 on rho = 16h + g'
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
+    radix16_fwd(x, t0, t1, t2, t3, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {  // canonical output
+      u64 v = x[k] >= q2 ? x[k] - q2 : x[k];
+      x[k] = v >= q ? v - q : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // coalesced 16-byte stores
+      const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
+      ulong2 v;
+      v.x = lds[bb * kBlkPitch + cpad(rho)];
+      v.y = lds[bb * kBlkPitch + cpad(rho) + 1];
+      *reinterpret_cast<ulong2*>(X + e) = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
+      const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
+      const ulong2 v = *reinterpret_cast<const ulong2*>(X + e);
+      lds[bb * kBlkPitch + cpad(rho)] = v.x;
+      lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
+    }
+    load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+    __syncthreads();
+    // round B first: stages s8+7..s8+4 on the 16 contiguous rho = 16h + g'
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
+    radix16_inv_321(x, t1, t2, t3, q, q2);
+    radix16_inv_0(x, t0, q, q2);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
+    load_tw(TW, s8, o, t0, t1, t2, t3);
+    __syncthreads();
+    // round A: stages s8+3..s8 on rho = 16k + g
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * k + lo4];
+    radix16_inv_321(x, t1, t2, t3, q, q2);
+    radix16_inv_0(x, t0, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      u64 v = x[k];
+      if (CANON_OUT) v = v >= q ? v - q : v;
+      X[b * 256 + 16 * k + lo4] = v;
+    }
+  }
+}
+
+// logN >= 16 uses both fast passes when logN == 16; the contig pass alone serves the last 8 stages of
+// any logN >= 13 (the generic LDS kernel does the leading logN-8 stages).
+void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
+                     u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
+  dim3 block(256);
+  dim3 grid_s(c.N >> 12, n_limbs, n_polys), grid_c(c.N >> 12, n_limbs, n_polys);
+  if (!inverse) {
+    hipLaunchKernelGGL(ntt8_strided_kernel<false>, grid_s, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+    hipLaunchKernelGGL((ntt8_contig_kernel<false, true>), grid_c, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+  } else {
+    hipLaunchKernelGGL((ntt8_contig_kernel<true, false>), grid_c, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+    hipLaunchKernelGGL(ntt8_strided_kernel<true>, grid_s, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+  }
+}
+
+void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
+                        u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
+  dim3 block(256), grid(c.N >> 12, n_limbs, n_polys);
+  if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+  else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+}
+
+}  // namespace acehip
