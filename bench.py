@@ -200,7 +200,7 @@ def main():
             "config": {"workload": "C2 (BASELINE configs[1]): forward+inverse negacyclic NTT, N=2^16, batch of %d limbs "
                                    "per GPU (%d PQ-extended ciphertext pairs, L=25 K=7), bit-exact vs CPU rtlib" % (limbs, N_CT),
                        "N": N, "limbs_per_gpu": limbs, "bytes_per_step_per_gpu": step_bytes, "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel<strided> + ntt_pass_kernel<contig> (forward NTT launch)",
+            "roofline": {"bound": "hbm", "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(fwd_ms, 4), "inverse_launch_ms": round(inv_ms, 4),
