@@ -60,6 +60,11 @@ SYMBOLS = [
     ("acehip_rescale", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_switch", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_switch_bytes", _u64, [_vp, _u32]),
+    ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_sample_uniform", C.c_int, [_vp, _vp, _u32, _u32, _u32, _u64, _vp]),
+    ("acehip_mul_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
+    ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
 ]
 
 _lib = None

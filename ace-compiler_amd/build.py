@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libacehip.so")
-SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "api.cpp", "host_params.cpp"]
+SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "rt_kernels.hip", "api.cpp", "host_params.cpp"]
 HEADERS = ["kernels.hpp", "device_arith.hpp", "host_params.hpp", "rou_table.inc", os.path.join("..", "..", "include", "acehip.h")]
 
 
@@ -44,3 +44,34 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+# ---- rt_ant drop-in shim (host C++ over the C ABI of libacehip.so) ----
+RT_DIR = os.path.join(CSRC, "rt")
+RT_LIB = os.path.join(LIBDIR, "libFHErt_ant.so")
+RT_COMMON_LIB = os.path.join(LIBDIR, "libFHErt_common.so")
+RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp"]
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+
+def build_rt(force=False, verbose=False):
+    """libFHErt_ant.so: same link name as the reference provider library (scripts/perf.py:202-207)."""
+    build(force=force, verbose=verbose)
+    srcs = [os.path.join(RT_DIR, s) for s in RT_SOURCES]
+    deps = srcs + [os.path.join(RT_DIR, "rt_internal.hpp"), os.path.join(INCLUDE, "rt_ant", "ant_api.h"), LIB]
+    if not force and os.path.exists(RT_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RT_LIB) for d in deps):
+        return RT_LIB
+    cxx = shutil.which("g++") or "g++"
+    # -ffp-contract=off: the FP64 canonical embedding must round like the reference's (no FMA fusion)
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+           "-I", INCLUDE, "-o", RT_LIB] + srcs + ["-L", LIBDIR, "-lacehip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # libFHErt_common: the reference link line names it too; everything lives in libFHErt_ant here
+    stub = os.path.join(LIBDIR, "_common_stub.c")
+    with open(stub, "w") as f:
+        f.write("const char* FHErt_common_provider(void) { return \"acehip\"; }\n")
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-O2", "-fPIC", "-shared", "-o", RT_COMMON_LIB, stub])
+    os.remove(stub)
+    return RT_LIB

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -552,6 +553,40 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
   launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
   return post_launch();
+}
+
+int acehip_values_to_rns(acehip_ctx* c, uint64_t* d, const int64_t* vals, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  launch_values_to_rns(c->dc, d, vals, level, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_sample_uniform(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, uint64_t seed, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  launch_sample_uniform(c->dc, d, level, pos0, n, seed, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_mul_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (n > 64) return fail(ACEHIP_EINVAL, "acehip_mul_scalars: at most 64 limbs per call");
+  LimbConsts w{};
+  for (u32 i = 0; i < n; ++i) w.w[i] = h_scalars[i];
+  launch_mul_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_decomp(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, uint32_t digit, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp: bad level/digit");
+  const u32 start = c->hp.alpha * digit, n2 = std::min(c->hp.alpha, level - start);
+  HIP_TRY(hipMemcpyAsync(out, in + (size_t)start * c->hp.N, (size_t)n2 * c->hp.N * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return (int)n2;
+}
+int acehip_mod_up(acehip_ctx* c, uint64_t* out, const uint64_t* digit_limbs, uint32_t level, uint32_t digit, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_mod_up: bad level/digit");
+  const u32 start = c->hp.alpha * digit, n2 = std::min(c->hp.alpha, level - start);
+  // same pipeline as Decomp_modup with the digit limbs supplied separately
+  if (int e = do_decomp_modup(c, out, digit_limbs - (size_t)start * c->hp.N, level, digit, ws_at(c, 0), (hipStream_t)s)) return e;
+  return (int)n2;
 }
 
 uint64_t acehip_key_switch_bytes(const acehip_ctx* c, uint32_t level) {

@@ -83,6 +83,16 @@ void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pin
 void launch_rescale_spread(const DevCtx& c, u64* t, const u64* last, const u64* c1, const u64* c1p, u32 level, hipStream_t s);
 // Rescale tail: out[i] = shoup(x[i], inv[i]) + t[i]
 void launch_rescale_tail(const DevCtx& c, u64* out, const u64* x, const u64* t, const u64* inv, const u64* invp, u32 level, hipStream_t s);
+// ---- setup-side kernels (keygen / encode), rt_kernels.hip ----
+// out[pos][n] = vals[n] mod prime(pos) for signed 64-bit vals (Transform_values_to_rns polynomial.c:362-392)
+void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
+// uniform residues from a counter-based generator (Sample_uniform_poly polynomial.c:1349-1371)
+void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s);
+struct LimbConsts {
+  u64 w[64];
+};
+// r[pos] = a[pos] * w[pos - pos0] mod prime(pos)   (Scalars_integer_multiply_poly polynomial.c:234-268)
+void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // key inner product for one digit: acc{0,1}[pos] (+)= key{0,1}[gi(pos)] * ext[pos], pos < level+K
 void launch_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext, u32 level,
                     bool accumulate, hipStream_t s);

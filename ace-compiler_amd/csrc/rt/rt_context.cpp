@@ -1,0 +1,283 @@
+// rt_context.cpp -- global context, key generation, key accessors
+// (reference: src/rtlib/context.c:29-138, src/util/ckks_key_generator.c:69-335,
+//  src/util/random_sample.c:78-150, include/rtlib/key_gen.h:28-75).
+#include <cmath>
+#include <cstring>
+#include <ctime>
+
+#include "rt_internal.hpp"
+
+namespace rt {
+
+// Sample_triangle random_sample.c:78-97: -1 w.p. 1/4, +1 w.p. 1/4, 0 w.p. 1/2
+void sample_triangle(std::vector<int64_t>& v) {
+  Context& c = ctx();
+  for (auto& x : v) {
+    const u64 r = c.rng() & 3;
+    x = r == 0 ? -1 : (r == 1 ? 1 : 0);
+  }
+}
+
+// Sample_ternary random_sample.c:99-150: exactly `hamming_weight` non-zeros, signs roughly balanced
+void sample_ternary(std::vector<int64_t>& v, size_t hw) {
+  Context& c = ctx();
+  const size_t n = v.size();
+  if (hw == 0) {
+    for (auto& x : v) x = (int64_t)(c.rng() % 3) - 1;
+    return;
+  }
+  if (hw > n) hw = n;
+  int64_t ones = -1000000;
+  while (ones < (int64_t)hw / 2 - 1 || ones > (int64_t)hw / 2 + 1) {
+    ones = 0;
+    std::fill(v.begin(), v.end(), 0);
+    size_t weight = 0;
+    while (weight < hw) {
+      const size_t idx = c.rng() % n;
+      if (v[idx] == 0) {
+        if (c.rng() & 1) {
+          v[idx] = 1;
+          ++ones;
+        } else {
+          v[idx] = -1;
+        }
+        ++weight;
+      }
+    }
+  }
+}
+
+static u64 p_mod(u64 q) {  // P mod q
+  Context& c = ctx();
+  unsigned __int128 r = 1;
+  for (u32 j = 0; j < c.K; ++j) r = (r * (c.primes[c.L + j] % q)) % q;
+  return (u64)r;
+}
+
+// Generate_switching_key ckks_key_generator.c:127-200:  b_j = -a_j*old + e_j + P*new [digit j limbs]
+SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) {
+  Context& c = ctx();
+  const u32 T = c.L + c.K;
+  const size_t N = c.N, poly_words = (size_t)T * N;
+  auto* sk = new SwitchKeyStore();
+  sk->data = dalloc((size_t)c.dnum * 2 * poly_words, false);
+  sk->parts.resize(c.dnum);
+  POLYNOMIAL e{};
+  poly_alloc(&e, c.N, c.L, c.K);
+  u64* pm = dalloc(poly_words, false);
+  std::vector<int64_t> tri(N);
+  std::vector<u64> scal(T);
+  for (u32 j = 0; j < c.dnum; ++j) {
+    u64* b = sk->data + ((size_t)j * 2 + 0) * poly_words;
+    u64* a = sk->data + ((size_t)j * 2 + 1) * poly_words;
+    HIPCHK(acehip_sample_uniform(c.hip, a, c.L, 0, T, c.rng(), nullptr));            // a_j (NTT domain)
+    HIPCHK(acehip_modmul(c.hip, b, a, old_key_ntt, c.L, 0, T, nullptr));            // a_j * old
+    for (u32 i = 0; i < T; ++i) scal[i] = (i < c.L && i / c.alpha == j) ? p_mod(c.primes[i]) : 0;
+    HIPCHK(acehip_mul_scalars(c.hip, pm, new_key_ntt, scal.data(), c.L, 0, T, nullptr));  // P*new on digit j
+    sample_triangle(tri);
+    poly_from_small(&e, tri);
+    poly_ntt(&e, false);
+    HIPCHK(acehip_modadd(c.hip, pm, pm, (u64*)e._data, c.L, 0, T, nullptr));        // e + P*new
+    HIPCHK(acehip_modsub(c.hip, b, pm, b, c.L, 0, T, nullptr));                     // b = e + P*new - a*old
+    auto set = [&](POLYNOMIAL& p, u64* d) {
+      p._ring_degree = c.N;
+      p._num_alloc_primes = T;
+      p._num_primes = c.L;
+      p._num_primes_p = c.K;
+      p._is_ntt = true;
+      p._data = (int64_t*)d;
+    };
+    set(sk->parts[j]._pk0, b);
+    set(sk->parts[j]._pk1, a);
+  }
+  poly_free(&e);
+  dfree(pm);
+  sk->key._num_parts = c.dnum;
+  sk->key._parts = sk->parts.data();
+  return sk;
+}
+
+void free_switch_key(SwitchKeyStore* k) {
+  if (!k) return;
+  dfree(k->data);
+  delete k;
+}
+
+// Generate_rot_key (fast variant) :238-266: key from sigma_{k^-1}(s) ... applied before the automorphism
+SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
+  Context& c = ctx();
+  auto it = c.auto_keys.find(auto_idx);
+  if (it != c.auto_keys.end()) return it->second;
+  const u32 T = c.L + c.K;
+  // k^-1 mod 2N (k odd): k^(N-1)
+  u64 inv = 1, base = auto_idx, e = c.N - 1, m = 2ull * c.N;
+  for (; e; e >>= 1) {
+    if (e & 1) inv = inv * base % m;
+    base = base * base % m;
+  }
+  u64* old_key = dalloc((size_t)T * c.N, false);
+  const uint32_t* perm = acehip_auto_order(c.hip, (u32)inv);
+  RT_ASSERT(perm, "automorphism table: %s", acehip_last_error());
+  HIPCHK(acehip_rotate(c.hip, old_key, c.sk_ntt, perm, c.L, 0, T, nullptr));
+  SwitchKeyStore* k = make_switch_key(c.sk_ntt, old_key);
+  dfree(old_key);
+  c.auto_keys[auto_idx] = k;
+  return k;
+}
+
+u32 ensure_rot_key(int32_t rotation) {
+  Context& c = ctx();
+  auto it = c.rot2auto.find(rotation);
+  if (it != c.rot2auto.end()) return it->second;
+  const u32 k = acehip_auto_index(c.hip, rotation);
+  c.rot2auto[rotation] = k;
+  ensure_auto_key(k);
+  return k;
+}
+
+void generate_keys() {
+  Context& c = ctx();
+  const u32 T = c.L + c.K;
+  const size_t N = c.N;
+  // secret key (Generate_secret_key :69-83)
+  c.sk_coef.assign(N, 0);
+  sample_ternary(c.sk_coef, c.hamming);
+  POLYNOMIAL s{};
+  poly_alloc(&s, c.N, c.L, c.K);
+  poly_from_small(&s, c.sk_coef);
+  poly_ntt(&s, false);
+  c.sk_ntt = (u64*)s._data;  // ownership moves to the context
+  // public key (Generate_public_key :85-125): pk1 = a, pk0 = -a*s + e
+  c.pk0 = dalloc((size_t)c.L * N, false);
+  c.pk1 = dalloc((size_t)c.L * N, false);
+  HIPCHK(acehip_sample_uniform(c.hip, c.pk1, c.L, 0, c.L, c.rng(), nullptr));
+  POLYNOMIAL e{};
+  poly_alloc(&e, c.N, c.L, 0);
+  std::vector<int64_t> tri(N);
+  sample_triangle(tri);
+  poly_from_small(&e, tri);
+  poly_ntt(&e, false);
+  HIPCHK(acehip_modmul(c.hip, c.pk0, c.pk1, c.sk_ntt, c.L, 0, c.L, nullptr));
+  HIPCHK(acehip_modsub(c.hip, c.pk0, (u64*)e._data, c.pk0, c.L, 0, c.L, nullptr));
+  poly_free(&e);
+  // relinearisation key (Generate_relin_key :204-216): new = s^2 (q-limbs; p-limbs stay 0), old = s
+  u64* s2 = dalloc((size_t)T * N, true);
+  HIPCHK(acehip_modmul(c.hip, s2, c.sk_ntt, c.sk_ntt, c.L, 0, c.L, nullptr));
+  SwitchKeyStore* rk = make_switch_key(s2, c.sk_ntt);
+  dfree(s2);
+  c.relin = *rk;
+  c.relin.key._parts = c.relin.parts.data();
+  delete rk;
+  // rotation keys for the compiler-provided index list (Generate_rot_maps :290-335)
+  for (size_t i = 0; i < c.prm->_num_rot_idx; ++i) ensure_rot_key(c.prm->_rot_idxs[i]);
+}
+
+}  // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+void Prepare_context() {
+  if (g_ctx != nullptr) return;
+  CKKS_PARAMS* prm = Get_context_params();
+  RT_ASSERT(prm != nullptr, "Get_context_params() returned NULL");
+  RT_ASSERT(acehip_device_count() > 0, "no MI355X visible: the rt_ant HIP provider has no CPU fallback");
+  auto* c = new Context();
+  c->prm = prm;
+  int dev = 0;
+  if (const char* e = getenv("ACEHIP_DEVICE")) dev = atoi(e);
+  c->hip = acehip_ctx_create(prm->_poly_degree, (uint32_t)prm->_mul_depth + 1, (uint32_t)prm->_first_mod_size,
+                             (uint32_t)prm->_scaling_mod_size, (uint32_t)prm->_num_q_parts, dev);
+  RT_ASSERT(c->hip != nullptr, "acehip_ctx_create failed: %s", acehip_last_error());
+  c->N = prm->_poly_degree;
+  c->L = acehip_num_q(c->hip);
+  c->K = acehip_num_p(c->hip);
+  c->dnum = acehip_num_q_parts(c->hip);
+  c->alpha = acehip_part_size(c->hip);
+  c->sf_bits = (u32)prm->_scaling_mod_size;
+  c->q0_bits = (u32)prm->_first_mod_size;
+  c->sf = (double)(1ull << c->sf_bits);
+  c->hamming = prm->_hamming_weight;
+  c->primes.resize(c->L + c->K);
+  for (u32 i = 0; i < c->L + c->K; ++i) c->primes[i] = acehip_prime(c->hip, i);
+  c->qmod.resize(c->L);
+  c->pmod.resize(c->K ? c->K : 1);
+  for (u32 i = 0; i < c->L; ++i) c->qmod[i] = MODULUS{(int64_t)c->primes[i], i, 0};
+  for (u32 j = 0; j < c->K; ++j) c->pmod[j] = MODULUS{(int64_t)c->primes[c->L + j], c->L + j, 0};
+  u64 seed = std::random_device{}() ^ ((u64)time(nullptr) << 20);
+  if (const char* e = getenv("ACEHIP_SEED")) seed = strtoull(e, nullptr, 10);
+  c->rng.seed(seed);
+  // canonical-embedding tables (Precompute_fft ntt.c:587-610), m = 2N
+  const size_t m = 2ull * c->N;
+  c->fft_rou.resize(m);
+  for (size_t i = 0; i < m; ++i) {
+    const double angle = 2 * M_PI * i / m;
+    c->fft_rou[i] = cplx(cos(angle), sin(angle));
+  }
+  c->rot_group.resize(c->N / 2);
+  c->rot_group[0] = 1;
+  for (size_t i = 1; i < c->N / 2; ++i) c->rot_group[i] = (u32)((5ull * c->rot_group[i - 1]) % m);
+  g_ctx = c;
+  // first stdout line parsed by scripts/perf.py:266-276 (context.c:49-57)
+  printf("ckks_param: _provider = %d, _poly_degree = %d, _sec_level = %ld, mul_depth = %ld, _first_mod_size = %ld, "
+         "_scaling_mod_size = %ld, _num_q_parts = %ld, _num_p = %ld, _num_rot_idx = %ld,_hamming_wieght = %ld\n",
+         prm->_provider, prm->_poly_degree, (long)prm->_sec_level, (long)prm->_mul_depth, (long)prm->_first_mod_size,
+         (long)prm->_scaling_mod_size, (long)c->dnum, (long)c->K, (long)prm->_num_rot_idx, (long)prm->_hamming_weight);
+  generate_keys();
+  bootstrap_setup_if_needed();
+  RT_DATA_INFO* di = Get_rt_data_info();
+  if (di != nullptr) {
+    bool ok = Pt_mgr_init(di->_file_name);
+    RT_ASSERT(ok, "Pt_mgr_init(%s) failed", di->_file_name);
+  }
+  sync();
+}
+
+void Finalize_context() {
+  if (g_ctx == nullptr) return;
+  Context& c = *g_ctx;
+  sync();
+  if (Get_rt_data_info() != nullptr) Pt_mgr_fini();
+  const size_t key_words = (size_t)c.dnum * 2 * (c.L + c.K) * c.N;
+  const size_t rot_cnt = c.auto_keys.size();
+  const size_t rot_bytes = rot_cnt * key_words * 8;
+  const size_t total = rot_bytes + key_words * 8 + (size_t)(c.L + c.K) * c.N * 8 + 2ull * c.L * c.N * 8;
+  printf("Total memory size for keys: rot_key_cnt = %ld, rot_key_size = %ld bytes, total_key_size = %ld bytes\n",
+         (long)rot_cnt, (long)rot_bytes, (long)total);
+  printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)c.weight_plain_cnt,
+         (long)c.weight_plain_bytes);
+  for (auto& kv : c.auto_keys) free_switch_key(kv.second);
+  c.auto_keys.clear();
+  pool_release_all();
+  acehip_ctx_destroy(c.hip);
+  delete g_ctx;
+  g_ctx = nullptr;
+}
+
+// ---- key accessors (key_gen.h:28-75) ----
+uint32_t Auto_idx(int32_t rot_idx) { return ensure_rot_key(rot_idx); }
+int64_t* Auto_order(int32_t rot_idx) {
+  const uint32_t* perm = acehip_auto_order(ctx().hip, Auto_idx(rot_idx));
+  RT_ASSERT(perm != nullptr, "cannot get precompute automorphism order");
+  return (int64_t*)perm;
+}
+SW_KEY Swk(bool is_rot, int32_t rot_idx) {
+  if (!is_rot) return &ctx().relin.key;
+  return &ensure_auto_key(Auto_idx(rot_idx))->key;
+}
+POLY Pk0_at(SW_KEY swk, uint32_t idx) {
+  RT_ASSERT(idx < swk->_num_parts, "switch key part index out of range");
+  return &swk->_parts[idx]._pk0;
+}
+POLY Pk1_at(SW_KEY swk, uint32_t idx) {
+  RT_ASSERT(idx < swk->_num_parts, "switch key part index out of range");
+  return &swk->_parts[idx]._pk1;
+}
+
+void Run_main_graph() {  // common/src/rt_lib.c:16-21
+  bool ok = Main_graph();
+  RT_ASSERT(ok, "Main_graph() failed");
+}
+
+}  // extern "C"

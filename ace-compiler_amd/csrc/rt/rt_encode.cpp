@@ -1,0 +1,425 @@
+// rt_encode.cpp -- CKKS encode / decode / encrypt / decrypt.
+// Reference: src/util/ckks_encoder.c:199-297 (Encode_impl, 64-bit path), :464-530 (Encode_val_at_level),
+// :649-703 (Decode), src/util/ntt.c:678-753 (Embedding / Embedding_inv), src/util/ckks_encryptor.c:20-95,
+// src/util/ckks_decryptor.c:19-65, src/ckks/plain_eval.c:17-58.
+// The FP64 embedding runs on the host exactly as the reference does (same butterfly order, libm
+// cos/sin table, no FMA contraction: this file is compiled with -ffp-contract=off); the integer
+// part (RNS reduction, scaling, NTT) runs on the device.
+#include <cmath>
+#include <cstring>
+
+#include "rt_internal.hpp"
+
+namespace rt {
+
+static inline u32 bitrev(u32 v, u32 width) {
+  u32 r = 0;
+  for (u32 i = 0; i < width; ++i) r |= ((v >> i) & 1u) << (width - 1 - i);
+  return r;
+}
+static void bit_reverse_vec(std::vector<cplx>& v) {
+  const size_t n = v.size();
+  u32 w = 0;
+  while ((1u << w) < n) ++w;
+  std::vector<cplx> t(n);
+  for (size_t i = 0; i < n; ++i) t[i] = v[bitrev((u32)i, w)];
+  v.swap(t);
+}
+static inline cplx cmul(const cplx& a, const cplx& b) {  // (ac - bd) + (ad + bc)i, C99 operand order
+  return cplx(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real());
+}
+
+// Embedding_inv ntt.c:713-753
+void embedding_inv(std::vector<cplx>& vals) {
+  Context& c = ctx();
+  const size_t n = vals.size(), m = 2ull * c.N;
+  u32 logn = 0;
+  while ((1u << logn) < n) ++logn;
+  for (u32 logm = logn; logm > 0; --logm) {
+    const size_t idx_mod = 1ull << (logm + 2), gap = m / idx_mod, num1 = 1ull << logm, num2 = 1ull << (logm - 1);
+    for (size_t j = 0; j < n; j += num1) {
+      for (size_t i = 0; i < num2; ++i) {
+        const size_t e = j + i, o = j + i + num2;
+        const size_t rou_idx = (idx_mod - (c.rot_group[i] % idx_mod)) * gap;
+        const cplx plus = vals[e] + vals[o];
+        cplx minus = vals[e] - vals[o];
+        minus = cmul(minus, c.fft_rou[rou_idx]);
+        vals[e] = plus;
+        vals[o] = minus;
+      }
+    }
+  }
+  bit_reverse_vec(vals);
+  for (auto& v : vals) v = cplx(v.real() / (double)n, v.imag() / (double)n);
+}
+
+// Embedding ntt.c:678-711
+void embedding(std::vector<cplx>& vals) {
+  Context& c = ctx();
+  const size_t n = vals.size(), m = 2ull * c.N;
+  u32 logn = 0;
+  while ((1u << logn) < n) ++logn;
+  bit_reverse_vec(vals);
+  for (u32 logm = 1; logm <= logn; ++logm) {
+    const size_t idx_mod = 1ull << (logm + 2), gap = m / idx_mod, num = 1ull << (logm - 1);
+    for (size_t j = 0; j < n; j += (1ull << logm)) {
+      for (size_t i = 0; i < num; ++i) {
+        const size_t e = j + i, o = j + i + num;
+        const size_t rou_idx = (c.rot_group[i] % idx_mod) * gap;
+        const cplx f = cmul(c.fft_rou[rou_idx], vals[o]);
+        const cplx plus = vals[e] + f, minus = vals[e] - f;
+        vals[e] = plus;
+        vals[o] = minus;
+      }
+    }
+  }
+}
+
+// Init_plaintext plaintext.h:114-129
+void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree) {
+  Context& c = ctx();
+  p->_scaling_factor = sf;
+  p->_sf_degree = sf_degree;
+  p->_slots = slots;
+  POLYNOMIAL* poly = &p->_poly;
+  if (poly->_data == nullptr || (poly->_num_primes + poly->_num_primes_p) == 0) {
+    if (poly->_data) poly_free(poly);
+    poly_alloc(poly, c.N, nq, np);
+  } else {
+    RT_ASSERT(poly->_num_primes == nq && poly->_num_primes_p == np, "unmatched size");
+  }
+}
+
+static u64 mulmod(u64 a, u64 b, u64 m) { return (u64)(((unsigned __int128)a * b) % m); }
+
+// Encode_impl ckks_encoder.c:199-297
+void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
+  Context& c = ctx();
+  RT_ASSERT(res, "null plaintext");
+  const u32 N = c.N;
+  if (slots == 0) slots = N / 2;
+  if (level == 0) level = c.L;
+  RT_ASSERT(level <= c.L, "level should not be larger than mul_depth + 1");
+  RT_ASSERT(len <= slots, "slot size is too small");
+  RT_ASSERT(slots <= N / 2, " slot size > N/2 ");
+  RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
+  std::vector<cplx> v(slots, cplx(0, 0));
+  for (size_t i = 0; i < len; ++i) v[i] = values[i];
+  embedding_inv(v);
+  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree);
+  std::vector<int64_t> msg(N, 0);
+  const u32 gap = N / (slots * 2);
+  for (u32 i = 0; i < slots; ++i) {
+    const double re = v[i].real() * c.sf + 0.5, im = v[i].imag() * c.sf + 0.5;
+    RT_ASSERT(re <= 9.2e18 && re >= -9.2e18 && im <= 9.2e18 && im >= -9.2e18,
+              "encode overflow, please choose a smaller scaling factor");
+    // the reference stores negatives as Max_64bit_value()+v and maps them back per limb
+    // (ckks_encoder.c:262-265, polynomial.c:369-391); the signed value is what every limb reduces
+    msg[(size_t)i * gap] = llround(re);
+    msg[(size_t)(i + slots) * gap] = llround(im);
+  }
+  POLYNOMIAL* poly = &res->_poly;
+  u64* tmp = dalloc(N, false);
+  HIPCHK(acehip_memcpy_h2d(tmp, msg.data(), (size_t)N * 8, nullptr));
+  HIPCHK(acehip_values_to_rns(c.hip, q_limbs(poly), (const int64_t*)tmp, level, 0, level, nullptr));
+  if (p_cnt) HIPCHK(acehip_values_to_rns(c.hip, p_limbs(poly), (const int64_t*)tmp, 0, 0, p_cnt, nullptr));
+  dfree(tmp);
+  if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) per limb
+    std::vector<u64> powp(level);
+    const u64 sfi = (u64)c.sf;
+    for (u32 i = 0; i < level; ++i) {
+      const u64 q = c.primes[i];
+      u64 pw = sfi % q;
+      for (u32 d = 2; d < sf_degree; ++d) pw = mulmod(pw, sfi % q, q);
+      powp[i] = pw;
+    }
+    HIPCHK(acehip_mul_scalars(c.hip, q_limbs(poly), q_limbs(poly), powp.data(), level, 0, level, nullptr));
+  }
+  poly->_is_ntt = false;
+  poly_ntt(poly, false);
+}
+
+// Encode_val_at_level ckks_encoder.c:464-530 (+ Scale_back_up_by_approxfactor :406-460)
+void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree) {
+  Context& c = ctx();
+  RT_ASSERT(res && sf_degree, "invalid plaintext / scaling factor degree");
+  if (level == 0) level = c.L;
+  RT_ASSERT(level <= c.L, "level should not be larger than mul_depth + 1");
+  const u32 N = c.N;
+  init_plaintext(res, N / 2, level, 0, pow(c.sf, (double)sf_degree), sf_degree);
+  const int MAX_BITS_IN_WORD = 61, MAX_LOG_STEP = 60;
+  const int32_t log_sf = (int32_t)ceil(log2(fabs(value * c.sf)));
+  const int32_t log_valid = log_sf <= MAX_BITS_IN_WORD ? log_sf : MAX_BITS_IN_WORD;
+  int32_t log_approx = log_sf - log_valid;
+  const double approx_factor = pow(2, log_approx);
+  const double scaled = value / approx_factor * c.sf + 0.5;
+  RT_ASSERT(scaled <= 9.2e18 && scaled >= -9.2e18, "encode overflow, please choose a smaller scaling factor");
+  const int64_t val = (int64_t)scaled;
+  const int64_t sfs = (int64_t)(c.sf + 0.5);
+  std::vector<u64> consts(level);
+  for (u32 i = 0; i < level; ++i) {
+    const u64 q = c.primes[i];
+    int64_t r = val % (int64_t)q;
+    if (r < 0) r += (int64_t)q;
+    u64 rv = (u64)r;
+    for (u32 j = 1; j < sf_degree; ++j) rv = mulmod(rv, (u64)sfs % q, q);
+    consts[i] = rv;
+  }
+  if (log_approx > 0) {
+    int32_t log_step = log_approx <= MAX_BITS_IN_WORD ? log_approx : MAX_BITS_IN_WORD;
+    std::vector<u64> approx(level);
+    for (u32 i = 0; i < level; ++i) approx[i] = (1ull << log_step) % c.primes[i];
+    int32_t rest = log_approx - log_step;
+    while (rest > 0) {
+      log_step = rest <= MAX_LOG_STEP ? rest : MAX_LOG_STEP;
+      for (u32 i = 0; i < level; ++i) approx[i] = mulmod(approx[i], (1ull << log_step) % c.primes[i], c.primes[i]);
+      rest -= log_step;
+    }
+    for (u32 i = 0; i < level; ++i) consts[i] = mulmod(consts[i], approx[i], c.primes[i]);
+  }
+  // every coefficient of limb i equals consts[i] (a constant polynomial in the NTT domain)
+  std::vector<int64_t> ones(N, 1);
+  u64* tmp = dalloc(N, false);
+  HIPCHK(acehip_memcpy_h2d(tmp, ones.data(), (size_t)N * 8, nullptr));
+  HIPCHK(acehip_values_to_rns(c.hip, q_limbs(&res->_poly), (const int64_t*)tmp, level, 0, level, nullptr));
+  dfree(tmp);
+  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level, nullptr));
+  res->_poly._is_ntt = true;
+}
+
+// exact CRT reconstruction of coefficient i over `level` primes, centred, as a double
+// (Reconstruct_rns_poly_to_values polynomial.c:467-499 + mpz_get_d in Decode :669-683)
+struct Crt {
+  u32 level;
+  std::vector<u64> inv;                  // (Q/q_i)^-1 mod q_i
+  std::vector<std::vector<u64>> hat;     // Q/q_i as little-endian words
+  std::vector<u64> Q, halfQ;
+  size_t words;
+};
+static void mp_mul_small(std::vector<u64>& a, u64 b) {
+  u64 carry = 0;
+  for (auto& w : a) {
+    unsigned __int128 t = (unsigned __int128)w * b + carry;
+    w = (u64)t;
+    carry = (u64)(t >> 64);
+  }
+  if (carry) a.push_back(carry);
+}
+static int mp_cmp(const std::vector<u64>& a, const std::vector<u64>& b) {
+  for (size_t i = a.size(); i-- > 0;)
+    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+static Crt make_crt(u32 level) {
+  Context& c = ctx();
+  Crt k;
+  k.level = level;
+  k.Q.assign(1, 1);
+  for (u32 i = 0; i < level; ++i) mp_mul_small(k.Q, c.primes[i]);
+  k.words = k.Q.size() + 1;
+  k.Q.resize(k.words, 0);
+  k.halfQ = k.Q;
+  for (size_t i = 0; i < k.words; ++i) k.halfQ[i] = (k.Q[i] >> 1) | (i + 1 < k.words ? k.Q[i + 1] << 63 : 0);
+  k.hat.resize(level);
+  k.inv.resize(level);
+  for (u32 i = 0; i < level; ++i) {
+    std::vector<u64> h(1, 1);
+    u64 hm = 1;
+    const u64 qi = c.primes[i];
+    for (u32 j = 0; j < level; ++j)
+      if (j != i) {
+        mp_mul_small(h, c.primes[j]);
+        hm = mulmod(hm, c.primes[j] % qi, qi);
+      }
+    h.resize(k.words, 0);
+    k.hat[i] = h;
+    u64 e = qi - 2, b = hm, r = 1;  // hm^-1 mod qi
+    for (; e; e >>= 1) {
+      if (e & 1) r = mulmod(r, b, qi);
+      b = mulmod(b, b, qi);
+    }
+    k.inv[i] = r;
+  }
+  return k;
+}
+static double crt_to_double(const Crt& k, const u64* residues /*[level]*/) {
+  Context& c = ctx();
+  std::vector<u64> acc(k.words + 1, 0);
+  for (u32 i = 0; i < k.level; ++i) {
+    const u64 y = mulmod(residues[i], k.inv[i], c.primes[i]);
+    u64 carry = 0;
+    for (size_t w = 0; w < k.words; ++w) {
+      unsigned __int128 t = (unsigned __int128)k.hat[i][w] * y + acc[w] + carry;
+      acc[w] = (u64)t;
+      carry = (u64)(t >> 64);
+    }
+    acc[k.words] += carry;
+  }
+  // acc < level * Q: subtract Q while >= Q
+  std::vector<u64> Qx = k.Q;
+  Qx.resize(k.words + 1, 0);
+  while (mp_cmp(acc, Qx) >= 0) {
+    u64 borrow = 0;
+    for (size_t w = 0; w < acc.size(); ++w) {
+      unsigned __int128 t = (unsigned __int128)acc[w] - Qx[w] - borrow;
+      acc[w] = (u64)t;
+      borrow = (u64)(t >> 64) ? 1 : 0;
+    }
+  }
+  std::vector<u64> hq = k.halfQ;
+  hq.resize(k.words + 1, 0);
+  bool neg = mp_cmp(acc, hq) > 0;
+  if (neg) {  // acc = Q - acc
+    u64 borrow = 0;
+    for (size_t w = 0; w < acc.size(); ++w) {
+      unsigned __int128 t = (unsigned __int128)Qx[w] - acc[w] - borrow;
+      acc[w] = (u64)t;
+      borrow = (u64)(t >> 64) ? 1 : 0;
+    }
+  }
+  long double r = 0;
+  for (size_t w = acc.size(); w-- > 0;) r = r * 18446744073709551616.0L + (long double)acc[w];
+  double d = (double)r;
+  return neg ? -d : d;
+}
+
+// Decode ckks_encoder.c:649-703
+void decode(std::vector<cplx>& out, PLAINTEXT* plain) {
+  Context& c = ctx();
+  POLYNOMIAL* poly = &plain->_poly;
+  const u32 level = (u32)poly->_num_primes, N = c.N, half_n = N / 2, slots = plain->_slots, gap = half_n / slots;
+  if (poly->_is_ntt) poly_ntt(poly, true);
+  std::vector<u64> host((size_t)level * N);
+  HIPCHK(acehip_memcpy_d2h(host.data(), q_limbs(poly), host.size() * 8, nullptr));
+  Crt k = make_crt(level);
+  std::vector<cplx> msg(slots);
+  std::vector<u64> r(level);
+  for (u32 i = 0; i < slots; ++i) {
+    for (u32 l = 0; l < level; ++l) r[l] = host[(size_t)l * N + (size_t)i * gap];
+    const double re = crt_to_double(k, r.data()) / plain->_scaling_factor;
+    for (u32 l = 0; l < level; ++l) r[l] = host[(size_t)l * N + (size_t)i * gap + half_n];
+    const double im = crt_to_double(k, r.data()) / plain->_scaling_factor;
+    msg[i] = cplx(re, im);
+  }
+  embedding(msg);
+  out = msg;
+}
+
+// Encrypt_msg ckks_encryptor.c:20-95:  c0 = pk0*v + e1 + m,  c1 = pk1*v + e2
+void encrypt(CIPHERTEXT* res, PLAINTEXT* plain) {
+  Context& c = ctx();
+  POLYNOMIAL* m = &plain->_poly;
+  const u32 l = (u32)m->_num_primes;
+  res->_scaling_factor = plain->_scaling_factor;
+  res->_sf_degree = plain->_sf_degree;
+  res->_slots = plain->_slots;
+  poly_init_like(&res->_c0_poly, m);
+  poly_init_like(&res->_c1_poly, m);
+  std::vector<int64_t> tri(c.N);
+  POLYNOMIAL v{}, e1{}, e2{};
+  poly_alloc(&v, c.N, l, 0);
+  poly_alloc(&e1, c.N, l, 0);
+  poly_alloc(&e2, c.N, l, 0);
+  sample_triangle(tri); poly_from_small(&v, tri); poly_ntt(&v, false);
+  sample_triangle(tri); poly_from_small(&e1, tri); poly_ntt(&e1, false);
+  sample_triangle(tri); poly_from_small(&e2, tri); poly_ntt(&e2, false);
+  u64* c0 = q_limbs(&res->_c0_poly);
+  u64* c1 = q_limbs(&res->_c1_poly);
+  HIPCHK(acehip_modmul(c.hip, c0, c.pk0, q_limbs(&v), l, 0, l, nullptr));
+  HIPCHK(acehip_modadd(c.hip, c0, q_limbs(&e1), c0, l, 0, l, nullptr));
+  HIPCHK(acehip_modadd(c.hip, c0, c0, q_limbs(m), l, 0, l, nullptr));
+  HIPCHK(acehip_modmul(c.hip, c1, c.pk1, q_limbs(&v), l, 0, l, nullptr));
+  HIPCHK(acehip_modadd(c.hip, c1, q_limbs(&e2), c1, l, 0, l, nullptr));
+  res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = true;
+  poly_free(&v);
+  poly_free(&e1);
+  poly_free(&e2);
+}
+
+// Decrypt ckks_decryptor.c:19-65:  m = c0 + c1*s
+void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph) {
+  Context& c = ctx();
+  const u32 l = (u32)ciph->_c0_poly._num_primes;
+  init_plaintext(res, ciph->_slots, l, ciph->_c0_poly._num_primes_p, ciph->_scaling_factor, ciph->_sf_degree);
+  u64* r = q_limbs(&res->_poly);
+  HIPCHK(acehip_modmul(c.hip, r, q_limbs(&ciph->_c1_poly), c.sk_ntt, l, 0, l, nullptr));
+  HIPCHK(acehip_modadd(c.hip, r, q_limbs(&ciph->_c0_poly), r, l, 0, l, nullptr));
+  res->_poly._is_ntt = true;
+}
+
+}  // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+// plain_eval.c:25-58
+void Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_degree, uint32_t level) {
+  if (len == 1) {
+    encode_value(plain, (double)*input, level, sc_degree);
+    return;
+  }
+  std::vector<cplx> v(len);
+  for (size_t i = 0; i < len; ++i) v[i] = cplx((double)input[i], 0.0);
+  encode_vector(plain, v.data(), len, level, 0, sc_degree, 0);
+  ctx().weight_plain_cnt++;
+  ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+}
+void Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t sc_degree, uint32_t level) {
+  if (len == 1) {
+    encode_value(plain, *input, level, sc_degree);
+    return;
+  }
+  std::vector<cplx> v(len);
+  for (size_t i = 0; i < len; ++i) v[i] = cplx(input[i], 0.0);
+  encode_vector(plain, v.data(), len, level, 0, sc_degree, 0);
+  ctx().weight_plain_cnt++;
+  ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+}
+
+CIPHER Encrypt(CIPHER res, PLAIN plain) {
+  encrypt(res, plain);
+  return res;
+}
+
+// cipher_eval.c:129-150: decrypt + decode, real parts
+double* Get_msg(CIPHER ciph) {
+  PLAINTEXT pt;
+  memset(&pt, 0, sizeof(pt));
+  decrypt(&pt, ciph);
+  std::vector<cplx> out;
+  decode(out, &pt);
+  double* data = (double*)malloc(sizeof(double) * out.size());
+  for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
+  poly_free(&pt._poly);
+  return data;
+}
+double* Get_msg_from_plain(PLAIN plain) {
+  PLAINTEXT pt = *plain;  // decode converts to the coefficient domain in place: work on a copy
+  pt._poly._data = nullptr;
+  poly_alloc(&pt._poly, plain->_poly._ring_degree, plain->_poly._num_primes, plain->_poly._num_primes_p);
+  poly_copy(&pt._poly, &plain->_poly);
+  std::vector<cplx> out;
+  decode(out, &pt);
+  double* data = (double*)malloc(sizeof(double) * out.size());
+  for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
+  poly_free(&pt._poly);
+  return data;
+}
+void Print_cipher_msg(FILE* fp, const char* name, CIPHER ciph, uint32_t len) {
+  double* m = Get_msg(ciph);
+  fprintf(fp, "[%s] level=%zu slots=%u sf_degree=%u: [", name, Level(ciph), ciph->_slots, ciph->_sf_degree);
+  for (uint32_t i = 0; i < len && i < ciph->_slots; ++i) fprintf(fp, " %.6f", m[i]);
+  fprintf(fp, " ]\n");
+  free(m);
+}
+void Dump_cipher_msg(const char* name, CIPHER ciph, uint32_t len) { Print_cipher_msg(stdout, name, ciph, len); }
+void Validate(CIPHER ciph, double* msg, uint32_t len, int32_t epsilon) {
+  double* m = Get_msg(ciph);
+  const double eps = pow(10.0, (double)epsilon);
+  for (uint32_t i = 0; i < len; ++i)
+    RT_ASSERT(fabs(m[i] - msg[i]) < eps, "Validate failed at %u: %f != %f", i, m[i], msg[i]);
+  free(m);
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// rt_internal.hpp -- internals of the rt_ant drop-in shim (libFHErt_ant.so).
+//
+// The shim is the host side of the boundary: it mirrors the reference provider API
+// (include/rt_ant/ant_api.h) and forwards every polynomial operation to the HIP library through the
+// C ABI of include/acehip.h.  No arithmetic on coefficients happens on the host except the FP64
+// canonical embedding of encode/decode and the final CRT reconstruction of decode, which the
+// reference also does on the CPU (ckks_encoder.c:199-297, :649-703).
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "acehip.h"
+#include "common/pt_mgr.h"
+#include "common/rt_api.h"
+#include "common/rt_stat.h"
+#include "rt_ant/ant_api.h"
+#include "rt_ant/rt_api.h"
+
+#define RT_ASSERT(cond, ...)                              \
+  do {                                                    \
+    if (!(cond)) {                                        \
+      fprintf(stderr, "%s:%d: ", __FILE__, __LINE__);     \
+      fprintf(stderr, __VA_ARGS__);                       \
+      fprintf(stderr, "\n");                              \
+      abort();                                            \
+    }                                                     \
+  } while (0)
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    int rc_ = (expr);                                                                      \
+    if (rc_ < 0) {                                                                         \
+      fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
+      abort();                                                                             \
+    }                                                                                      \
+  } while (0)
+
+namespace rt {
+
+using u64 = uint64_t;
+using u32 = uint32_t;
+using cplx = std::complex<double>;
+
+struct SwitchKeyStore {
+  SWITCH_KEY key;                 // what Swk() returns; _parts[d]._pk0/_pk1 point into `data`
+  std::vector<PUBLIC_KEY> parts;
+  u64* data = nullptr;            // [dnum][2][L+K][N] on the device (layout of acehip_key_switch)
+};
+
+struct Context {
+  acehip_ctx* hip = nullptr;
+  CKKS_PARAMS* prm = nullptr;
+  u32 N = 0, L = 0, K = 0, dnum = 0, alpha = 0, sf_bits = 0, q0_bits = 0;
+  size_t hamming = 0;
+  double sf = 0;                  // default scaling factor 2^sf_bits
+  std::vector<MODULUS> qmod, pmod;
+  std::vector<u64> primes;        // [L+K]
+  // keys on the device
+  u64* sk_ntt = nullptr;          // [L+K][N] NTT domain
+  u64* pk0 = nullptr;             // [L][N]
+  u64* pk1 = nullptr;
+  SwitchKeyStore relin;
+  std::map<u32, SwitchKeyStore*> auto_keys;   // automorphism index -> key
+  std::map<int32_t, u32> rot2auto;            // rotation -> automorphism index
+  std::vector<int64_t> sk_coef;               // ternary secret, host copy (signed)
+  std::mt19937_64 rng;
+  // FFT tables for the canonical embedding (ntt.c:587-610): m = 2N
+  std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
+  std::vector<u32> rot_group;     // 5^i mod 2N
+  // statistics
+  size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
+};
+
+extern Context* g_ctx;
+Context& ctx();
+
+// ---- device memory pool (stream-ordered reuse; generated code does thousands of Alloc/Free) ----
+u64* dalloc(size_t words, bool zero);
+void dfree(u64* p);
+void pool_release_all();
+size_t pool_bytes_in_use();
+
+// ---- polynomial helpers on POLYNOMIAL structs (device data) ----
+void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np);           // Alloc_poly_data polynomial.h:54
+void poly_free(POLYNOMIAL* p);                                         // Free_poly_data   :71
+void poly_init_like(POLYNOMIAL* res, POLYNOMIAL* like);                // Init_poly        :331
+void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src);                      // Copy_polynomial
+u64* q_limbs(POLYNOMIAL* p);
+u64* p_limbs(POLYNOMIAL* p);
+enum class Op { Add, Sub, Mul, MulAdd };
+// res = a (op) b over the q-limbs of res (+ p-limbs when with_p)
+void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p);
+void poly_ntt(POLYNOMIAL* p, bool inverse);                            // Conv_poly2ntt_inplace / ntt2poly
+void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx);        // Rotate_poly (NTT domain)
+void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transform_values_at_level(without_mod)
+void sync();
+
+// ---- sampling (random_sample.c) ----
+void sample_triangle(std::vector<int64_t>& v);                         // :78-97
+void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight);   // :99-150
+
+// ---- keys (ckks_key_generator.c) ----
+void generate_keys();
+SwitchKeyStore* make_switch_key(const u64* new_key_ntt /*[L+K][N]*/, const u64* old_key_ntt);
+u32 ensure_rot_key(int32_t rotation);   // Insert_rot_map :290; returns automorphism index
+SwitchKeyStore* ensure_auto_key(u32 auto_idx);
+void free_switch_key(SwitchKeyStore* k);
+
+// ---- encode / decode (ckks_encoder.c) ----
+void embedding_inv(std::vector<cplx>& vals);                           // ntt.c:713-753
+void embedding(std::vector<cplx>& vals);                               // ntt.c:678-711
+void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt);
+void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree);
+void decode(std::vector<cplx>& out, PLAINTEXT* plain);
+void encrypt(CIPHERTEXT* res, PLAINTEXT* plain);                       // ckks_encryptor.c:20-95
+void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph);                        // ckks_decryptor.c:19-65
+void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree);
+
+void bootstrap_setup_if_needed();
+
+}  // namespace rt

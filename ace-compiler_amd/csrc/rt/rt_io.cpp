@@ -1,0 +1,238 @@
+// rt_io.cpp -- program-facing glue: tensors, IO tables, Prepare_input / Handle_output,
+// Get_input_data / Set_output_data, per-op timers, and the message-file weight manager.
+// Reference: common/src/{tensor.c,io_lib.c,rt_stat.c,pt_mgr.c:182-191,rt_data_file.c},
+// ant/src/rtlib/rtlib.c:20-87, include/fhe/core/rt_data_def.h:90-109.
+#include <fcntl.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstring>
+#include <ctime>
+
+#include "rt_internal.hpp"
+
+using namespace rt;
+
+namespace {
+
+struct IoSlot {
+  const char* name;
+  std::vector<void*> ct;
+};
+thread_local std::vector<IoSlot> g_inputs, g_outputs;
+thread_local bool g_io_ready = false;
+
+void io_init() {
+  if (g_io_ready) return;
+  for (int i = 0; i < Get_input_count(); ++i) {
+    DATA_SCHEME* s = Get_encode_scheme(i);
+    g_inputs.push_back(IoSlot{s->_name, std::vector<void*>((size_t)s->_count, nullptr)});
+  }
+  for (int i = 0; i < Get_output_count(); ++i) {
+    DATA_SCHEME* s = Get_decode_scheme(i);
+    g_outputs.push_back(IoSlot{s->_name, std::vector<void*>((size_t)s->_count, nullptr)});
+  }
+  g_io_ready = true;
+}
+void*& io_at(std::vector<IoSlot>& tab, const char* name, size_t idx) {
+  for (auto& s : tab)
+    if (strcmp(s.name, name) == 0) {
+      RT_ASSERT(idx < s.ct.size(), "index out of bounds");
+      return s.ct[idx];
+    }
+  RT_ASSERT(false, "fail to find %s.", name);
+  static void* dummy = nullptr;
+  return dummy;
+}
+
+double now_s() {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+thread_local double g_tm_stamp = 0;
+
+// message-file weight manager (DE_MSG_F32): header page, entries, LUT at the end
+struct DataFileHdr {
+  char _magic[8];
+  uint32_t _rt_ver;
+  uint16_t _flag;
+  uint8_t _ent_type;
+  uint8_t _ent_align;
+  uint64_t _ent_count;
+  uint64_t _lut_ofst;
+  struct timespec _ctime;
+  char _model[48];
+  char _uuid[40];
+};
+struct DataLutEntry {
+  char _name[16];
+  uint32_t _index;
+  uint32_t _size;
+  uint64_t _ent_ofst;
+};
+struct PtMgr {
+  DataFileHdr hdr;
+  std::vector<DataLutEntry> lut;
+  std::vector<char> buf;  // all messages (file bytes [4096, lut_ofst))
+  bool open = false;
+} g_pt;
+
+}  // namespace
+
+extern "C" {
+
+// ---- tensor.c ----
+TENSOR* Alloc_tensor(size_t n, size_t c, size_t h, size_t w, const double* vals) {
+  const size_t tsize = n * c * h * w * sizeof(double);
+  TENSOR* t = (TENSOR*)malloc(sizeof(TENSOR) + tsize);
+  t->_shape._n = n;
+  t->_shape._c = c;
+  t->_shape._h = h;
+  t->_shape._w = w;
+  if (vals == nullptr) memset(t->_vals, 0, tsize);
+  else memcpy(t->_vals, vals, tsize);
+  return t;
+}
+void Free_tensor(TENSOR* tensor) { free(tensor); }
+bool Is_tensor_match(TENSOR* a, TENSOR* b) {
+  return TENSOR_N(a) == TENSOR_N(b) && TENSOR_C(a) == TENSOR_C(b) && TENSOR_H(a) == TENSOR_H(b) && TENSOR_W(a) == TENSOR_W(b);
+}
+TENSOR* Add_tensor(TENSOR* a, TENSOR* b) {
+  RT_ASSERT(Is_tensor_match(a, b), "input tensor not match");
+  TENSOR* r = Alloc_tensor(TENSOR_N(a), TENSOR_C(a), TENSOR_H(a), TENSOR_W(a), nullptr);
+  const size_t n = TENSOR_SIZE(a);
+  for (size_t i = 0; i < n; ++i) r->_vals[i] = a->_vals[i] + b->_vals[i];
+  return r;
+}
+void Print_tensor(FILE* fp, TENSOR* t) {
+  fprintf(fp, "(tensor): [\n");
+  for (size_t n = 0; n < TENSOR_N(t); n++) {
+    if (n) fprintf(fp, "\n");
+    for (size_t c = 0; c < TENSOR_C(t); c++) {
+      if (c) fprintf(fp, "\n");
+      for (size_t h = 0; h < TENSOR_H(t); h++) {
+        if (h) fprintf(fp, "\n");
+        for (size_t w = 0; w < TENSOR_W(t); w++) fprintf(fp, " %f", TENSOR_ELEM(t, n, c, h, w));
+      }
+    }
+  }
+  fprintf(fp, "\n]\n");
+}
+
+// ---- rt_stat.c:14-28 (wall clock here: the work is on the GPU, CPU clock() would read ~0) ----
+void Tm_start(const char*) { g_tm_stamp = now_s(); }
+void Tm_taken(const char* msg) {
+  rt::sync();
+  const double cur = now_s();
+  fprintf(stdout, "[RT_STAT] %s takes %.3f seconds.\n", msg, cur - g_tm_stamp);
+  g_tm_stamp = cur;
+}
+
+// ---- rtlib.c:41-87 ----
+void Prepare_input(TENSOR* input, const char* name) {
+  io_init();
+  const size_t len = TENSOR_SIZE(input);
+  std::vector<cplx> v(len);
+  for (size_t i = 0; i < len; ++i) v[i] = cplx(input->_vals[i], 0.0);
+  PLAINTEXT pt;
+  memset(&pt, 0, sizeof(pt));
+  encode_vector(&pt, v.data(), len, 0, 0, 1, 0);  // ENCODE: full level, default slots, sf_degree 1
+  CIPHER ct = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
+  encrypt(ct, &pt);
+  poly_free(&pt._poly);
+  io_at(g_inputs, name, 0) = ct;
+}
+
+double* Handle_output(const char* name) {
+  io_init();
+  CIPHER ct = (CIPHER)io_at(g_outputs, name, 0);
+  RT_ASSERT(ct != nullptr, "not find data");
+  PLAINTEXT pt;
+  memset(&pt, 0, sizeof(pt));
+  decrypt(&pt, ct);
+  std::vector<cplx> out;
+  decode(out, &pt);
+  double* data = (double*)malloc(out.size() * sizeof(double));
+  for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
+  poly_free(&pt._poly);
+  Free_cipher(ct);
+  io_at(g_outputs, name, 0) = nullptr;
+  return data;
+}
+
+CIPHERTEXT Get_input_data(const char* name, size_t idx) {
+  io_init();
+  CIPHERTEXT* data = (CIPHERTEXT*)io_at(g_inputs, name, idx);
+  RT_ASSERT(data != nullptr, "not find data");
+  CIPHERTEXT ret = *data;
+  free(data);  // only the shell: the polys now belong to the caller (rtlib.c:74-80)
+  io_at(g_inputs, name, idx) = nullptr;
+  return ret;
+}
+
+void Set_output_data(const char* name, size_t idx, CIPHER data) {
+  io_init();
+  CIPHER out = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
+  Copy_ciph(out, data);
+  Free_ciph_poly(data, 1);
+  io_at(g_outputs, name, idx) = out;
+}
+
+// ---- pt_mgr.c (message mode) ----
+bool Pt_mgr_init(const char* fname) {
+  int fd = open(fname, O_RDONLY);
+  if (fd < 0) return false;
+  bool ok = pread(fd, &g_pt.hdr, sizeof(DataFileHdr), 0) == (ssize_t)sizeof(DataFileHdr) &&
+            memcmp(g_pt.hdr._magic, "!ANTFHE\0", 8) == 0;
+  if (ok) {
+    g_pt.lut.resize(g_pt.hdr._ent_count);
+    const size_t lut_bytes = sizeof(DataLutEntry) * g_pt.lut.size();
+    ok = pread(fd, g_pt.lut.data(), lut_bytes, g_pt.hdr._lut_ofst) == (ssize_t)lut_bytes;
+  }
+  if (ok) {
+    RT_ASSERT(g_pt.hdr._ent_type != DE_PLAINTEXT,
+              "DE_PLAINTEXT data files are not supported yet by the HIP provider (use DE_MSG_F32)");
+    const size_t sz = g_pt.hdr._lut_ofst - 4096;
+    g_pt.buf.resize(sz);
+    ok = pread(fd, g_pt.buf.data(), sz, 4096) == (ssize_t)sz;
+  }
+  close(fd);
+  g_pt.open = ok;
+  return ok;
+}
+void Pt_mgr_fini() {
+  g_pt.buf.clear();
+  g_pt.lut.clear();
+  g_pt.open = false;
+}
+void Pt_prefetch(uint32_t) {}
+void* Pt_get(uint32_t, size_t, uint32_t, uint32_t) {
+  RT_ASSERT(false, "Pt_get: DE_PLAINTEXT data files are not supported yet");
+  return nullptr;
+}
+void* Pt_get_validate(float*, uint32_t, size_t, uint32_t, uint32_t) {
+  RT_ASSERT(false, "TODO: not implemented");
+  return nullptr;
+}
+void Pt_free(uint32_t) {}
+static float* pt_entry(uint32_t index, size_t len) {
+  RT_ASSERT(g_pt.open, "weight data file is not open");
+  RT_ASSERT(index < g_pt.lut.size(), "index out of entry range");
+  RT_ASSERT(g_pt.lut[index]._size >= len * sizeof(float), "entry size too small");
+  const uint64_t ofst = g_pt.lut[index]._ent_ofst - 4096;
+  RT_ASSERT(ofst + len * sizeof(float) <= g_pt.buf.size(), "entry offset too large");
+  return (float*)&g_pt.buf[ofst];
+}
+void Pt_from_msg(void* pt, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
+  Encode_plain_from_float((PLAIN)pt, pt_entry(index, len), len, scale, level);
+}
+void Pt_from_msg_validate(void* pt, float* buf, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
+  float* data = pt_entry(index, len);
+  for (uint32_t i = 0; i < len; ++i)
+    RT_ASSERT(fabs(buf[i] - data[i]) < 0.000001, "Pt_from_msg_validate failed. index=%d, i=%d: %f != %f.", index, i, buf[i], data[i]);
+  Encode_plain_from_float((PLAIN)pt, data, len, scale, level);
+}
+
+}  // extern "C"

@@ -1,0 +1,419 @@
+// rt_poly.cpp -- device memory pool, POLYNOMIAL helpers and the polynomial/ciphertext part of the
+// rt_ant API (reference: include/poly/poly_eval.h, src/poly/{poly_eval,poly_arith}.c,
+// src/ckks/cipher_eval.c:18-123, include/util/{polynomial,ciphertext}.h).
+#include <cstring>
+
+#include "rt_internal.hpp"
+
+namespace rt {
+
+Context* g_ctx = nullptr;
+Context& ctx() {
+  RT_ASSERT(g_ctx != nullptr, "rt_ant context is not prepared (call Prepare_context first)");
+  return *g_ctx;
+}
+
+// ---- pool: exact-size free lists.  All launches go to the default stream in program order, so a
+// buffer released by Free_* can be handed out again immediately: later kernels are ordered after
+// earlier ones.  Nothing is returned to the driver before Finalize_context (hipFree synchronises).
+static std::mutex pool_mu;
+static std::map<size_t, std::vector<u64*>> pool_free;
+static std::map<u64*, size_t> pool_live;
+static size_t pool_live_bytes = 0;
+
+u64* dalloc(size_t words, bool zero) {
+  if (words == 0) words = 1;
+  u64* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    auto it = pool_free.find(words);
+    if (it != pool_free.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+    }
+  }
+  if (!p) {
+    p = (u64*)acehip_malloc(words * sizeof(u64));
+    RT_ASSERT(p != nullptr, "device allocation of %zu bytes failed: %s", words * sizeof(u64), acehip_last_error());
+  }
+  {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    pool_live[p] = words;
+    pool_live_bytes += words * sizeof(u64);
+  }
+  if (zero) HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
+  return p;
+}
+
+void dfree(u64* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(pool_mu);
+  auto it = pool_live.find(p);
+  RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
+  pool_live_bytes -= it->second * sizeof(u64);
+  pool_free[it->second].push_back(p);
+  pool_live.erase(it);
+}
+
+void pool_release_all() {
+  std::lock_guard<std::mutex> lk(pool_mu);
+  for (auto& kv : pool_free)
+    for (u64* p : kv.second) acehip_free(p);
+  pool_free.clear();
+  for (auto& kv : pool_live) acehip_free(kv.first);
+  pool_live.clear();
+  pool_live_bytes = 0;
+}
+size_t pool_bytes_in_use() { return pool_live_bytes; }
+
+void sync() { HIPCHK(acehip_stream_sync(nullptr)); }
+
+// ---- POLYNOMIAL helpers ----
+void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np) {
+  p->_ring_degree = N;
+  p->_num_primes = nq;
+  p->_num_primes_p = np;
+  p->_num_alloc_primes = nq + np;
+  p->_is_ntt = false;
+  p->_data = (int64_t*)dalloc((size_t)(nq + np) * N, true);
+}
+void poly_free(POLYNOMIAL* p) {
+  if (p->_data) {
+    dfree((u64*)p->_data);
+    p->_data = nullptr;
+  }
+  p->_num_alloc_primes = 0;
+}
+// Init_poly polynomial.h:331-348: allocate, or reuse + zero-fill
+void poly_init_like(POLYNOMIAL* res, POLYNOMIAL* like) {
+  const u32 N = like->_ring_degree;
+  const size_t nq = like->_num_primes, np = like->_num_primes_p;
+  if (res->_data == nullptr) {
+    poly_alloc(res, N, nq, np);
+  } else {
+    if (res->_num_alloc_primes * (size_t)res->_ring_degree < (nq + np) * (size_t)N) {
+      poly_free(res);
+      poly_alloc(res, N, nq, np);
+    } else {
+      HIPCHK(acehip_memset(res->_data, 0, res->_num_alloc_primes * (size_t)res->_ring_degree * 8, nullptr));
+      res->_ring_degree = N;
+      res->_num_primes = nq;
+      res->_num_primes_p = np;
+      if (res->_num_alloc_primes == 0) res->_num_alloc_primes = nq + np;
+      res->_is_ntt = false;
+    }
+  }
+}
+u64* q_limbs(POLYNOMIAL* p) { return (u64*)p->_data; }
+u64* p_limbs(POLYNOMIAL* p) { return (u64*)p->_data + (p->_num_alloc_primes - p->_num_primes_p) * (size_t)p->_ring_degree; }
+
+// Copy_polynomial (polynomial.h): copies q part and p part
+void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src) {
+  if (res == src) return;
+  const size_t N = src->_ring_degree;
+  RT_ASSERT(res->_data && res->_num_alloc_primes >= src->_num_primes + src->_num_primes_p, "Copy_poly: result too small");
+  res->_num_primes = src->_num_primes;
+  res->_num_primes_p = src->_num_primes_p;
+  res->_is_ntt = src->_is_ntt;
+  if (src->_num_primes) HIPCHK(acehip_memcpy_d2d(q_limbs(res), q_limbs(src), src->_num_primes * N * 8, nullptr));
+  if (src->_num_primes_p) HIPCHK(acehip_memcpy_d2d(p_limbs(res), p_limbs(src), src->_num_primes_p * N * 8, nullptr));
+}
+
+void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p) {
+  Context& c = ctx();
+  auto fn = op == Op::Add ? acehip_modadd : op == Op::Sub ? acehip_modsub : op == Op::Mul ? acehip_modmul : acehip_modmuladd;
+  const u32 l = (u32)res->_num_primes;
+  if (l) HIPCHK(fn(c.hip, q_limbs(res), q_limbs(a), q_limbs(b), l, 0, l, nullptr));
+  if (with_p && res->_num_primes_p) {
+    // level 0: position j -> prime p_j
+    HIPCHK(fn(c.hip, p_limbs(res), p_limbs(a), p_limbs(b), 0, 0, (u32)res->_num_primes_p, nullptr));
+  }
+}
+
+void poly_ntt(POLYNOMIAL* p, bool inverse) {
+  Context& c = ctx();
+  auto fn = inverse ? acehip_ntt_inverse : acehip_ntt_forward;
+  const u32 l = (u32)p->_num_primes;
+  if (l) HIPCHK(fn(c.hip, q_limbs(p), l, 0, l, nullptr));
+  if (p->_num_primes_p) HIPCHK(fn(c.hip, p_limbs(p), 0, 0, (u32)p->_num_primes_p, nullptr));
+  p->_is_ntt = !inverse;
+}
+
+void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx) {
+  Context& c = ctx();
+  const uint32_t* perm = acehip_auto_order(c.hip, auto_idx);
+  RT_ASSERT(perm != nullptr, "automorphism table: %s", acehip_last_error());
+  const u32 l = (u32)a->_num_primes;
+  if (l) HIPCHK(acehip_rotate(c.hip, q_limbs(res), q_limbs(a), perm, l, 0, l, nullptr));
+  if (a->_num_primes_p) HIPCHK(acehip_rotate(c.hip, p_limbs(res), p_limbs(a), perm, 0, 0, (u32)a->_num_primes_p, nullptr));
+  res->_is_ntt = a->_is_ntt;
+}
+
+// small signed values -> residues on every limb of p (q then p)
+void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals) {
+  Context& c = ctx();
+  u64* tmp = dalloc(c.N, false);
+  HIPCHK(acehip_memcpy_h2d(tmp, vals.data(), c.N * 8, nullptr));
+  const u32 l = (u32)p->_num_primes;
+  if (l) HIPCHK(acehip_values_to_rns(c.hip, q_limbs(p), (const int64_t*)tmp, l, 0, l, nullptr));
+  if (p->_num_primes_p) HIPCHK(acehip_values_to_rns(c.hip, p_limbs(p), (const int64_t*)tmp, 0, 0, (u32)p->_num_primes_p, nullptr));
+  dfree(tmp);
+  p->_is_ntt = false;
+}
+
+static u32 gi_of(MODULUS* m) { return m->_gi; }
+
+}  // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+// ---- context accessors (context.c:140-160) ----
+uint32_t Degree() { return ctx().N; }
+double Get_default_sc() { return ctx().sf; }
+size_t Get_q_parts() { return ctx().dnum; }
+size_t Get_p_cnt() { return ctx().K; }
+MODULUS* Q_modulus() { return ctx().qmod.data(); }
+MODULUS* P_modulus() { return ctx().pmod.data(); }
+
+// ---- poly_eval.h:29-113 ----
+POLY Alloc_poly(uint32_t degree, size_t q_primes, bool extend_p) {
+  RT_ASSERT(q_primes > 0, "Alloc_poly: q primes should not be NULL");
+  POLY p = (POLY)malloc(sizeof(POLYNOMIAL));
+  poly_alloc(p, degree, q_primes, extend_p ? ctx().K : 0);
+  p->_is_ntt = true;  // "hard code for now, ntt should be set by compiler" (poly_eval.h:34-35)
+  return p;
+}
+void Free_poly_data(POLY poly) { poly_free(poly); }
+void Free_poly(POLY poly) {
+  poly_free(poly);
+  free(poly);
+}
+void Copy_poly(POLY res, POLY poly) { poly_copy(res, poly); }
+void Set_coeffs(POLY dst, uint32_t level, uint32_t degree, int64_t* src) {
+  int64_t* d = Coeffs(dst, level, degree);
+  if (d == src) return;  // generated code does self-copies (resnet20 .inc:1546)
+  HIPCHK(acehip_memcpy_d2d(d, src, (size_t)degree * 8, nullptr));
+}
+size_t Num_decomp(POLY poly) { return acehip_num_decomp(ctx().hip, (uint32_t)poly->_num_primes); }
+
+// ---- poly_arith.c:14-56: one limb per call, modulus = Q_modulus()+i or P_modulus()+i ----
+int64_t* Hw_modadd(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
+  HIPCHK(acehip_hw_modadd(ctx().hip, (u64*)res, (u64*)a, (u64*)b, m->_gi, nullptr));
+  return res + degree;
+}
+int64_t* Hw_modmul(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
+  HIPCHK(acehip_hw_modmul(ctx().hip, (u64*)res, (u64*)a, (u64*)b, m->_gi, nullptr));
+  return res + degree;
+}
+int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, uint32_t degree) {
+  if (res == a) {  // the reference loop would read overwritten data too; keep it well defined
+    u64* tmp = dalloc(degree, false);
+    HIPCHK(acehip_memcpy_d2d(tmp, a, (size_t)degree * 8, nullptr));
+    HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, tmp, (const uint32_t*)rot_precomp, m->_gi, nullptr));
+    dfree(tmp);
+  } else {
+    HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, (u64*)a, (const uint32_t*)rot_precomp, m->_gi, nullptr));
+  }
+  return res + degree;
+}
+
+// ---- poly_eval.c:11-49 ----
+POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
+  Context& c = ctx();
+  const u32 level = (u32)poly->_num_primes;
+  const u32 start = c.alpha * q_part_idx;
+  RT_ASSERT(q_part_idx < acehip_num_decomp(c.hip, level), "Decomp: part index out of range");
+  const u32 n2 = std::min(c.alpha, level - start);
+  if (res->_num_alloc_primes < n2) {  // Decompose_poly polynomial.c:860-866
+    poly_free(res);
+    poly_alloc(res, c.N, n2, 0);
+  } else {
+    res->_num_primes = n2;
+    res->_num_primes_p = 0;
+  }
+  int rc = acehip_decomp(c.hip, q_limbs(res), q_limbs(poly), level, q_part_idx, nullptr);
+  HIPCHK(rc);
+  res->_is_ntt = poly->_is_ntt;
+  return res;
+}
+POLY Mod_up(POLY new_poly, POLY old_poly, uint32_t q_part_idx) {
+  Context& c = ctx();
+  const u32 level = (u32)new_poly->_num_primes;  // Raise_rns_base_with_parts(.., Poly_level(new_poly), ..)
+  RT_ASSERT(new_poly->_num_primes_p == c.K && new_poly->_num_alloc_primes - c.K == level,
+            "raise_rns_base: result size not match");
+  RT_ASSERT(old_poly->_is_ntt, "Mod_up: coefficient-domain input is not supported by the HIP path");
+  HIPCHK(acehip_mod_up(c.hip, q_limbs(new_poly), q_limbs(old_poly), level, q_part_idx, nullptr));
+  new_poly->_is_ntt = true;
+  return new_poly;
+}
+POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
+  Context& c = ctx();
+  const u32 level = (u32)poly->_num_primes;
+  RT_ASSERT(res->_num_primes == level && res->_num_primes_p == c.K && res->_num_alloc_primes == level + c.K,
+            "Decomp_modup: result must be allocated with Alloc_poly(degree, Poly_level(poly), 1)");
+  RT_ASSERT(poly->_is_ntt, "Decomp_modup: coefficient-domain input is not supported by the HIP path");
+  HIPCHK(acehip_decomp_modup(c.hip, q_limbs(res), q_limbs(poly), level, q_part_idx, nullptr));
+  res->_is_ntt = true;
+  return res;
+}
+POLY Mod_down(POLY res, POLY poly) {
+  Context& c = ctx();
+  const u32 level = (u32)poly->_num_primes;
+  RT_ASSERT(res->_num_primes == level && poly->_num_primes_p == c.K, "reduce_rns_base: result size not match");
+  RT_ASSERT(poly->_num_alloc_primes - c.K == level, "Mod_down: p-limbs must follow the q-limbs");
+  HIPCHK(acehip_mod_down(c.hip, q_limbs(res), q_limbs(poly), level, nullptr));
+  res->_is_ntt = poly->_is_ntt;
+  return res;
+}
+POLY Rescale(POLY res, POLY poly) {
+  Context& c = ctx();
+  const u32 level = (u32)poly->_num_primes;
+  RT_ASSERT(res->_num_primes == level, "Rescale_poly: primes not match");
+  RT_ASSERT(level > 1, "Rescale_poly: level not enough after rescale");
+  if (res == poly || res->_data == poly->_data) {
+    u64* tmp = dalloc((size_t)(level - 1) * c.N, false);
+    HIPCHK(acehip_rescale(c.hip, tmp, q_limbs(poly), level, nullptr));
+    HIPCHK(acehip_memcpy_d2d(q_limbs(res), tmp, (size_t)(level - 1) * c.N * 8, nullptr));
+    dfree(tmp);
+  } else {
+    HIPCHK(acehip_rescale(c.hip, q_limbs(res), q_limbs(poly), level, nullptr));
+  }
+  res->_is_ntt = true;
+  res->_num_primes = level - 1;  // Mod_down_q_primes polynomial.h:300
+  return res;
+}
+
+// ---- ciphertext metadata (cipher_eval.c:18-123, ciphertext.h) ----
+static void init_ciphertext(CIPHER res, u32 N, size_t nq, size_t np, double sf, u32 sf_degree, u32 slots) {
+  res->_scaling_factor = sf;  // Init_ciphertext ciphertext.h:179-205: allocate only if empty, never clears
+  res->_sf_degree = sf_degree;
+  res->_slots = slots;
+  if (res->_c0_poly._data == nullptr) poly_alloc(&res->_c0_poly, N, nq, np);
+  else RT_ASSERT(res->_c0_poly._ring_degree == N && res->_c0_poly._num_primes == nq, "unmatched ciphertxt");
+  if (res->_c1_poly._data == nullptr) poly_alloc(&res->_c1_poly, N, nq, np);
+  else RT_ASSERT(res->_c1_poly._ring_degree == N && res->_c1_poly._num_primes == nq, "unmatched ciphertxt");
+}
+static void set_level(CIPHER c, size_t level) {
+  c->_c0_poly._num_primes = level;
+  c->_c1_poly._num_primes = level;
+}
+// Adjust_level(ciph1, ciph2, resize=false) ciphertext.h:283-325: the operand with the smaller level
+static CIPHER lower_level(CIPHER a, CIPHER b) {
+  RT_ASSERT(a && b, "invalid ciph");
+  if (a->_c0_poly._data == nullptr) return b;
+  RT_ASSERT(b->_c0_poly._data != nullptr, "poly coeffs of input ciph is invalid");
+  return a->_c0_poly._num_primes > b->_c0_poly._num_primes ? b : a;
+}
+// Init_cipher cipher_eval.c:18-30: Init_ciphertext_from_ciph (zero-fill on reuse unless res == ciph)
+static void init_cipher_from(CIPHER res, CIPHER ciph, double sf, u32 sf_degree) {
+  res->_scaling_factor = sf;
+  res->_sf_degree = sf_degree;
+  res->_slots = ciph->_slots;
+  if (res != ciph) {
+    poly_init_like(&res->_c0_poly, &ciph->_c0_poly);
+    poly_init_like(&res->_c1_poly, &ciph->_c1_poly);
+  }
+  res->_c0_poly._is_ntt = true;
+  res->_c1_poly._is_ntt = true;
+  set_level(res, ciph->_c0_poly._num_primes);
+}
+
+void Init_ciph_same_scale(CIPHER res, CIPHER ciph1, CIPHER ciph2) {
+  CIPHER c = ciph2 != nullptr ? lower_level(ciph1, ciph2) : ciph1;
+  init_ciphertext(res, c->_c0_poly._ring_degree, c->_c0_poly._num_primes, c->_c0_poly._num_primes_p, c->_scaling_factor,
+                  c->_sf_degree, c->_slots);
+  res->_c0_poly._is_ntt = true;
+  res->_c1_poly._is_ntt = true;
+}
+void Init_ciph_same_scale_plain(CIPHER res, CIPHER ciph, PLAIN) { init_cipher_from(res, ciph, ciph->_scaling_factor, ciph->_sf_degree); }
+void Init_ciph_up_scale(CIPHER res, CIPHER c1, CIPHER c2) {
+  CIPHER c = lower_level(c1, c2);
+  init_cipher_from(res, c, c1->_scaling_factor * c2->_scaling_factor, c1->_sf_degree + c2->_sf_degree);
+}
+void Init_ciph_up_scale_plain(CIPHER res, CIPHER ciph, PLAIN plain) {
+  init_cipher_from(res, ciph, ciph->_scaling_factor * plain->_scaling_factor, ciph->_sf_degree + plain->_sf_degree);
+}
+void Init_ciph_down_scale(CIPHER res, CIPHER ciph) {
+  init_cipher_from(res, ciph, ciph->_scaling_factor / ctx().sf, ciph->_sf_degree - 1);
+}
+static void init_from3(POLYNOMIAL* r0, POLYNOMIAL* r1, POLYNOMIAL* s0, POLYNOMIAL* s1) {
+  poly_init_like(r0, s0);
+  poly_init_like(r1, s1);
+}
+void Init_ciph_same_scale_ciph3(CIPHER res, CIPHER3 ciph) {
+  RT_ASSERT(res, "invalid ciphertext");
+  res->_scaling_factor = ciph->_scaling_factor;
+  res->_sf_degree = ciph->_sf_degree;
+  res->_slots = ciph->_slots;
+  init_from3(&res->_c0_poly, &res->_c1_poly, &ciph->_c0_poly, &ciph->_c1_poly);
+  res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = true;
+  set_level(res, ciph->_c0_poly._num_primes);
+}
+void Init_ciph3_same_scale_ciph3(CIPHER3 res, CIPHER3 c1, CIPHER3 c2) {
+  RT_ASSERT(res, "invalid ciphertext");
+  CIPHER3 c = c1;
+  if (c2 != nullptr && c1->_c0_poly._data != nullptr && c2->_c0_poly._num_primes < c1->_c0_poly._num_primes) c = c2;
+  if (c2 != nullptr && c1->_c0_poly._data == nullptr) c = c2;
+  res->_scaling_factor = c->_scaling_factor;
+  res->_sf_degree = c->_sf_degree;
+  res->_slots = c->_slots;
+  if (res != c) {
+    poly_init_like(&res->_c0_poly, &c->_c0_poly);
+    poly_init_like(&res->_c1_poly, &c->_c1_poly);
+    poly_init_like(&res->_c2_poly, &c->_c2_poly);
+  }
+  res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = res->_c2_poly._is_ntt = true;
+  res->_c0_poly._num_primes = res->_c1_poly._num_primes = res->_c2_poly._num_primes = c->_c0_poly._num_primes;
+}
+void Init_ciph3_up_scale(CIPHER3 res, CIPHER c1, CIPHER c2) {
+  RT_ASSERT(res, "invalid ciphertext");
+  CIPHER c = lower_level(c1, c2);
+  res->_scaling_factor = c1->_scaling_factor * c2->_scaling_factor;
+  res->_sf_degree = c1->_sf_degree + c2->_sf_degree;
+  res->_slots = c->_slots;
+  RT_ASSERT(c->_c0_poly._num_primes_p == 0, "invalid num of p primes");
+  poly_init_like(&res->_c0_poly, &c->_c0_poly);
+  poly_init_like(&res->_c1_poly, &c->_c0_poly);
+  poly_init_like(&res->_c2_poly, &c->_c0_poly);
+  res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = res->_c2_poly._is_ntt = true;
+  res->_c0_poly._num_primes = res->_c1_poly._num_primes = res->_c2_poly._num_primes = c->_c0_poly._num_primes;
+}
+void Copy_ciph(CIPHER res, CIPHER ciph) {  // Copy_ciphertext ciphertext.h:247-253
+  if (res == ciph) return;
+  res->_scaling_factor = ciph->_scaling_factor;
+  res->_sf_degree = ciph->_sf_degree;
+  res->_slots = ciph->_slots;
+  poly_init_like(&res->_c0_poly, &ciph->_c0_poly);
+  poly_init_like(&res->_c1_poly, &ciph->_c1_poly);
+  poly_copy(&res->_c0_poly, &ciph->_c0_poly);
+  poly_copy(&res->_c1_poly, &ciph->_c1_poly);
+}
+size_t Level(CIPHER ciph) { return ciph->_c0_poly._num_primes; }
+uint32_t Sc_degree(CIPHER ciph) { return ciph->_sf_degree; }
+uint32_t Get_slots(CIPHER ciph) { return ciph->_slots; }
+void Set_slots(CIPHER ciph, uint32_t slots) { ciph->_slots = slots; }
+void Free_ciph_poly(CIPHER ciph, uint32_t cnt) {
+  for (uint32_t i = 0; i < cnt; ++i) {
+    poly_free(&ciph[i]._c0_poly);
+    poly_free(&ciph[i]._c1_poly);
+  }
+}
+void Zero_ciph(CIPHER ciph) {
+  poly_free(&ciph->_c0_poly);
+  poly_free(&ciph->_c1_poly);
+  memset(ciph, 0, sizeof(*ciph));
+}
+void Free_cipher(CIPHER ciph) {
+  if (!ciph) return;
+  poly_free(&ciph->_c0_poly);
+  poly_free(&ciph->_c1_poly);
+  free(ciph);
+}
+void Free_plain(PLAIN plain) {
+  if (!plain) return;
+  poly_free(&plain->_poly);
+}
+
+}  // extern "C"

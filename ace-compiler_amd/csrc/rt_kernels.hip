@@ -1,0 +1,72 @@
+// rt_kernels.hip -- setup-side kernels used by key generation, encryption and encoding
+// (one-time or per-input work, not the per-op hot path).
+#include "kernels.hpp"
+
+namespace acehip {
+
+// out[pos][n] = vals[n] mod q (canonical), vals signed 64-bit
+__global__ __launch_bounds__(256) void values_to_rns_kernel(DevCtx c, u64* __restrict__ out, const int64_t* __restrict__ vals,
+                                                            u32 level, u32 pos0) {
+  const u32 pos = pos0 + blockIdx.y;
+  const DevPrime& P = c.primes[limb_prime(pos, level, c.L)];
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= c.N) return;
+  const int64_t v = vals[n];
+  const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+  u64 r = mag < P.q ? mag : reduce128(U128{mag, 0}, P.q, P.prec128_lo, P.prec128_hi);
+  if (v < 0 && r != 0) r = P.q - r;
+  out[(size_t)pos * c.N + n] = r;
+}
+
+void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(values_to_rns_kernel, grid, block, 0, s, c, out, vals, level, pos0);
+}
+
+__device__ __forceinline__ u64 mix64(u64 z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// uniform in [0,q): 128 random bits reduced mod q (bias < 2^-60)
+__global__ __launch_bounds__(256) void sample_uniform_kernel(DevCtx c, u64* __restrict__ out, u32 level, u32 pos0, u64 seed) {
+  const u32 pos = pos0 + blockIdx.y;
+  const DevPrime& P = c.primes[limb_prime(pos, level, c.L)];
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= c.N) return;
+  const u64 ctr = ((u64)pos << 32) | n;
+  const u64 a = mix64(seed + 0x9E3779B97F4A7C15ull * (2 * ctr + 1));
+  const u64 b = mix64(a ^ (seed * 0xD1342543DE82EF95ull + 2 * ctr + 2));
+  out[(size_t)pos * c.N + n] = reduce128(U128{a, b >> 4}, P.q, P.prec128_lo, P.prec128_hi);
+}
+
+void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(sample_uniform_kernel, grid, block, 0, s, c, out, level, pos0, seed);
+}
+
+__global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
+                                                          LimbConsts w, u32 level, u32 pos0) {
+  const u32 pos = pos0 + blockIdx.y;
+  const DevPrime P = c.primes[limb_prime(pos, level, c.L)];
+  const u64 wl = w.w[blockIdx.y];
+  const size_t base = (size_t)pos * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  ulong2 v = *reinterpret_cast<const ulong2*>(a + base + i);
+  v.x = mul_mod(v.x, wl, P);
+  v.y = mul_mod(v.y, wl, P);
+  *reinterpret_cast<ulong2*>(r + base + i) = v;
+}
+
+void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs,
+                        hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(mul_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);
+}
+
+}  // namespace acehip

@@ -129,6 +129,23 @@ int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint3
 int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in,
                       const uint64_t* d_key, uint32_t level, acehip_stream stream);
 
+/* ---- setup-side entry points (key generation, encryption, encoding: SURVEY 8 rows a15-a18) ----
+ * d_poly[pos][n] = d_vals[n] mod prime(pos), d_vals signed 64-bit on the device
+ *   (Transform_values_to_rns polynomial.c:362-392 / Transform_values_at_level :432). */
+int acehip_values_to_rns(acehip_ctx* ctx, uint64_t* d_poly, const int64_t* d_vals, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* uniformly random residues (Sample_uniform_poly polynomial.c:1349-1371; the generator differs from the
+ * reference's BLAKE2 PRNG: key material is random by construction, parity is per operator) */
+int acehip_sample_uniform(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, uint64_t seed, acehip_stream stream);
+/* d_res[pos] = d_a[pos] * h_scalars[pos - pos0] mod prime(pos); h_scalars is a HOST array of n_limbs words
+ * (Scalars_integer_multiply_poly polynomial.c:234-268, Scalar_integer_multiply_poly :198) */
+int acehip_mul_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* the unfused pair of the generated code (eg_fhertlib_relin.inc:79-80):
+ * Decomp (poly_eval.c:11 -> Decompose_poly polynomial.c:848): d_out[0..n2) = digit limbs of d_in;
+ * Mod_up (poly_eval.c:19 -> Raise_rns_base_with_parts polynomial.c:877-925): d_digit (n2 limbs, NTT
+ * domain) raised to level+K limbs of d_out.  Both return the digit size n2 (>0) or a negative error. */
+int acehip_decomp(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, uint32_t digit, acehip_stream stream);
+int acehip_mod_up(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_digit, uint32_t level, uint32_t digit, acehip_stream stream);
+
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
 
