@@ -63,6 +63,9 @@ SYMBOLS = [
     ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_sample_uniform", C.c_int, [_vp, _vp, _u32, _u32, _u32, _u64, _vp]),
     ("acehip_mul_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_add_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_modup_digits", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    ("acehip_key_inner_product", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
 ]

@@ -50,7 +50,7 @@ if __name__ == "__main__":
 RT_DIR = os.path.join(CSRC, "rt")
 RT_LIB = os.path.join(LIBDIR, "libFHErt_ant.so")
 RT_COMMON_LIB = os.path.join(LIBDIR, "libFHErt_common.so")
-RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp"]
+RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp", "rt_bootstrap.cpp"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 
@@ -58,7 +58,7 @@ def build_rt(force=False, verbose=False):
     """libFHErt_ant.so: same link name as the reference provider library (scripts/perf.py:202-207)."""
     build(force=force, verbose=verbose)
     srcs = [os.path.join(RT_DIR, s) for s in RT_SOURCES]
-    deps = srcs + [os.path.join(RT_DIR, "rt_internal.hpp"), os.path.join(INCLUDE, "rt_ant", "ant_api.h"), LIB]
+    deps = srcs + [os.path.join(RT_DIR, "rt_internal.hpp"), os.path.join(RT_DIR, "rt_ev.hpp"), os.path.join(RT_DIR, "bts_coeffs.inc"), os.path.join(INCLUDE, "rt_ant", "ant_api.h"), LIB]
     if not force and os.path.exists(RT_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RT_LIB) for d in deps):
         return RT_LIB
     cxx = shutil.which("g++") or "g++"

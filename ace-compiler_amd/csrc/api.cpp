@@ -589,6 +589,44 @@ int acehip_mod_up(acehip_ctx* c, uint64_t* out, const uint64_t* digit_limbs, uin
   return (int)n2;
 }
 
+int acehip_add_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (n > 64) return fail(ACEHIP_EINVAL, "acehip_add_scalars: at most 64 limbs per call");
+  LimbConsts w{};
+  for (u32 i = 0; i < n; ++i) w.w[i] = h_scalars[i];
+  launch_add_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+// Switch_key_precompute (polynomial.c:1224-1239, 1337-1343): every digit of d_in raised to level+K limbs
+int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32_t level, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_modup_digits: bad level");
+  const HostParams& hp = c->hp;
+  hipStream_t s = (hipStream_t)s_;
+  const KsPlan* plan = get_ks_plan(c, level);
+  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
+  const size_t N = hp.N, E = (size_t)(level + hp.K) * N;
+  const u32 nd = plan->nd;
+  u64* coef = c->ws;
+  HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
+  launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E, hp.alpha);
+  for (u32 d = 0; d < nd; ++d) {  // digit limbs pass through (polynomial.c:1265-1273)
+    const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
+    HIP_TRY(hipMemcpyAsync(ext + d * E + (size_t)start * N, in + (size_t)start * N, (size_t)n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  }
+  return post_launch();
+}
+// Fast_switch_key_ext (ckks_evaluator.c:418-460): acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K limbs, no ModDown
+int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, const uint64_t* key, const uint64_t* ext, uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_inner_product: bad level");
+  const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
+  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s);
+  return post_launch();
+}
+
 uint64_t acehip_key_switch_bytes(const acehip_ctx* c, uint32_t level) {
   const HostParams& hp = c->hp;
   const u64 b = hp.num_decomp(level);

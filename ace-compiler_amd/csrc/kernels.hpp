@@ -93,6 +93,8 @@ struct LimbConsts {
 };
 // r[pos] = a[pos] * w[pos - pos0] mod prime(pos)   (Scalars_integer_multiply_poly polynomial.c:234-268)
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
+// r[pos] = a[pos] + w[pos - pos0] mod prime(pos)   (adding a constant plaintext, Add_const ckks_evaluator.c:116)
+void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // key inner product for one digit: acc{0,1}[pos] (+)= key{0,1}[gi(pos)] * ext[pos], pos < level+K
 void launch_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext, u32 level,
                     bool accumulate, hipStream_t s);

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __res
   const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
-  const u32 own = pos < level ? pos / alpha : 0xffffffffu;  // digit whose ModUp passes this limb through
+  // digit whose ModUp passes this limb through (read from `in` when given; otherwise ext holds it)
+  const u32 own = (in != nullptr && pos < level) ? pos / alpha : 0xffffffffu;
   ulong2 r0{0, 0}, r1{0, 0};
   for (u32 d = 0; d < nd; ++d) {
     const u64* e_src = (d == own) ? in + pb : ext + d * ext_stride + pb;

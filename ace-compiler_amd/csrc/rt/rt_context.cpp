@@ -249,6 +249,8 @@ void Finalize_context() {
          (long)c.weight_plain_bytes);
   for (auto& kv : c.auto_keys) free_switch_key(kv.second);
   c.auto_keys.clear();
+  bootstrap_release();
+  ev::clear_monomial_cache();
   pool_release_all();
   acehip_ctx_destroy(c.hip);
   delete g_ctx;

@@ -123,5 +123,7 @@ void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph);                        // ckks_d
 void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree);
 
 void bootstrap_setup_if_needed();
+void bootstrap_release();
+namespace ev { void clear_monomial_cache(); }
 
 }  // namespace rt

@@ -62,6 +62,27 @@ __global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* __restr
   *reinterpret_cast<ulong2*>(r + base + i) = v;
 }
 
+__global__ __launch_bounds__(256) void add_scalars_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
+                                                          LimbConsts w, u32 level, u32 pos0) {
+  const u32 pos = pos0 + blockIdx.y;
+  const u64 q = c.primes[limb_prime(pos, level, c.L)].q;
+  const u64 wl = w.w[blockIdx.y];
+  const size_t base = (size_t)pos * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  ulong2 v = *reinterpret_cast<const ulong2*>(a + base + i);
+  v.x = add_mod(v.x, wl, q);
+  v.y = add_mod(v.y, wl, q);
+  *reinterpret_cast<ulong2*>(r + base + i) = v;
+}
+
+void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs,
+                        hipStream_t s) {
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  hipLaunchKernelGGL(add_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);
+}
+
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs,
                         hipStream_t s) {
   if (n_limbs == 0) return;

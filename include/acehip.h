@@ -146,6 +146,17 @@ int acehip_mul_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, co
 int acehip_decomp(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, uint32_t digit, acehip_stream stream);
 int acehip_mod_up(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_digit, uint32_t level, uint32_t digit, acehip_stream stream);
 
+/* d_res[pos] = d_a[pos] + h_scalars[pos - pos0] mod prime(pos): adding a constant plaintext
+ * (Add_const ckks_evaluator.c:116-128 with Encode_val_at_level ckks_encoder.c:464-530) */
+int acehip_add_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* hoisting building blocks of Bootstrap (ckks_bootstrap_context.c:1237-1381):
+ * Switch_key_precompute (polynomial.c:1224-1239): every digit of d_in (level limbs) raised to level+K limbs,
+ *   d_ext laid out [num_decomp(level)][level+K][N];
+ * Fast_switch_key_ext (ckks_evaluator.c:418-460): d_acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K
+ *   limbs, no ModDown. */
+int acehip_modup_digits(acehip_ctx* ctx, uint64_t* d_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
+int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext, uint32_t level, acehip_stream stream);
+
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
 
