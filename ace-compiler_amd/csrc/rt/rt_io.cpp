@@ -181,7 +181,35 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
 }
 
 // ---- pt_mgr.c (message mode) ----
+// ACEHIP_RT_DATA_FILE overrides the path the compiler baked into Get_rt_data_info() (the checked-in ResNet
+// sources name /app/release/...); ACEHIP_RT_DATA_SYNTH=1 replaces the file by deterministic synthetic
+// weights N(0, 0.05) (there is no weight file in the reference tree: SURVEY 8d, C4).
+static bool g_pt_synth = false;
+static float* synth_entry(uint32_t index, size_t len) {
+  static thread_local std::vector<float> buf;
+  buf.resize(len);
+  uint64_t z = 0x9E3779B97F4A7C15ull * (index + 1) + 12345;
+  for (size_t i = 0; i < len; i += 2) {
+    z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+    const double u1 = ((z >> 11) + 1.0) / 9007199254740993.0;
+    z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+    const double u2 = (z >> 11) / 9007199254740992.0;
+    const double r = sqrt(-2.0 * log(u1)) * 0.05;
+    buf[i] = (float)(r * cos(2 * M_PI * u2));
+    if (i + 1 < len) buf[i + 1] = (float)(r * sin(2 * M_PI * u2));
+  }
+  return buf.data();
+}
+
 bool Pt_mgr_init(const char* fname) {
+  if (const char* e = getenv("ACEHIP_RT_DATA_SYNTH")) {
+    if (atoi(e) != 0) {
+      g_pt_synth = true;
+      g_pt.open = true;
+      return true;
+    }
+  }
+  if (const char* e = getenv("ACEHIP_RT_DATA_FILE")) fname = e;
   int fd = open(fname, O_RDONLY);
   if (fd < 0) return false;
   bool ok = pread(fd, &g_pt.hdr, sizeof(DataFileHdr), 0) == (ssize_t)sizeof(DataFileHdr) &&
@@ -219,6 +247,11 @@ void* Pt_get_validate(float*, uint32_t, size_t, uint32_t, uint32_t) {
 void Pt_free(uint32_t) {}
 static float* pt_entry(uint32_t index, size_t len) {
   RT_ASSERT(g_pt.open, "weight data file is not open");
+  if (g_pt_synth) {
+    static FILE* trace = getenv("ACEHIP_PT_TRACE") ? fopen(getenv("ACEHIP_PT_TRACE"), "w") : nullptr;
+    if (trace) fprintf(trace, "%u %zu\n", index, len);
+    return synth_entry(index, len);
+  }
   RT_ASSERT(index < g_pt.lut.size(), "index out of entry range");
   RT_ASSERT(g_pt.lut[index]._size >= len * sizeof(float), "entry size too small");
   const uint64_t ofst = g_pt.lut[index]._ent_ofst - 4096;

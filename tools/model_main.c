@@ -1,0 +1,65 @@
+/* model_main.c -- driver for an ACE-generated model source on a synthetic input.
+ *
+ * Our own main (the reference's dataset harness needs the CIFAR binaries, which are not in the tree:
+ * rtlib/ant/dataset/resnet_cifar.main.inc).  The generated source is included UNCHANGED from where it
+ * lies (-DMODEL_INC='"<path>.inc"'); see `make -C oracle models`.
+ *   usage: model <n_images> [c h w]      env: ACEHIP_RT_DATA_SYNTH=1 for synthetic weights
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include "common/rtlib.h"
+
+static double now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+int main(int argc, char* argv[]) {
+  int    n_images = argc > 1 ? atoi(argv[1]) : 1;
+  size_t c = argc > 4 ? atoi(argv[2]) : 3, h = argc > 4 ? atoi(argv[3]) : 32, w = argc > 4 ? atoi(argv[4]) : 32;
+  double t0 = now_s();
+  Prepare_context();
+  double t1 = now_s();
+  printf("[MODEL] Prepare_context: %.3f s\n", t1 - t0);
+  unsigned long long z = 1;
+  for (int img = 0; img < n_images; ++img) {
+    TENSOR* in = Alloc_tensor(1, c, h, w, NULL);
+    for (size_t i = 0; i < c * h * w; ++i) { /* U(-1,1), seed 1 */
+      z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+      in->_vals[i] = (double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+    }
+    double a = now_s();
+    Prepare_input(in, "input");
+    Free_tensor(in);
+    double b = now_s();
+    Run_main_graph();
+    double* out = Handle_output("output");
+    double  e   = now_s();
+    printf("[MODEL] image %d: encrypt %.3f s, Main_graph+decrypt %.3f s, logits:", img, b - a, e - b);
+    for (int i = 0; i < 10; ++i) printf(" %.4f", out[i]);
+    printf("\n");
+    free(out);
+  }
+  Finalize_context();
+  printf("[MODEL] total %.3f s\n", now_s() - t0);
+  return 0;
+}
+
+/* The generated source hard-codes the weight file path of the machine it was compiled on
+ * (/app/release/....msg); rename its Get_rt_data_info and supply one that reads MODEL_DATA_FILE. */
+#define Get_rt_data_info Generated_get_rt_data_info
+#include MODEL_INC
+#undef Get_rt_data_info
+RT_DATA_INFO* Get_rt_data_info() {
+  static RT_DATA_INFO info;
+  RT_DATA_INFO*       gen = Generated_get_rt_data_info();
+  if (gen == NULL) return NULL;
+  info               = *gen;
+  const char* f      = getenv("MODEL_DATA_FILE");
+  if (f != NULL) info._file_name = f;
+  return &info;
+}
