@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X-native CKKS polynomial layer.
+"""bench.py -- headline benchmark of the MI355X-native CKKS runtime.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], "C2" of SURVEY 8d): forward + inverse negacyclic NTT at
-N = 2^16 over a resident batch of 1024 limbs (16 PQ-extended ciphertext pairs of the C3 parameter
-set L=25, K=7: 16 x 2 polys x 32 limbs = 512 MiB, larger than the 256 MiB Infinity Cache so the
-numbers are HBM numbers).  A step = one forward NTT and one inverse NTT of every limb of the batch.
-metric = algorithmic NTT bandwidth: 16*N bytes per limb-transform * transforms / time.
-Each rank (one per GPU) owns an independent batch: weak scaling, no data-path collective
-(ciphertexts are independent; RCCL is only used for the barrier / max-reduce of the timing).
+Headline workload (BASELINE.json metric, configs[3] = SURVEY 8d "C4"): encrypted inference of the
+ACE-compiled ResNet-20/CIFAR-10 program (the reference's checked-in generated source, N=2^16, L=34,
+dnum=3, 19 bootstraps) on a synthetic 3x32x32 image with synthetic weights.  A step = one image:
+encode+encrypt, Main_graph, decrypt+decode, through the rt_ant drop-in API (libFHErt_ant.so over the
+acehip C ABI).  The generated program is build/models/libmodel_resnet20.so (compiled unchanged from
+/root/reference by tools/build_models.py in the dev container; it travels with the snapshot).  If that
+library is absent the bench falls back to the largest configuration that needs no generated source:
+C3, the full key-switch at N=2^16, L=25, dnum=4 (and says so in config.workload).
+Each rank (one per GPU) runs independent images: replicas, weak scaling, no data-path collective
+(the reference's own parallel axis is images: resnet_cifar.main.inc:77-116); RCCL only carries the
+barrier and the max-reduce of the timing.
 
-Extra, same JSON line:
-  roofline      dominant kernel family (forward NTT = its two pass kernels) timed with HIP events on
-                the launch stream inside the timed region
-  key_switch    BASELINE.json configs[2] (C3): full key-switch at N=2^16, L=25, dnum=4, events-timed
-  cpu_baseline  the reference rtlib (oracle/_ref/ref_dump bench, kind "reference") or the oracle
-                port, one host thread, bounded sample; rank 0 at N=1 only
+Same JSON line:
+  roofline      the dominant kernel family (forward NTT, its two 8-stage pass kernels), HIP events on the
+                launch stream over a 1024-limb batch (512 MiB > Infinity Cache): algorithmic 16*N B/limb
+  key_switch    C3 key-switch, HIP-event timed
+  cpu_baseline  reference rtlib (oracle/_ref/ref_dump, kind "reference") or the oracle port on this
+                host, 1 thread, bounded sample (NTT + key-switch micro-ops), scaled to images/s with the
+                measured op mix of the full CPU run recorded in profiles/cpu_resnet20_devbox.json
 """
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -30,61 +36,82 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-N, L, Q0, SF, DNUM = 65536, 25, 60, 56, 4
-N_CT = 16  # ciphertext pairs in the resident batch
+N, L, Q0, SF, DNUM = 65536, 25, 60, 56, 4   # C2/C3 parameter set
+N_CT = 16                                    # ciphertext pairs in the resident NTT batch
+MODEL_LIB = os.path.join(ROOT, "build", "models", "libmodel_resnet20.so")
 
 
-def cpu_baseline():
-    """Reference rtlib timed on this host (1 thread): ~10-20 s of CPU work."""
+def cpu_baseline(have_model):
+    """Reference rtlib micro-ops timed on this host (1 thread, ~15 s)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    res = None
     if os.path.exists(ref):
         try:
             out = subprocess.run([ref, "bench", str(N), str(L), str(Q0), str(SF), str(DNUM), str(L), "8", "3000"],
                                  capture_output=True, text=True, timeout=300, check=True).stdout
             r = json.loads(out.strip().splitlines()[-1])
-            per = r["ntt_fwd_s"] + r["ntt_inv_s"]
-            return {"value": round(2 * 16 * N / per / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
-                    "sample": "3000 Ftt_fwd + 3000 Ftt_inv of one limb (N=2^16) and 8 full key-switches "
-                              "(L=25,dnum=4) by the reference rtlib (gcc -O3), 1 thread",
-                    "ntt_fwd_ms": round(r["ntt_fwd_s"] * 1e3, 4), "ntt_inv_ms": round(r["ntt_inv_s"] * 1e3, 4),
-                    "key_switch_s": round(r["key_switch_s"], 4),
-                    "key_switch_per_s": round(1.0 / r["key_switch_s"], 4)}
-        except Exception as e:  # fall through to the port
+            res = {"cores": 1, "kind": "reference", "ntt_fwd_ms": round(r["ntt_fwd_s"] * 1e3, 4),
+                   "ntt_inv_ms": round(r["ntt_inv_s"] * 1e3, 4), "key_switch_s": round(r["key_switch_s"], 4),
+                   "sample": "3000 Ftt_fwd + 3000 Ftt_inv of one limb (N=2^16) and 8 full key-switches (L=25, dnum=4) "
+                             "by the reference rtlib (gcc -O3), 1 thread"}
+        except Exception as e:
             sys.stderr.write("reference baseline failed (%s); timing the oracle port instead\n" % e)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
+    if res is None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
 
-    import _oracle as O
-
-    o = O.Oracle(N, L, Q0, SF, DNUM)
-    x = o.uniform(1, 1, 1)
-    reps = 3000
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        o.lib.orc_ntt_fwd(O.ptr(x[0]), o.prime_ptr(0), N)
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        o.lib.orc_ntt_inv(O.ptr(x[0]), o.prime_ptr(0), N)
-    t2 = time.perf_counter()
-    a, key = o.uniform(L, L, 1), o.make_key(101)
-    t3 = time.perf_counter()
-    for _ in range(4):
-        o.key_switch(a, key, L)
-    t4 = time.perf_counter()
-    per = (t2 - t0) / reps
-    return {"value": round(2 * 16 * N / per / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "3000 fwd + 3000 inv NTTs of one limb (N=2^16) and 4 key-switches by oracle/ckks_oracle.c, 1 thread",
-            "ntt_fwd_ms": round((t1 - t0) / reps * 1e3, 4), "ntt_inv_ms": round((t2 - t1) / reps * 1e3, 4),
-            "key_switch_s": round((t4 - t3) / 4, 4), "key_switch_per_s": round(4 / (t4 - t3), 4)}
+        o = O.Oracle(N, L, Q0, SF, DNUM)
+        x = o.uniform(1, 1, 1)
+        reps = 3000
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o.lib.orc_ntt_fwd(O.ptr(x[0]), o.prime_ptr(0), N)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            o.lib.orc_ntt_inv(O.ptr(x[0]), o.prime_ptr(0), N)
+        t2 = time.perf_counter()
+        a, key = o.uniform(L, L, 1), o.make_key(101)
+        t3 = time.perf_counter()
+        for _ in range(4):
+            o.key_switch(a, key, L)
+        t4 = time.perf_counter()
+        res = {"cores": 1, "kind": "port", "ntt_fwd_ms": round((t1 - t0) / reps * 1e3, 4),
+               "ntt_inv_ms": round((t2 - t1) / reps * 1e3, 4), "key_switch_s": round((t4 - t3) / 4, 4),
+               "sample": "3000 fwd + 3000 inv NTTs of one limb (N=2^16) and 4 key-switches by oracle/ckks_oracle.c, 1 thread"}
+    ntt_gbs = 2 * 16 * N / ((res["ntt_fwd_ms"] + res["ntt_inv_ms"]) * 1e-3) / 1e9
+    res["ntt_GBs"] = round(ntt_gbs, 4)
+    res["key_switch_per_s"] = round(1.0 / res["key_switch_s"], 4)
+    if have_model:
+        # scale to images/s: (full CPU ResNet-20 seconds / key-switch seconds) measured once on the dev box
+        dev = os.path.join(ROOT, "profiles", "cpu_resnet20_devbox.json")
+        ratio, src = None, None
+        if os.path.exists(dev):
+            d = json.load(open(dev))
+            if d.get("image_s") and d.get("key_switch_s"):
+                ratio, src = d["image_s"] / d["key_switch_s"], "profiles/cpu_resnet20_devbox.json"
+        if ratio is None:  # published: 1453.96 s/image (ace_pre.log:28); key-switch 0.58 s on the survey box (BASELINE.md 2)
+            ratio, src = 1453.96 / 0.58, "BASELINE.md (published 1453.96 s/image; 0.58 s key-switch)"
+        res["value"] = round(1.0 / (ratio * res["key_switch_s"]), 8)
+        res["unit"] = "images/s"
+        res["sample"] += "; scaled to images/s by (CPU ResNet-20 s/image) / (CPU key-switch s) = %.1f from %s" % (ratio, src)
+    else:
+        res["value"], res["unit"] = res["key_switch_per_s"], "key-switches/s"
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["auto", "resnet20", "keyswitch"], default="auto")
     args = ap.parse_args()
+
+    # the runtime library prints the reference's stdout contract ([RT_STAT] ..., ckks_param: ...) from C;
+    # keep fd 1 clean for the ONE JSON line: route everything else to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,76 +128,26 @@ def main():
 
     import ace_compiler_amd as A
 
+    bmod = sys.modules["ace_compiler_amd.build"]
+    use_model = args.workload != "keyswitch" and os.path.exists(MODEL_LIB) and os.path.exists(bmod.RT_LIB)
+    if args.workload == "resnet20" and not use_model:
+        raise SystemExit("bench: %s or libFHErt_ant.so missing (build with tools/build_models.py / __graft_entry__.build())" % MODEL_LIB)
+
     rt = A.AceHip(N, L, Q0, SF, DNUM, device=local_rank)  # raises without GPU / library: no fallback
     lib, h = rt.lib, rt.h
-    T = L + rt.K  # 32 limbs per PQ-extended polynomial
-    n_polys = 2 * N_CT
-    poly_words = T * N
-    batch = rt.buf(n_polys * poly_words)
-    # synthetic data: one random extended polynomial (canonical residues per limb), replicated
-    rng = np.random.default_rng(1234 + rank)
-    host = np.empty((T, N), dtype=np.uint64)
-    for l in range(T):
-        host[l] = rng.integers(0, rt.primes[l], size=N, dtype=np.uint64)
-    for p in range(n_polys):
-        rt.check(lib.acehip_memcpy_h2d(batch.at(p * poly_words), host.ctypes.data, poly_words * 8, None))
-
-    def fwd():
-        rt.check(lib.acehip_ntt_batch(h, batch.ptr, poly_words, n_polys, L, 0, T, 0, None))
-
-    def inv():
-        rt.check(lib.acehip_ntt_batch(h, batch.ptr, poly_words, n_polys, L, 0, T, 1, None))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         rt.sync()
 
-    for _ in range(args.warmup):
-        fwd()
-        inv()
-    barrier()
-    ev = [[lib.acehip_event_create() for _ in range(3)] for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        lib.acehip_event_record(ev[k][0], None)
-        fwd()
-        lib.acehip_event_record(ev[k][1], None)
-        inv()
-        lib.acehip_event_record(ev[k][2], None)
-    rt.sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    import ctypes as C
-
-    ms = C.c_float()
-    fwd_ms = inv_ms = 0.0
-    for k in range(args.steps):
-        lib.acehip_event_elapsed_ms(ev[k][0], ev[k][1], C.byref(ms))
-        fwd_ms += ms.value
-        lib.acehip_event_elapsed_ms(ev[k][1], ev[k][2], C.byref(ms))
-        inv_ms += ms.value
-    fwd_ms /= args.steps
-    inv_ms /= args.steps
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # parity spot-check of the timed buffers: fwd then inv returned the input exactly
-    back = np.empty((T, N), dtype=np.uint64)
-    rt.check(lib.acehip_memcpy_d2h(back.ctypes.data, batch.at((n_polys - 1) * poly_words), poly_words * 8, None))
-    assert np.array_equal(back, host), "NTT round trip over the timed batch is not the identity"
-
-    limbs = n_polys * T
-    bytes_per_dir = 16 * N * limbs           # algorithmic: read + write every limb once
-    step_bytes = 2 * bytes_per_dir
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * step_bytes / (elapsed / args.steps) / 1e9
-
-    # C3 key-switch, events-timed (not part of the timed NTT region)
+    # ---------------- headline: ResNet-20 images/s (or the C3 key-switch fallback) ----------------
+    T = L + rt.K
+    poly_words = T * N
+    rng = np.random.default_rng(1234 + rank)
+    host = np.empty((T, N), dtype=np.uint64)
+    for l in range(T):
+        host[l] = rng.integers(0, rt.primes[l], size=N, dtype=np.uint64)
     a = rt.buf(L * N)
     rt.check(lib.acehip_memcpy_h2d(a.ptr, host.ctypes.data, L * N * 8, None))
     key = rt.buf(DNUM * 2 * poly_words)
@@ -180,6 +157,96 @@ def main():
 
     def ks():
         rt.check(lib.acehip_key_switch(h, o0.ptr, o1.ptr, a.ptr, key.ptr, L, None))
+
+    logits = None
+    if use_model:
+        os.environ["ACEHIP_DEVICE"] = str(local_rank)
+        os.environ.setdefault("ACEHIP_RT_DATA_SYNTH", "1")
+        # libmodel defines Main_graph + the Get_* callbacks and is linked against libFHErt_ant.so, so one
+        # dlopen resolves both directions of the generated-code <-> runtime boundary
+        fhe = C.CDLL(MODEL_LIB, mode=C.RTLD_GLOBAL)
+        fhe.Alloc_tensor.restype = C.c_void_p
+        fhe.Alloc_tensor.argtypes = [C.c_size_t] * 4 + [C.c_void_p]
+        fhe.Prepare_input.argtypes = [C.c_void_p, C.c_char_p]
+        fhe.Free_tensor.argtypes = [C.c_void_p]
+        fhe.Handle_output.restype = C.POINTER(C.c_double)
+        fhe.Handle_output.argtypes = [C.c_char_p]
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        fhe.Prepare_context()
+        img_rng = np.random.default_rng(1)
+
+        def step():
+            img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
+            t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
+            fhe.Prepare_input(t, b"input")
+            fhe.Free_tensor(t)
+            fhe.Run_main_graph()
+            out = fhe.Handle_output(b"output")
+            vals = [out[i] for i in range(10)]
+            libc.free(out)
+            return vals
+
+        unit, metric = "images/s", "encrypted images/sec (ResNet-20 CIFAR-10, N=2^16)"
+        workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
+                    "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
+                    "N(0,0.05); one image per step per GPU")
+    else:
+        def step():
+            ks()
+            return None
+
+        unit, metric = "key-switches/s", "full key-switch throughput (N=2^16, L=25, dnum=4)"
+        workload = ("C3 (BASELINE configs[2]) FALLBACK: build/models/libmodel_resnet20.so not present, so the headline ResNet-20 "
+                    "workload cannot run; full key-switch N=2^16 L=25 dnum=4 K=7 on resident inputs")
+
+    for _ in range(args.warmup):
+        logits = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    rt.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    if use_model:
+        fhe.Finalize_context()
+
+    # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
+    n_polys = 2 * N_CT
+    batch = rt.buf(n_polys * poly_words)
+    for p in range(n_polys):
+        rt.check(lib.acehip_memcpy_h2d(batch.at(p * poly_words), host.ctypes.data, poly_words * 8, None))
+
+    def fwd():
+        rt.check(lib.acehip_ntt_batch(h, batch.ptr, poly_words, n_polys, L, 0, T, 0, None))
+
+    def inv():
+        rt.check(lib.acehip_ntt_batch(h, batch.ptr, poly_words, n_polys, L, 0, T, 1, None))
+
+    for _ in range(2):
+        fwd()
+        inv()
+    reps = 10
+    fwd_ms = inv_ms = 0.0
+    for _ in range(reps):
+        fwd_ms += rt.time_ms(fwd, 1)
+        inv_ms += rt.time_ms(inv, 1)
+    fwd_ms /= reps
+    inv_ms /= reps
+    back = np.empty((T, N), dtype=np.uint64)
+    rt.check(lib.acehip_memcpy_d2h(back.ctypes.data, batch.at((n_polys - 1) * poly_words), poly_words * 8, None))
+    assert np.array_equal(back, host), "NTT round trip over the timed batch is not the identity"
+    limbs = n_polys * T
+    bytes_per_dir = 16 * N * limbs  # algorithmic: read + write every limb once
 
     for _ in range(3):
         ks()
@@ -193,28 +260,29 @@ def main():
         if os.path.exists(tr_path):
             traffic = json.load(open(tr_path)).get("ntt_forward_bytes_per_launch")
         out = {
-            "metric": "negacyclic NTT algorithmic bandwidth (fwd+inv, N=2^16, 64-bit primes)",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2 (BASELINE configs[1]): forward+inverse negacyclic NTT, N=2^16, batch of %d limbs "
-                                   "per GPU (%d PQ-extended ciphertext pairs, L=25 K=7), bit-exact vs CPU rtlib" % (limbs, N_CT),
-                       "N": N, "limbs_per_gpu": limbs, "bytes_per_step_per_gpu": step_bytes, "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
+            "metric": metric, "value": round(value, 6), "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": workload, "N": 65536, "parallelism": "replicas x%d (one image stream per GPU)" % world},
+            "roofline": {"bound": "hbm",
+                         "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(fwd_ms, 4), "inverse_launch_ms": round(inv_ms, 4),
-                         "algorithmic_bytes_per_launch": bytes_per_dir},
+                         "algorithmic_bytes_per_launch": bytes_per_dir,
+                         "ntt_fwd_inv_GBs": round(2 * bytes_per_dir / ((fwd_ms + inv_ms) * 1e-3) / 1e9, 2),
+                         "batch": "%d limbs (%d PQ-extended ciphertext pairs, L=25 K=7), 512 MiB" % (limbs, N_CT)},
             "key_switch": {"workload": "C3 (BASELINE configs[2]): full key-switch N=2^16 L=25 dnum=4 K=7",
-                           "ms": round(ks_ms, 4), "per_s": round(1e3 / ks_ms, 2),
-                           "algorithmic_bytes": int(ks_bytes),
+                           "ms": round(ks_ms, 4), "per_s": round(1e3 / ks_ms, 2), "algorithmic_bytes": int(ks_bytes),
                            "achieved_GBs": round(ks_bytes / (ks_ms * 1e-3) / 1e9, 2),
                            "frac_of_hbm_peak": round(ks_bytes / (ks_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if logits is not None:
+            out["config"]["last_logits"] = [round(v, 5) for v in logits]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(use_model)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     rt.close()

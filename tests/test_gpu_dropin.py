@@ -26,5 +26,23 @@ def test_reference_generated_example(name):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SUCESS!" in r.stdout
     # stdout contract parsed by the reference's scripts/perf.py:233-276
-    assert r.stdout.lstrip().startswith("ckks_param: _provider = 0")
+    assert "ckks_param: _provider = 0, _poly_degree = " in r.stdout
     assert "Total memory size for keys: rot_key_cnt =" in r.stdout
+
+
+def test_own_program_config_c1(tmp_path):
+    """BASELINE configs[0] through the drop-in API with a program of our own (tests/c/dropin_c1.c): HAdd spelled
+    per limb, HMul + relinearise, Rescale, Rotate, plaintext multiply at N=2^14, 4 limbs; compiled here with gcc
+    against include/ and libFHErt_ant.so exactly like a generated program would be."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "dropin_c1")
+    inc = os.path.join(ROOT, "include")
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c", "dropin_c1.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe]
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
