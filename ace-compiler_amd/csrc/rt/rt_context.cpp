@@ -247,6 +247,8 @@ void Finalize_context() {
          (long)rot_cnt, (long)rot_bytes, (long)total);
   printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)c.weight_plain_cnt,
          (long)c.weight_plain_bytes);
+  if (getenv("ACEHIP_PROFILE"))
+    printf("[ACEHIP] host seconds: FP64 embedding %.3f, encode total (host side) %.3f, Main_graph %.3f\n", c.t_embed, c.t_encode, c.t_main);
   for (auto& kv : c.auto_keys) free_switch_key(kv.second);
   c.auto_keys.clear();
   bootstrap_release();
@@ -278,7 +280,10 @@ POLY Pk1_at(SW_KEY swk, uint32_t idx) {
 }
 
 void Run_main_graph() {  // common/src/rt_lib.c:16-21
+  const double t0 = wall_s();
   bool ok = Main_graph();
+  sync();
+  ctx().t_main += wall_s() - t0;
   RT_ASSERT(ok, "Main_graph() failed");
 }
 

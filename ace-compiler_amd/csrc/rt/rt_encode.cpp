@@ -105,7 +105,9 @@ void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u3
   RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
   std::vector<cplx> v(slots, cplx(0, 0));
   for (size_t i = 0; i < len; ++i) v[i] = values[i];
+  const double te0 = wall_s();
   embedding_inv(v);
+  c.t_embed += wall_s() - te0;
   init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree);
   std::vector<int64_t> msg(N, 0);
   const u32 gap = N / (slots * 2);
@@ -137,6 +139,7 @@ void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u3
   }
   poly->_is_ntt = false;
   poly_ntt(poly, false);
+  c.t_encode += wall_s() - te0;
 }
 
 // Encode_val_at_level ckks_encoder.c:464-530 (+ Scale_back_up_by_approxfactor :406-460)

@@ -75,6 +75,7 @@ struct Context {
   std::vector<u32> rot_group;     // 5^i mod 2N
   // statistics
   size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
+  double t_embed = 0, t_encode = 0, t_main = 0;  // host seconds (ACEHIP_PROFILE=1 prints them)
 };
 
 extern Context* g_ctx;
@@ -100,6 +101,7 @@ void poly_ntt(POLYNOMIAL* p, bool inverse);                            // Conv_p
 void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx);        // Rotate_poly (NTT domain)
 void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transform_values_at_level(without_mod)
 void sync();
+double wall_s();
 
 // ---- sampling (random_sample.c) ----
 void sample_triangle(std::vector<int64_t>& v);                         // :78-97

@@ -2,6 +2,7 @@
 // rt_ant API (reference: include/poly/poly_eval.h, src/poly/{poly_eval,poly_arith}.c,
 // src/ckks/cipher_eval.c:18-123, include/util/{polynomial,ciphertext}.h).
 #include <cstring>
+#include <ctime>
 
 #include "rt_internal.hpp"
 
@@ -67,6 +68,11 @@ void pool_release_all() {
 size_t pool_bytes_in_use() { return pool_live_bytes; }
 
 void sync() { HIPCHK(acehip_stream_sync(nullptr)); }
+double wall_s() {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
 
 // ---- POLYNOMIAL helpers ----
 void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np) {

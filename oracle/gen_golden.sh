@@ -42,4 +42,16 @@ for s in "${OPS[@]}"; do
   set -- $s
   $D ops $2 $3 $4 $5 $6 $7 $8 > $G/ref_ops_$1.json
 done
+# encode: name N L q0 sf dnum level seed
+ENC=(
+ "n16_l3_lv3        16    3  60 50 2 3  1"
+ "n64_l7_lv4        64    7  60 51 3 4  2"
+ "n1024_l7_lv6      1024  7  60 51 3 6  3"
+ "bl_n65536_l25_lv20 65536 25 60 56 4 20 4"
+ "rn_n65536_l34_lv12 65536 34 51 50 3 12 5"
+)
+for s in "${ENC[@]}"; do
+  set -- $s
+  $D encode $2 $3 $4 $5 $6 $7 $8 > $G/ref_encode_$1.json
+done
 ls -la $G

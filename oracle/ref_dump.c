@@ -23,6 +23,8 @@
 #include "util/ntt.h"
 #include "util/number_theory.h"
 #include "util/polynomial.h"
+#include "util/ckks_encoder.h"
+#include "util/plaintext.h"
 
 /* generated-code callbacks the rtlib expects from the program it is linked into */
 CKKS_PARAMS*  Get_context_params() { return NULL; }
@@ -345,6 +347,49 @@ static int do_ops(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_
   return 0;
 }
 
+
+/* Encode_at_level_with_sf / Encode_val_at_level (what Pt_from_msg / Encode_plain_from_float do,
+ * src/ckks/plain_eval.c:17-42): message m[i] = (float)(((i*7 + seed) mod 17) - 8) / 16 for i < len */
+static int do_encode(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, u64 seed) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CKKS_ENCODER*   enc = Alloc_ckks_encoder(p);
+  Full = N <= 64;
+  printf("{\n  \"N\": %u, \"L\": %zu, \"q0_bits\": %zu, \"sf_bits\": %zu, \"dnum_req\": %zu, \"level\": %zu, \"seed\": %llu,\n  \"cases\": [\n",
+         N, L, q0, sf, dnum, level, seed);
+  size_t lens[3] = {N / 2, N / 4, N / 8 > 1 ? N / 8 : 2};
+  int first = 1;
+  for (int li = 0; li < 3; li++) {
+    for (uint32_t sfd = 1; sfd <= 2; sfd++) {
+      size_t len = lens[li];
+      if (sfd == 2 && level < 2) continue;
+      VALUE_LIST* vals = Alloc_value_list(DCMPLX_TYPE, len);
+      for (size_t i = 0; i < len; i++) DCMPLX_VALUE_AT(vals, i) = (double)((float)((int)((i * 7 + seed) % 17) - 8) / 16.0f);
+      PLAINTEXT* pt = Alloc_plaintext();
+      Encode_at_level_with_sf(pt, enc, vals, level, 0, sfd);
+      printf("%s   {\"len\": %zu, \"sf_degree\": %u, \"slots\": %u, \"scale\": %.17g,\n", first ? "" : ",\n", len, sfd, pt->_slots, pt->_scaling_factor);
+      first = 0;
+      emit_vec("poly", Get_poly_coeffs(Get_plain_poly(pt)), level * N, 1);
+      printf("   }");
+      Free_plaintext(pt);
+      Free_value_list(vals);
+    }
+  }
+  printf("\n  ],\n  \"consts\": [\n");
+  double cvals[4] = {0.5685231134608953462717, -1.0, 3.25e-7, 12345.678};
+  for (int ci = 0; ci < 4; ci++) {
+    for (uint32_t sfd = 1; sfd <= 2; sfd++) {
+      PLAINTEXT* pt = Alloc_plaintext();
+      Encode_val_at_level(pt, enc, cvals[ci], level, sfd);
+      printf("   {\"value\": %.17g, \"sf_degree\": %u, \"limb0\": [", cvals[ci], sfd);
+      for (size_t l = 0; l < level; l++) printf("%s%llu", l ? "," : "", (u64)Get_poly_coeffs(Get_plain_poly(pt))[l * N]);
+      printf("]}%s\n", (ci == 3 && sfd == 2) ? "" : ",");
+      Free_plaintext(pt);
+    }
+  }
+  printf("  ]\n}\n");
+  return 0;
+}
+
 static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 /* CPU baseline: the reference rtlib timed on this host (single thread, as published: README.md:94) */
@@ -392,6 +437,7 @@ int main(int argc, char** argv) {
   size_t   L = atoi(argv[3]), q0 = atoi(argv[4]), sf = atoi(argv[5]), dnum = atoi(argv[6]);
   if (!strcmp(argv[1], "params")) return do_params(N, L, q0, sf, dnum);
   if (!strcmp(argv[1], "ops")) return do_ops(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
+  if (!strcmp(argv[1], "encode")) return do_encode(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
   if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1, argc > 9 ? atoi(argv[9]) : 20);
   return 2;
 }
