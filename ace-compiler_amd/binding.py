@@ -39,10 +39,14 @@ SYMBOLS = [
     ("acehip_memcpy_d2h", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_memcpy_d2d", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_memset", C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
+    ("acehip_malloc_host", _vp, [C.c_size_t]),
+    ("acehip_free_host", C.c_int, [_vp]),
+    ("acehip_memcpy_h2d_async", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_stream_sync", C.c_int, [_vp]),
     ("acehip_event_create", _vp, []),
     ("acehip_event_record", C.c_int, [_vp, _vp]),
     ("acehip_event_elapsed_ms", C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    ("acehip_event_sync", C.c_int, [_vp]),
     ("acehip_event_destroy", C.c_int, [_vp]),
     ("acehip_ntt_forward", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_ntt_inverse", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
@@ -61,6 +65,8 @@ SYMBOLS = [
     ("acehip_key_switch", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_switch_bytes", _u64, [_vp, _u32]),
     ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_encode", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _u32, _vp]),
+    ("acehip_encode_status", C.c_int, [_vp]),
     ("acehip_sample_uniform", C.c_int, [_vp, _vp, _u32, _u32, _u32, _u64, _vp]),
     ("acehip_mul_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_add_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
@@ -134,6 +140,7 @@ class AceHip:
         if not self.h:
             raise AceHipError(self.err())
         self.N, self.L, self.K = N, self.lib.acehip_num_q(self.h), self.lib.acehip_num_p(self.h)
+        self.sf_bits = sf_bits
         self.dnum, self.alpha = self.lib.acehip_num_q_parts(self.h), self.lib.acehip_part_size(self.h)
         self.primes = [self.lib.acehip_prime(self.h, i) for i in range(self.L + self.K)]
 
@@ -261,6 +268,23 @@ class AceHip:
         da.free()
         dr.free()
         return out
+
+    def encode(self, values, level, slots=0, sf_degree=1, n_p=0, sf_bits=None):
+        """acehip_encode: message (float32 / float64 / complex128 array) -> (q limbs [level,N], p limbs [n_p,N])"""
+        v = np.ascontiguousarray(values)
+        kind = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex128): 2}[v.dtype]
+        dv = DeviceBuffer(self, max(v.size, 1), v.dtype)
+        if v.size:
+            dv.upload(v)
+        dq, dp = self.buf(level * self.N), self.buf(max(n_p, 1) * self.N)
+        sf = float(2 ** (self.sf_bits if sf_bits is None else sf_bits))
+        self.check(self.lib.acehip_encode(self.h, dq.ptr, dp.ptr if n_p else None, dv.ptr, kind, v.size, slots, sf, sf_degree,
+                                          level, n_p, None))
+        self.check(self.lib.acehip_encode_status(self.h))
+        q, p_ = dq.download((level, self.N)), dp.download((max(n_p, 1), self.N))[:n_p]
+        for d in (dv, dq, dp):
+            d.free()
+        return q, p_
 
     def key_switch(self, a, key, level):
         da, dk = self.to_device(a), self.to_device(key)

@@ -2,6 +2,7 @@
 // host-side sequencing of Decomp_modup / Mod_down / Rescale / key-switch.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
@@ -72,6 +73,12 @@ struct acehip_ctx {
   // workspace (one per context; launches of one context are expected on one stream at a time)
   u64* ws = nullptr;
   size_t ws_words = 0;
+  // encode (embed.hip): twiddles cos/sin(2 pi j / 2N) from the host libm, 5^i mod 2N, scratch, sticky overflow flag
+  cd* emb_rou = nullptr;
+  u32* emb_rot = nullptr;
+  cd* emb_work = nullptr;
+  int64_t* emb_msg = nullptr;
+  int* emb_err = nullptr;
 
   template <typename T>
   T* up(const std::vector<T>& v) {
@@ -266,6 +273,26 @@ int acehip_free(void* p) {
 int acehip_memcpy_h2d(void* d, const void* h, size_t n, acehip_stream s) {
   HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
   HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+void* acehip_malloc_host(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    g_err = "hipHostMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+int acehip_free_host(void* p) {
+  HIP_TRY(hipHostFree(p));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_h2d_async(void* d, const void* h, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_event_sync(void* e) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)e));
   return ACEHIP_OK;
 }
 int acehip_memcpy_d2h(void* h, const void* d, size_t n, acehip_stream s) {
@@ -573,6 +600,83 @@ int acehip_mul_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint
   launch_mul_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
+// Encode_at_level_with_sf ckks_encoder.c:395 -> Encode_impl :199-297 (64-bit path)
+static int ensure_embed_tables(acehip_ctx* c) {
+  std::lock_guard<std::mutex> g(c->mu);
+  if (c->emb_rou) return 0;
+  const size_t N = c->hp.N, m = 2 * N;
+  std::vector<double> rou(2 * m);
+  for (size_t i = 0; i < m; ++i) {  // Precompute_fft ntt.c:587-610
+    // glibc's sincos(), which is what gcc makes of the reference's cos(angle) + sin(angle) pair: it differs from
+    // separate cos()/sin() calls in the last bit for ~0.1% of the entries, and clang would emit the latter
+    const double angle = 2 * M_PI * i / m;
+    sincos(angle, &rou[2 * i + 1], &rou[2 * i]);
+  }
+  std::vector<u32> rot(N / 2 ? N / 2 : 1, 1);
+  for (size_t i = 1; i < N / 2; ++i) rot[i] = (u32)((5ull * rot[i - 1]) % m);
+  u32* d_rot = c->up(rot);
+  double* d_rou = c->up(rou);
+  void *work = nullptr, *msg = nullptr, *err = nullptr;
+  if (!d_rot || !d_rou || hipMalloc(&work, N / 2 * 16 + 16) != hipSuccess || hipMalloc(&msg, N * 8) != hipSuccess ||
+      hipMalloc(&err, 64) != hipSuccess)
+    return fail(ACEHIP_EHIP, "acehip_encode: table allocation failed");
+  c->owned.push_back(work);
+  c->owned.push_back(msg);
+  c->owned.push_back(err);
+  if (hipMemset(err, 0, 64) != hipSuccess) return fail(ACEHIP_EHIP, "acehip_encode: memset failed");
+  c->emb_rot = d_rot;
+  c->emb_work = (cd*)work;
+  c->emb_msg = (int64_t*)msg;
+  c->emb_err = (int*)err;
+  c->emb_rou = (cd*)d_rou;
+  return 0;
+}
+
+int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                  double sf, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  const u32 N = c->hp.N;
+  if (slots == 0) slots = N / 2;
+  if (kind < 0 || kind > 2 || slots > N / 2 || (slots & (slots - 1)) || len > slots || sf_degree < 1 || level == 0 ||
+      level > c->hp.L || n_p > c->hp.K || (n_p && !d_p) || !d_q || (!d_vals && len))
+    return fail(ACEHIP_EINVAL, "acehip_encode: bad arguments");
+  if (int e = ensure_embed_tables(c)) return e;
+  hipStream_t st = (hipStream_t)s;
+  launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
+  launch_values_to_rns(c->dc, d_q, c->emb_msg, level, 0, level, st);
+  if (n_p) launch_values_to_rns(c->dc, d_p, c->emb_msg, 0, 0, n_p, st);
+  if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
+    const u64 sfi = (u64)sf;
+    for (u32 l0 = 0; l0 < level; l0 += 64) {
+      LimbConsts w{};
+      const u32 n = std::min(64u, level - l0);
+      for (u32 i = 0; i < n; ++i) {
+        const u64 q = c->hp.primes[l0 + i].q;
+        u64 pw = sfi % q;
+        for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+        w.w[i] = pw;
+      }
+      launch_mul_scalars(c->dc, d_q, d_q, w, level, l0, n, st);
+    }
+  }
+  launch_ntt(c->dc, d_q, level, 0, level, false, st);
+  if (n_p) launch_ntt(c->dc, d_p, 0, 0, n_p, false, st);
+  return post_launch();
+}
+
+int acehip_encode_status(acehip_ctx* c) {
+  if (int e = check_dev(c)) return e;
+  if (!c->emb_err) return 0;
+  int flag = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&flag, c->emb_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIP_TRY(hipMemset(c->emb_err, 0, sizeof(int)));
+    return fail(ACEHIP_EINVAL, "encode overflow, please choose a smaller scaling factor");
+  }
+  return 0;
+}
+
 int acehip_decomp(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, uint32_t digit, acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp: bad level/digit");

@@ -92,6 +92,10 @@ struct LimbConsts {
   u64 w[64];
 };
 // r[pos] = a[pos] * w[pos - pos0] mod prime(pos)   (Scalars_integer_multiply_poly polynomial.c:234-268)
+// embed.hip: rounded, scaled inverse canonical embedding (device FP64, bit-identical to the reference host code)
+struct cd;
+void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
+                      const u32* rot_group, double sf, int* err_flag, hipStream_t s);
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // r[pos] = a[pos] + w[pos - pos0] mod prime(pos)   (adding a constant plaintext, Add_const ckks_evaluator.c:116)
 void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);

@@ -213,11 +213,14 @@ void Prepare_context() {
   c->fft_rou.resize(m);
   for (size_t i = 0; i < m; ++i) {
     const double angle = 2 * M_PI * i / m;
-    c->fft_rou[i] = cplx(cos(angle), sin(angle));
+    double sn, cs;
+    sincos(angle, &sn, &cs);  // what gcc emits for the reference's cos()/sin() pair (see csrc/api.cpp)
+    c->fft_rou[i] = cplx(cs, sn);
   }
   c->rot_group.resize(c->N / 2);
   c->rot_group[0] = 1;
   for (size_t i = 1; i < c->N / 2; ++i) c->rot_group[i] = (u32)((5ull * c->rot_group[i - 1]) % m);
+  c->profile = getenv("ACEHIP_PROFILE") != nullptr;
   g_ctx = c;
   // first stdout line parsed by scripts/perf.py:266-276 (context.c:49-57)
   printf("ckks_param: _provider = %d, _poly_degree = %d, _sec_level = %ld, mul_depth = %ld, _first_mod_size = %ld, "
@@ -238,6 +241,7 @@ void Finalize_context() {
   if (g_ctx == nullptr) return;
   Context& c = *g_ctx;
   sync();
+  HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
   if (Get_rt_data_info() != nullptr) Pt_mgr_fini();
   const size_t key_words = (size_t)c.dnum * 2 * (c.L + c.K) * c.N;
   const size_t rot_cnt = c.auto_keys.size();
@@ -247,12 +251,12 @@ void Finalize_context() {
          (long)rot_cnt, (long)rot_bytes, (long)total);
   printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)c.weight_plain_cnt,
          (long)c.weight_plain_bytes);
-  if (getenv("ACEHIP_PROFILE"))
-    printf("[ACEHIP] host seconds: FP64 embedding %.3f, encode total (host side) %.3f, Main_graph %.3f\n", c.t_embed, c.t_encode, c.t_main);
+  if (c.profile) printf("[ACEHIP] host seconds: encode (launch side) %.3f, Main_graph %.3f\n", c.t_encode, c.t_main);
   for (auto& kv : c.auto_keys) free_switch_key(kv.second);
   c.auto_keys.clear();
   bootstrap_release();
   ev::clear_monomial_cache();
+  stage_release();
   pool_release_all();
   acehip_ctx_destroy(c.hip);
   delete g_ctx;

@@ -2,9 +2,9 @@
 // Reference: src/util/ckks_encoder.c:199-297 (Encode_impl, 64-bit path), :464-530 (Encode_val_at_level),
 // :649-703 (Decode), src/util/ntt.c:678-753 (Embedding / Embedding_inv), src/util/ckks_encryptor.c:20-95,
 // src/util/ckks_decryptor.c:19-65, src/ckks/plain_eval.c:17-58.
-// The FP64 embedding runs on the host exactly as the reference does (same butterfly order, libm
-// cos/sin table, no FMA contraction: this file is compiled with -ffp-contract=off); the integer
-// part (RNS reduction, scaling, NTT) runs on the device.
+// Encode runs entirely on the device (acehip_encode: FP64 inverse embedding in the reference's butterfly
+// order without FMA contraction, then RNS reduction, scaling, NTT); decode's forward embedding and the exact
+// CRT reconstruction stay on the host as in the reference (this file is compiled with -ffp-contract=off).
 #include <cmath>
 #include <cstring>
 
@@ -27,30 +27,6 @@ static void bit_reverse_vec(std::vector<cplx>& v) {
 }
 static inline cplx cmul(const cplx& a, const cplx& b) {  // (ac - bd) + (ad + bc)i, C99 operand order
   return cplx(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real());
-}
-
-// Embedding_inv ntt.c:713-753
-void embedding_inv(std::vector<cplx>& vals) {
-  Context& c = ctx();
-  const size_t n = vals.size(), m = 2ull * c.N;
-  u32 logn = 0;
-  while ((1u << logn) < n) ++logn;
-  for (u32 logm = logn; logm > 0; --logm) {
-    const size_t idx_mod = 1ull << (logm + 2), gap = m / idx_mod, num1 = 1ull << logm, num2 = 1ull << (logm - 1);
-    for (size_t j = 0; j < n; j += num1) {
-      for (size_t i = 0; i < num2; ++i) {
-        const size_t e = j + i, o = j + i + num2;
-        const size_t rou_idx = (idx_mod - (c.rot_group[i] % idx_mod)) * gap;
-        const cplx plus = vals[e] + vals[o];
-        cplx minus = vals[e] - vals[o];
-        minus = cmul(minus, c.fft_rou[rou_idx]);
-        vals[e] = plus;
-        vals[o] = minus;
-      }
-    }
-  }
-  bit_reverse_vec(vals);
-  for (auto& v : vals) v = cplx(v.real() / (double)n, v.imag() / (double)n);
 }
 
 // Embedding ntt.c:678-711
@@ -92,10 +68,56 @@ void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u3
 
 static u64 mulmod(u64 a, u64 b, u64 m) { return (u64)(((unsigned __int128)a * b) % m); }
 
-// Encode_impl ckks_encoder.c:199-297
-void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
+// Host values -> device through a small pinned ring so that the copy is asynchronous on the compute
+// stream (a pageable hipMemcpy would drain the whole launch queue on every encode).
+namespace {
+struct StageRing {
+  static constexpr int SLOTS = 8;
+  size_t slot_bytes = 0;
+  char* host = nullptr;     // pinned, SLOTS * slot_bytes
+  char* dev = nullptr;
+  void* ev[SLOTS] = {};
+  int next = 0;
+} g_ring;
+}  // namespace
+
+const void* stage_to_device(const void* src, size_t bytes) {
+  Context& c = ctx();
+  StageRing& r = g_ring;
+  const size_t need = (size_t)c.N * 8;  // N/2 complex doubles
+  RT_ASSERT(bytes <= need, "staging buffer too small");
+  if (r.host == nullptr || r.slot_bytes < need) {
+    stage_release();
+    r.slot_bytes = need;
+    r.host = (char*)acehip_malloc_host(need * StageRing::SLOTS);
+    r.dev = (char*)acehip_malloc(need * StageRing::SLOTS);
+    RT_ASSERT(r.host && r.dev, "staging allocation failed: %s", acehip_last_error());
+    for (auto& e : r.ev) e = acehip_event_create();
+  }
+  const int k = r.next;
+  r.next = (k + 1) % StageRing::SLOTS;
+  HIPCHK(acehip_event_sync(r.ev[k]));  // the copy that last read this pinned slot has finished
+  memcpy(r.host + (size_t)k * r.slot_bytes, src, bytes);
+  HIPCHK(acehip_memcpy_h2d_async(r.dev + (size_t)k * r.slot_bytes, r.host + (size_t)k * r.slot_bytes, bytes, nullptr));
+  HIPCHK(acehip_event_record(r.ev[k], nullptr));
+  return r.dev + (size_t)k * r.slot_bytes;
+}
+void stage_release() {
+  StageRing& r = g_ring;
+  if (r.host) {
+    sync();
+    for (auto& e : r.ev) acehip_event_destroy(e);
+    acehip_free_host(r.host);
+    acehip_free(r.dev);
+  }
+  r = StageRing{};
+}
+
+// Encode_impl ckks_encoder.c:199-297 on device-resident values (kind: 0 float, 1 double, 2 complex double)
+void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
   Context& c = ctx();
   RT_ASSERT(res, "null plaintext");
+  const double t0 = c.profile ? wall_s() : 0;
   const u32 N = c.N;
   if (slots == 0) slots = N / 2;
   if (level == 0) level = c.L;
@@ -103,43 +125,17 @@ void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u3
   RT_ASSERT(len <= slots, "slot size is too small");
   RT_ASSERT(slots <= N / 2, " slot size > N/2 ");
   RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
-  std::vector<cplx> v(slots, cplx(0, 0));
-  for (size_t i = 0; i < len; ++i) v[i] = values[i];
-  const double te0 = wall_s();
-  embedding_inv(v);
-  c.t_embed += wall_s() - te0;
   init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree);
-  std::vector<int64_t> msg(N, 0);
-  const u32 gap = N / (slots * 2);
-  for (u32 i = 0; i < slots; ++i) {
-    const double re = v[i].real() * c.sf + 0.5, im = v[i].imag() * c.sf + 0.5;
-    RT_ASSERT(re <= 9.2e18 && re >= -9.2e18 && im <= 9.2e18 && im >= -9.2e18,
-              "encode overflow, please choose a smaller scaling factor");
-    // the reference stores negatives as Max_64bit_value()+v and maps them back per limb
-    // (ckks_encoder.c:262-265, polynomial.c:369-391); the signed value is what every limb reduces
-    msg[(size_t)i * gap] = llround(re);
-    msg[(size_t)(i + slots) * gap] = llround(im);
-  }
   POLYNOMIAL* poly = &res->_poly;
-  u64* tmp = dalloc(N, false);
-  HIPCHK(acehip_memcpy_h2d(tmp, msg.data(), (size_t)N * 8, nullptr));
-  HIPCHK(acehip_values_to_rns(c.hip, q_limbs(poly), (const int64_t*)tmp, level, 0, level, nullptr));
-  if (p_cnt) HIPCHK(acehip_values_to_rns(c.hip, p_limbs(poly), (const int64_t*)tmp, 0, 0, p_cnt, nullptr));
-  dfree(tmp);
-  if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) per limb
-    std::vector<u64> powp(level);
-    const u64 sfi = (u64)c.sf;
-    for (u32 i = 0; i < level; ++i) {
-      const u64 q = c.primes[i];
-      u64 pw = sfi % q;
-      for (u32 d = 2; d < sf_degree; ++d) pw = mulmod(pw, sfi % q, q);
-      powp[i] = pw;
-    }
-    HIPCHK(acehip_mul_scalars(c.hip, q_limbs(poly), q_limbs(poly), powp.data(), level, 0, level, nullptr));
-  }
-  poly->_is_ntt = false;
-  poly_ntt(poly, false);
-  c.t_encode += wall_s() - te0;
+  HIPCHK(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level,
+                       p_cnt, nullptr));
+  poly->_is_ntt = true;
+  if (c.profile) c.t_encode += wall_s() - t0;
+}
+
+void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
+  static_assert(sizeof(cplx) == 16, "std::complex<double> is two doubles");
+  encode_device(res, len ? stage_to_device(values, len * sizeof(cplx)) : nullptr, 2, len, level, slots, sf_degree, p_cnt);
 }
 
 // Encode_val_at_level ckks_encoder.c:464-530 (+ Scale_back_up_by_approxfactor :406-460)
@@ -181,12 +177,8 @@ void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree) {
     for (u32 i = 0; i < level; ++i) consts[i] = mulmod(consts[i], approx[i], c.primes[i]);
   }
   // every coefficient of limb i equals consts[i] (a constant polynomial in the NTT domain)
-  std::vector<int64_t> ones(N, 1);
-  u64* tmp = dalloc(N, false);
-  HIPCHK(acehip_memcpy_h2d(tmp, ones.data(), (size_t)N * 8, nullptr));
-  HIPCHK(acehip_values_to_rns(c.hip, q_limbs(&res->_poly), (const int64_t*)tmp, level, 0, level, nullptr));
-  dfree(tmp);
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level, nullptr));
+  HIPCHK(acehip_memset(q_limbs(&res->_poly), 0, (size_t)level * N * 8, nullptr));
+  HIPCHK(acehip_add_scalars(c.hip, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level, nullptr));
   res->_poly._is_ntt = true;
 }
 
@@ -342,6 +334,7 @@ void encrypt(CIPHERTEXT* res, PLAINTEXT* plain) {
 // Decrypt ckks_decryptor.c:19-65:  m = c0 + c1*s
 void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph) {
   Context& c = ctx();
+  HIPCHK(acehip_encode_status(c.hip));  // encode overflow (the reference's assert) surfaces here at the latest
   const u32 l = (u32)ciph->_c0_poly._num_primes;
   init_plaintext(res, ciph->_slots, l, ciph->_c0_poly._num_primes_p, ciph->_scaling_factor, ciph->_sf_degree);
   u64* r = q_limbs(&res->_poly);
@@ -362,9 +355,7 @@ void Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_
     encode_value(plain, (double)*input, level, sc_degree);
     return;
   }
-  std::vector<cplx> v(len);
-  for (size_t i = 0; i < len; ++i) v[i] = cplx((double)input[i], 0.0);
-  encode_vector(plain, v.data(), len, level, 0, sc_degree, 0);
+  encode_device(plain, stage_to_device(input, len * sizeof(float)), 0, len, level, 0, sc_degree, 0);
   ctx().weight_plain_cnt++;
   ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }
@@ -373,9 +364,7 @@ void Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t s
     encode_value(plain, *input, level, sc_degree);
     return;
   }
-  std::vector<cplx> v(len);
-  for (size_t i = 0; i < len; ++i) v[i] = cplx(input[i], 0.0);
-  encode_vector(plain, v.data(), len, level, 0, sc_degree, 0);
+  encode_device(plain, stage_to_device(input, len * sizeof(double)), 1, len, level, 0, sc_degree, 0);
   ctx().weight_plain_cnt++;
   ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }

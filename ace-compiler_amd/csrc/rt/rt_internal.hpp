@@ -70,12 +70,13 @@ struct Context {
   std::map<int32_t, u32> rot2auto;            // rotation -> automorphism index
   std::vector<int64_t> sk_coef;               // ternary secret, host copy (signed)
   std::mt19937_64 rng;
-  // FFT tables for the canonical embedding (ntt.c:587-610): m = 2N
+  // FFT tables for the canonical embedding of decode (ntt.c:587-610): m = 2N
   std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
   std::vector<u32> rot_group;     // 5^i mod 2N
   // statistics
   size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
-  double t_embed = 0, t_encode = 0, t_main = 0;  // host seconds (ACEHIP_PROFILE=1 prints them)
+  bool profile = false;                          // ACEHIP_PROFILE=1: host-side timers below are printed
+  double t_encode = 0, t_main = 0;
 };
 
 extern Context* g_ctx;
@@ -115,8 +116,10 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx);
 void free_switch_key(SwitchKeyStore* k);
 
 // ---- encode / decode (ckks_encoder.c) ----
-void embedding_inv(std::vector<cplx>& vals);                           // ntt.c:713-753
 void embedding(std::vector<cplx>& vals);                               // ntt.c:678-711
+const void* stage_to_device(const void* src, size_t bytes);           // async H2D through a pinned ring
+void stage_release();
+void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt);
 void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt);
 void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree);
 void decode(std::vector<cplx>& out, PLAINTEXT* plain);

@@ -76,6 +76,8 @@ struct PtMgr {
   DataFileHdr hdr;
   std::vector<DataLutEntry> lut;
   std::vector<char> buf;  // all messages (file bytes [4096, lut_ofst))
+  char* dbuf = nullptr;   // the same bytes resident in HBM: Pt_from_msg encodes straight from here
+  std::map<uint32_t, std::pair<float*, size_t>> synth_dev;  // synthetic mode: device copy per entry
   bool open = false;
 } g_pt;
 
@@ -225,12 +227,22 @@ bool Pt_mgr_init(const char* fname) {
     const size_t sz = g_pt.hdr._lut_ofst - 4096;
     g_pt.buf.resize(sz);
     ok = pread(fd, g_pt.buf.data(), sz, 4096) == (ssize_t)sz;
+    if (ok) {
+      g_pt.dbuf = (char*)acehip_malloc(sz);
+      RT_ASSERT(g_pt.dbuf, "weight upload: %s", acehip_last_error());
+      HIPCHK(acehip_memcpy_h2d(g_pt.dbuf, g_pt.buf.data(), sz, nullptr));
+    }
   }
   close(fd);
   g_pt.open = ok;
   return ok;
 }
 void Pt_mgr_fini() {
+  rt::sync();
+  if (g_pt.dbuf) acehip_free(g_pt.dbuf);
+  g_pt.dbuf = nullptr;
+  for (auto& kv : g_pt.synth_dev) acehip_free(kv.second.first);
+  g_pt.synth_dev.clear();
   g_pt.buf.clear();
   g_pt.lut.clear();
   g_pt.open = false;
@@ -258,14 +270,36 @@ static float* pt_entry(uint32_t index, size_t len) {
   RT_ASSERT(ofst + len * sizeof(float) <= g_pt.buf.size(), "entry offset too large");
   return (float*)&g_pt.buf[ofst];
 }
+// device address of the entry (weights stay resident in HBM; no host copy per encode)
+static const float* pt_entry_dev(uint32_t index, size_t len) {
+  float* host = pt_entry(index, len);
+  if (!g_pt_synth) return (const float*)(g_pt.dbuf + ((char*)host - g_pt.buf.data()));
+  auto it = g_pt.synth_dev.find(index);
+  if (it != g_pt.synth_dev.end() && it->second.second >= len) return it->second.first;
+  if (it != g_pt.synth_dev.end()) acehip_free(it->second.first);
+  float* d = (float*)acehip_malloc(len * sizeof(float));
+  RT_ASSERT(d, "weight upload: %s", acehip_last_error());
+  HIPCHK(acehip_memcpy_h2d(d, host, len * sizeof(float), nullptr));
+  g_pt.synth_dev[index] = {d, len};
+  return d;
+}
+static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
+  if (len == 1) {  // plain_eval.c:25-33: a single value is a constant polynomial
+    Encode_plain_from_float(plain, pt_entry(index, len), len, scale, level);
+    return;
+  }
+  rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+  rt::ctx().weight_plain_cnt++;
+  rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+}
 void Pt_from_msg(void* pt, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
-  Encode_plain_from_float((PLAIN)pt, pt_entry(index, len), len, scale, level);
+  pt_encode((PLAIN)pt, index, len, scale, level);
 }
 void Pt_from_msg_validate(void* pt, float* buf, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
   float* data = pt_entry(index, len);
   for (uint32_t i = 0; i < len; ++i)
     RT_ASSERT(fabs(buf[i] - data[i]) < 0.000001, "Pt_from_msg_validate failed. index=%d, i=%d: %f != %f.", index, i, buf[i], data[i]);
-  Encode_plain_from_float((PLAIN)pt, data, len, scale, level);
+  pt_encode((PLAIN)pt, index, len, scale, level);
 }
 
 }  // extern "C"

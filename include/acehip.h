@@ -78,11 +78,17 @@ int   acehip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, acehip_str
 int   acehip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, acehip_stream stream);
 int   acehip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, acehip_stream stream);
 int   acehip_memset(void* d_ptr, int value, size_t bytes, acehip_stream stream);
+/* pinned host memory + a copy that does not wait (the source must stay untouched until an event recorded
+ * after it has completed: acehip_event_sync) */
+void* acehip_malloc_host(size_t bytes);
+int   acehip_free_host(void* h_ptr);
+int   acehip_memcpy_h2d_async(void* d_dst, const void* h_pinned_src, size_t bytes, acehip_stream stream);
 int   acehip_stream_sync(acehip_stream stream);
 /* HIP events on the launch stream (bench.py times kernels with these, not with host clocks) */
 void* acehip_event_create(void);
 int   acehip_event_record(void* event, acehip_stream stream);
 int   acehip_event_elapsed_ms(void* start, void* stop, float* ms_out); /* synchronises on `stop` */
+int   acehip_event_sync(void* event);   /* returns at once for an event never recorded */
 int   acehip_event_destroy(void* event);
 
 /* ---- NTT.  In-place over limbs [pos0, pos0+n_limbs) of the polynomial at d_poly extended at `level`.
@@ -133,6 +139,16 @@ int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const
  * d_poly[pos][n] = d_vals[n] mod prime(pos), d_vals signed 64-bit on the device
  *   (Transform_values_to_rns polynomial.c:362-392 / Transform_values_at_level :432). */
 int acehip_values_to_rns(acehip_ctx* ctx, uint64_t* d_poly, const int64_t* d_vals, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* CKKS encode of a message vector, everything on the device (Encode_at_level_with_sf ckks_encoder.c:395 ->
+ * Encode_impl :199-297 with Embedding_inv ntt.c:713-753): d_vals holds `len` values (kind 0 = float real,
+ * 1 = double real, 2 = complex double re/im interleaved), zero padded to `slots` (0 = N/2, a power of two);
+ * the FP64 inverse embedding follows the reference's butterfly order with no FMA contraction, so the plaintext
+ * is bit-identical.  Output: `level` q-limbs at d_q (times Delta^(sf_degree-1)) and n_p p-limbs at d_p
+ * (may be NULL when n_p == 0), both in the NTT domain.  Coefficient overflow (|x*Delta| > 9.2e18, the
+ * reference's assert) is recorded in a sticky flag: acehip_encode_status() synchronises and reports it. */
+int acehip_encode(acehip_ctx* ctx, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                  double scaling_factor, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream stream);
+int acehip_encode_status(acehip_ctx* ctx);
 /* uniformly random residues (Sample_uniform_poly polynomial.c:1349-1371; the generator differs from the
  * reference's BLAKE2 PRNG: key material is random by construction, parity is per operator) */
 int acehip_sample_uniform(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, uint64_t seed, acehip_stream stream);

@@ -116,6 +116,14 @@ void orc_rescale(const ORC_CTX* c, uint64_t* out, const uint64_t* in, uint32_t l
 void orc_key_switch(const ORC_CTX* c, uint64_t* out0, uint64_t* out1, const uint64_t* in,
                     const uint64_t* key, uint32_t level);
 
+/* ---- encoder (ckks_encode.c): Encode_impl ckks_encoder.c:199-297 with Embedding_inv ntt.c:713-753;
+ * values = len complex numbers (re, im interleaved) zero padded to `slots` (0 = N/2); out_q = level limbs,
+ * out_p = n_p limbs on the p primes, NTT domain.  -1 = the reference's "encode overflow" assert. ---- */
+int orc_encode(const ORC_CTX* c, uint64_t* out_q, uint64_t* out_p, const double* values, size_t len, uint32_t slots,
+               uint32_t sf_degree, uint32_t level, uint32_t n_p);
+/* Encode_val_at_level ckks_encoder.c:464-530: residue of the constant on each of `level` limbs */
+int orc_encode_value(const ORC_CTX* c, uint64_t* out_consts, double value, uint32_t sf_degree, uint32_t level);
+
 /* checksums used by the golden fixtures */
 uint64_t orc_sum64(const uint64_t* v, size_t n);
 uint64_t orc_xorw(const uint64_t* v, size_t n);

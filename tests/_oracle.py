@@ -33,7 +33,7 @@ class OrcCtx(C.Structure):
 
 def build():
     """(Re)build liboracle.so with gcc if it is missing or older than its sources."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ckks_oracle.c", "ckks_oracle.h", "rou_table.inc")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ckks_oracle.c", "ckks_encode.c", "ckks_oracle.h", "rou_table.inc")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
@@ -83,6 +83,10 @@ def lib():
         L.orc_mod_down.argtypes = [C.POINTER(OrcCtx), vp, vp, u32]
         L.orc_rescale.argtypes = [C.POINTER(OrcCtx), vp, vp, u32]
         L.orc_key_switch.argtypes = [C.POINTER(OrcCtx), vp, vp, vp, vp, u32]
+        L.orc_encode.restype = C.c_int
+        L.orc_encode.argtypes = [C.POINTER(OrcCtx), vp, vp, vp, C.c_size_t, u32, u32, u32, u32]
+        L.orc_encode_value.restype = C.c_int
+        L.orc_encode_value.argtypes = [C.POINTER(OrcCtx), vp, C.c_double, u32, u32]
         L.orc_sum64.restype = u64
         L.orc_sum64.argtypes = [vp, C.c_size_t]
         L.orc_xorw.restype = u64
@@ -91,6 +95,11 @@ def lib():
         L.orc_splitmix64.argtypes = [u64, u64]
         _lib = L
     return _lib
+
+
+def encode_message(n, seed):
+    """the message oracle/ref_dump.c `encode` feeds the reference: (float)(((i*7+seed)%17)-8)/16"""
+    return (((np.arange(n, dtype=np.int64) * 7 + seed) % 17) - 8).astype(np.float32) / np.float32(16.0)
 
 
 def ptr(a):
@@ -215,6 +224,21 @@ class Oracle:
         self.lib.orc_key_switch(self.h, ptr(o0), ptr(o1), ptr(np.ascontiguousarray(a)),
                                 ptr(np.ascontiguousarray(key)), level)
         return o0, o1
+
+    def encode(self, values, level, slots=0, sf_degree=1, n_p=0):
+        """values: complex array (zero padded to slots) -> (q limbs [level,N], p limbs [n_p,N]) NTT domain"""
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.complex128))
+        q = np.empty((level, self.N), dtype=np.uint64)
+        p = np.empty((max(n_p, 1), self.N), dtype=np.uint64)
+        rc = lib().orc_encode(self.h, ptr(q), ptr(p), v.ctypes.data_as(C.c_void_p), v.size, slots, sf_degree, level, n_p)
+        if rc != 0:
+            raise OverflowError("encode overflow")
+        return q, p[:n_p]
+
+    def encode_value(self, value, level, sf_degree=1):
+        out = np.empty(level, dtype=np.uint64)
+        assert lib().orc_encode_value(self.h, ptr(out), float(value), sf_degree, level) == 0
+        return out
 
     def num_decomp(self, level):
         return self.lib.orc_num_decomp(self.h, level)

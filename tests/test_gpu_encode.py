@@ -61,7 +61,7 @@ def test_encode_matches_reference(stub, path):
     try:
         for case in g["cases"]:
             n = case["len"]
-            msg = np.array([np.float32(((i * 7 + g["seed"]) % 17) - 8) / np.float32(16.0) for i in range(n)], dtype=np.float32)
+            msg = O.encode_message(n, g["seed"])
             pt = C.create_string_buffer(stub.Stub_sizeof_plaintext())
             stub.Encode_plain_from_float(pt, msg.ctypes.data, n, case["sf_degree"], level)
             got = _download(stub, pt, N)
@@ -81,3 +81,71 @@ def test_encode_matches_reference(stub, path):
             stub.Free_plain(pt)
     finally:
         stub.Finalize_context()
+
+
+# ---- acehip_encode through the C ABI against the oracle (oracle/ckks_encode.c, itself pinned to the reference
+# fixtures by tests/test_oracle_golden.py::test_encode_matches_reference) on inputs the fixtures do not cover:
+# complex values, sparse slot counts, extended (q+p) plaintexts, ragged and empty messages, wide dynamic range.
+ENC_CASES = [
+    # N, L, q0, sf, dnum, level, slots, len, kind, sf_degree, n_p
+    (16, 3, 60, 50, 2, 3, 0, 8, "f32", 1, 0),
+    (16, 3, 60, 50, 2, 2, 2, 2, "c128", 1, 0),
+    (16, 3, 60, 50, 2, 3, 1, 1, "f64", 2, 2),
+    (64, 7, 60, 51, 3, 4, 0, 0, "f32", 1, 0),          # empty message: the zero plaintext
+    (64, 7, 60, 51, 3, 7, 8, 5, "c128", 3, 3),
+    (1024, 7, 60, 51, 3, 6, 0, 511, "f64", 1, 0),       # ragged
+    (1024, 7, 60, 51, 3, 6, 256, 256, "c128", 1, 3),    # exactly the low-pass block size
+    (1024, 7, 60, 51, 3, 6, 512, 300, "c128", 2, 0),    # one strided stage
+    (4096, 6, 60, 50, 3, 6, 0, 2048, "f32", 1, 0),
+    (65536, 4, 60, 56, 2, 4, 0, 32768, "f32", 1, 0),    # ResNet weight shape: full slots, float message
+    (65536, 4, 60, 56, 2, 3, 4096, 4096, "c128", 1, 1), # bootstrap precompute shape: sparse slots, extended
+    (131072, 3, 60, 50, 1, 2, 0, 65536, "f64", 1, 0),   # largest ring degree the compiler emits
+]
+
+
+def _message(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    mag = np.ldexp(rng.standard_normal(n), rng.integers(-20, 4, size=n))   # wide dynamic range
+    if kind == "f32":
+        return mag.astype(np.float32)
+    if kind == "f64":
+        return mag.astype(np.float64)
+    return (mag + 1j * rng.standard_normal(n)).astype(np.complex128)
+
+
+@pytest.mark.parametrize("case", ENC_CASES, ids=["N%d_lv%d_s%d_n%d_%s_d%d_p%d" % (c[0], c[5], c[6], c[7], c[8], c[9], c[10]) for c in ENC_CASES])
+def test_encode_abi_matches_oracle(case):
+    import ace_compiler_amd as A
+
+    N, L, q0, sf, dnum, level, slots, n, kind, deg, n_p = case
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum, device=0)
+    try:
+        msg = _message(kind, n, 1000 + N + n)
+        q, p = rt.encode(msg, level, slots=slots, sf_degree=deg, n_p=n_p)
+        eq, ep = o.encode(msg.astype(np.complex128), level, slots=slots, sf_degree=deg, n_p=n_p)
+        assert np.array_equal(q, eq)
+        assert np.array_equal(p, ep)
+    finally:
+        rt.close()
+        o.close()
+
+
+def test_encode_overflow_is_reported():
+    """|x * Delta| > 9.2e18 is the reference's "encode overflow" assert (ckks_encoder.c:255-258): the device path
+    records it and acehip_encode_status fails; the oracle reports the same."""
+    import ace_compiler_amd as A
+
+    o = O.Oracle(64, 3, 60, 50, 1)
+    rt = A.AceHip(64, 3, 60, 50, 1, device=0)
+    try:
+        msg = np.full(32, 1.0e5, dtype=np.float64)
+        with pytest.raises(OverflowError):
+            o.encode(msg.astype(np.complex128), 3)
+        with pytest.raises(A.AceHipError, match="encode overflow"):
+            rt.encode(msg, 3)
+        q, _ = rt.encode(np.ones(32), 3)  # the flag is cleared once reported
+        assert np.array_equal(q, o.encode(np.ones(32, dtype=np.complex128), 3)[0])
+    finally:
+        rt.close()
+        o.close()
