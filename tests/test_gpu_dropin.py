@@ -46,3 +46,32 @@ def test_own_program_config_c1(tmp_path):
     subprocess.check_call(cmd)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_resnet20_logits_match_reference_cpu_run(tmp_path):
+    """BASELINE configs[3] end to end: the UNCHANGED ACE-generated ResNet-20 source (resnet20_cifar10_pre.onnx.inc,
+    linked against our library by `make -C oracle models`) on the synthetic weight file of tools/make_weight_file.py
+    must reproduce the logits the REFERENCE rtlib computed on the CPU from the same file and image
+    (profiles/cpu_resnet20_devbox.json, 1429 s there).  Keys and encryption noise are random on both sides, so the
+    comparison is at CKKS precision, not bit level; the weight plaintext count and rotation-key count are exact."""
+    import json
+    import re
+    import sys
+
+    exe = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/examples/model_* not built (needs /root/reference: make -C oracle models)")
+    wfile = str(tmp_path / "resnet20.msg")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_weight_file.py"), "--entries",
+                           os.path.join(ROOT, "tests", "golden", "resnet20_pt_entries.txt"), "--out", wfile])
+    env = dict(os.environ, ACEHIP_RT_DATA_FILE=wfile, MODEL_DATA_FILE=wfile)
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"logits:((?: -?\d+\.\d+)+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    got = [float(x) for x in m.group(1).split()]
+    ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_resnet20_devbox.json")))["logits_reference_cpu"]
+    assert len(got) == len(ref) == 10
+    assert max(abs(a - b) for a, b in zip(got, ref)) <= 2e-4, (got, ref)
+    assert "rot_key_cnt = 227," in r.stdout            # same rotation-key set as the reference log
+    assert "Total memory size for weight plain: cnt = 6044," in r.stdout
