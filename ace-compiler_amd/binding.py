@@ -59,6 +59,7 @@ SYMBOLS = [
     ("acehip_hw_modadd", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_modmul", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_rotate", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_hw_batch", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_decomp_modup", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_down", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_rescale", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
@@ -95,6 +96,14 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+class HwOp(C.Structure):
+    """acehip_hw_op of include/acehip.h"""
+    _fields_ = [("op", C.c_uint32), ("prime_gi", C.c_uint32), ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p)]
+
+
+HW_ADD, HW_MUL, HW_ROTATE, HW_COPY, HW_ZERO = range(5)
 
 
 class DeviceBuffer:
@@ -285,6 +294,11 @@ class AceHip:
         for d in (dv, dq, dp):
             d.free()
         return q, p_
+
+    def hw_batch(self, ops):
+        """ops: iterable of (op, prime_gi, res_ptr, a_ptr, b_ptr) device addresses -> acehip_hw_batch"""
+        arr = (HwOp * len(ops))(*[HwOp(o, g, r, a or None, b or None) for o, g, r, a, b in ops])
+        self.check(self.lib.acehip_hw_batch(self.h, arr, len(ops), None))
 
     def key_switch(self, a, key, level):
         da, dk = self.to_device(a), self.to_device(key)

@@ -472,6 +472,207 @@ int acehip_hw_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32
   return post_launch();
 }
 
+// ---- acehip_hw_batch: a list of per-limb ops, executed as if issued one by one ----
+namespace {
+struct HwScratch {  // reused across calls: the shim flushes ~10k batches per ResNet-20 image
+  struct Slot {
+    u64 key;  // bucket + 1, 0 = empty
+    u64 ptr;
+    u32 node;
+  };
+  std::vector<Slot> table;
+  std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b;
+  std::vector<char> written;
+};
+thread_local HwScratch g_hw;
+
+inline bool hw_has_a(u32 k) { return k != ACEHIP_HW_ZERO; }
+inline bool hw_has_b(u32 k) { return k == ACEHIP_HW_ADD || k == ACEHIP_HW_MUL; }
+
+u32 uf_find(std::vector<u32>& p, u32 x) {
+  while (p[x] != x) {
+    p[x] = p[p[x]];
+    x = p[x];
+  }
+  return x;
+}
+
+// node id of limb pointer `ptr` (one node per distinct limb), or UINT32_MAX if it partially overlaps a limb
+// already seen (then the batch cannot be reordered and is issued op by op)
+u32 hw_node(HwScratch& h, u64 ptr, u64 span, u64 mask) {
+  const u64 b = ptr / span;
+  u32 found = UINT32_MAX;
+  for (int d = -1; d <= 1; ++d) {
+    const u64 key = b + (u64)(int64_t)d + 1;
+    if (key == 0) continue;
+    for (u64 i = (key * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
+      HwScratch::Slot& sl = h.table[i & mask];
+      if (sl.key == 0) break;
+      if (sl.key != key) continue;
+      if (sl.ptr == ptr) found = sl.node;
+      else if ((sl.ptr < ptr ? ptr - sl.ptr : sl.ptr - ptr) < span) return UINT32_MAX;
+      break;  // at most one limb per bucket once partial overlaps are excluded
+    }
+  }
+  if (found != UINT32_MAX) return found;
+  const u32 node = (u32)h.parent.size();
+  h.parent.push_back(node);
+  h.written.push_back(0);
+  for (u64 i = ((b + 1) * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
+    HwScratch::Slot& sl = h.table[i & mask];
+    if (sl.key == 0) {
+      sl = HwScratch::Slot{b + 1, ptr, node};
+      break;
+    }
+  }
+  return node;
+}
+
+void hw_issue_one(acehip_ctx* c, const acehip_hw_op& o, hipStream_t st) {
+  HwBatchArgs args;
+  args.op[0] = HwBatchOp{o.res, o.a, (const u64*)o.b, o.op, o.prime_gi};
+  args.seg_start[0] = 0;
+  args.seg_start[1] = 1;
+  if (o.op == ACEHIP_HW_ROTATE) launch_hw_batch_rotate(c->dc, args, 1, st);
+  else launch_hw_batch_ew(c->dc, args, 1, st);
+}
+
+// elementwise run ops[0, m): chains = connected components over limbs that some op of the run writes
+void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st) {
+  HwScratch& h = g_hw;
+  const u64 span = (u64)c->hp.N * 8;
+  size_t cap = 64;
+  while (cap < 6 * m) cap <<= 1;
+  if (h.table.size() < cap) h.table.resize(cap);
+  std::memset(h.table.data(), 0, cap * sizeof(HwScratch::Slot));
+  const u64 mask = cap - 1;
+  h.parent.clear();
+  h.written.clear();
+  h.n_res.resize(m);
+  h.n_a.resize(m);
+  h.n_b.resize(m);
+  bool reorder_ok = true;
+  for (size_t k = 0; k < m && reorder_ok; ++k) {
+    const acehip_hw_op& o = ops[k];
+    const u32 nr = hw_node(h, (u64)o.res, span, mask);
+    const u32 na = hw_has_a(o.op) ? hw_node(h, (u64)o.a, span, mask) : 0;
+    const u32 nb = hw_has_b(o.op) ? hw_node(h, (u64)o.b, span, mask) : 0;
+    if (nr == UINT32_MAX || na == UINT32_MAX || nb == UINT32_MAX) {
+      reorder_ok = false;
+      break;
+    }
+    h.n_res[k] = nr;
+    h.n_a[k] = na;
+    h.n_b[k] = nb;
+    h.written[nr] = 1;
+  }
+  if (!reorder_ok) {  // partially overlapping limbs: keep the caller's order, one launch per op
+    for (size_t k = 0; k < m; ++k) hw_issue_one(c, ops[k], st);
+    return;
+  }
+  for (size_t k = 0; k < m; ++k) {
+    const u32 r = uf_find(h.parent, h.n_res[k]);
+    if (hw_has_a(ops[k].op) && h.written[h.n_a[k]]) h.parent[uf_find(h.parent, h.n_a[k])] = r;
+    if (hw_has_b(ops[k].op) && h.written[h.n_b[k]]) h.parent[uf_find(h.parent, h.n_b[k])] = uf_find(h.parent, r);
+  }
+  // chains numbered by first appearance; ops of a chain keep their program order
+  const u32 n_nodes = (u32)h.parent.size();
+  h.comp_of_node.assign(n_nodes, UINT32_MAX);
+  h.cnt.clear();
+  for (size_t k = 0; k < m; ++k) {
+    const u32 root = uf_find(h.parent, h.n_res[k]);
+    if (h.comp_of_node[root] == UINT32_MAX) {
+      h.comp_of_node[root] = (u32)h.cnt.size();
+      h.cnt.push_back(0);
+    }
+    h.cnt[h.comp_of_node[root]]++;
+  }
+  u32 run = 0;
+  for (auto& x : h.cnt) {  // counts -> start offsets
+    const u32 t = x;
+    x = run;
+    run += t;
+  }
+  h.ord.resize(m);
+  for (size_t k = 0; k < m; ++k) h.ord[h.cnt[h.comp_of_node[uf_find(h.parent, h.n_res[k])]]++] = (u32)k;
+  // after the scatter cnt[j] = end offset of chain j
+  HwBatchArgs args;
+  u32 n_ops = 0, n_seg = 0, chain = 0, prev_chain = UINT32_MAX;
+  args.seg_start[0] = 0;
+  for (size_t t = 0; t < m; ++t) {
+    while (t >= h.cnt[chain]) ++chain;
+    if (n_ops == HW_BATCH_MAX) {  // a chain cut here continues in the next launch, which is ordered after this one
+      args.seg_start[++n_seg] = (uint16_t)n_ops;
+      launch_hw_batch_ew(c->dc, args, n_seg, st);
+      n_ops = 0;
+      n_seg = 0;
+      prev_chain = UINT32_MAX;
+    }
+    if (n_ops && chain != prev_chain) args.seg_start[++n_seg] = (uint16_t)n_ops;
+    prev_chain = chain;
+    const acehip_hw_op& o = ops[h.ord[t]];
+    args.op[n_ops++] = HwBatchOp{o.res, o.a, (const u64*)o.b, o.op, o.prime_gi};
+  }
+  args.seg_start[++n_seg] = (uint16_t)n_ops;
+  launch_hw_batch_ew(c->dc, args, n_seg, st);
+}
+
+inline bool limbs_overlap(const void* x, const void* y, u64 span) {
+  const u64 a = (u64)x, b = (u64)y;
+  return (a < b ? b - a : a - b) < span;
+}
+
+// rotation run: gathers are independent unless a result aliases a source or result of the same launch
+void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st) {
+  const u64 span = (u64)c->hp.N * 8;
+  HwBatchArgs args;
+  u32 n_ops = 0;
+  size_t first = 0;
+  for (size_t k = 0; k < m; ++k) {
+    bool cut = n_ops == HW_BATCH_MAX;
+    for (size_t j = first; j < k && !cut; ++j)
+      cut = limbs_overlap(ops[k].res, ops[j].res, span) || limbs_overlap(ops[k].res, ops[j].a, span) ||
+            limbs_overlap(ops[k].a, ops[j].res, span);
+    if (cut) {
+      launch_hw_batch_rotate(c->dc, args, n_ops, st);
+      n_ops = 0;
+      first = k;
+    }
+    args.op[n_ops++] = HwBatchOp{ops[k].res, ops[k].a, (const u64*)ops[k].b, ops[k].op, ops[k].prime_gi};
+  }
+  launch_hw_batch_rotate(c->dc, args, n_ops, st);
+}
+}  // namespace
+
+int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (n == 0) return ACEHIP_OK;
+  if (!ops) return fail(ACEHIP_EINVAL, "acehip_hw_batch: null op list");
+  const u32 T = c->hp.L + c->hp.K;
+  const u64 span = (u64)c->hp.N * 8;
+  for (size_t k = 0; k < n; ++k) {
+    const acehip_hw_op& o = ops[k];
+    if (o.op > ACEHIP_HW_ZERO) return fail(ACEHIP_EINVAL, "acehip_hw_batch: unknown op");
+    if (!o.res || (hw_has_a(o.op) && !o.a) || ((hw_has_b(o.op) || o.op == ACEHIP_HW_ROTATE) && !o.b))
+      return fail(ACEHIP_EINVAL, "acehip_hw_batch: null operand");
+    if (hw_has_b(o.op) && o.prime_gi >= T) return fail(ACEHIP_EINVAL, "prime index out of range");
+    if (o.op == ACEHIP_HW_ROTATE && limbs_overlap(o.res, o.a, span))
+      return fail(ACEHIP_EINVAL, "acehip_hw_batch: in-place rotation is not supported");
+  }
+  (void)hipSetDevice(c->device);
+  hipStream_t st = (hipStream_t)s;
+  size_t i = 0;
+  while (i < n) {
+    size_t j = i;
+    const bool rot = ops[i].op == ACEHIP_HW_ROTATE;
+    while (j < n && (ops[j].op == ACEHIP_HW_ROTATE) == rot) ++j;
+    if (rot) hw_run_rotate(c, ops + i, j - i, st);
+    else hw_run_ew(c, ops + i, j - i, st);
+    i = j;
+  }
+  return post_launch();
+}
+
 int acehip_decomp_modup(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, uint32_t digit, acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp_modup: bad level/digit");

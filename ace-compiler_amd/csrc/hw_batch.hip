@@ -1,0 +1,69 @@
+// hw_batch.hip -- many per-limb Hw_modadd / Hw_modmul / Hw_rotate calls (poly_arith.c:14-56) in a handful of
+// launches.  ACE-generated code spells every ciphertext operation as a host loop over the RNS limbs, one
+// Hw_* call per limb and component; launched one by one that is ~600k kernels of 1.5 MB each per ResNet-20
+// image and the GPU idles on launch latency.  The host side (api.cpp acehip_hw_batch) groups a list of such
+// ops into dependency chains (ops that touch a common written limb, kept in program order) and hands up to
+// HW_BATCH_MAX ops to one launch: blockIdx.y walks one chain segment in order, so a coefficient's whole
+// history stays in one lane and the sequential semantics of the original call sequence are preserved.
+#include "device_arith.hpp"
+#include "kernels.hpp"
+
+namespace acehip {
+
+// every lane owns coefficients (i, i+1) of all limbs of its segment: read-after-write between ops of a chain
+// goes through the lane's own stores, which it observes in order
+__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs args) {
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
+  for (u32 k = beg; k < end; ++k) {
+    const HwBatchOp op = args.op[k];
+    ulong2 vr;
+    if (op.kind == HW_OP_ZERO) {
+      vr.x = 0;
+      vr.y = 0;
+    } else {
+      const ulong2 va = *reinterpret_cast<const ulong2*>(op.a + i);
+      if (op.kind == HW_OP_COPY) {
+        vr = va;
+      } else {
+        const ulong2 vb = *reinterpret_cast<const ulong2*>(op.b + i);
+        const DevPrime P = c.primes[op.gi];
+        if (op.kind == HW_OP_ADD) {
+          vr.x = add_mod(va.x, vb.x, P.q);
+          vr.y = add_mod(va.y, vb.y, P.q);
+        } else {
+          vr.x = mul_mod(va.x, vb.x, P);
+          vr.y = mul_mod(va.y, vb.y, P);
+        }
+      }
+    }
+    *reinterpret_cast<ulong2*>(op.res + i) = vr;
+  }
+}
+
+// independent gathers r[j] = a[perm[j]] (the host guarantees no result aliases any source of the launch)
+__global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgs args) {
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= N) return;
+  const HwBatchOp op = args.op[blockIdx.y];
+  const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const u32*>(op.b) + i);
+  ulong2 v;
+  v.x = op.a[p.x];
+  v.y = op.a[p.y];
+  *reinterpret_cast<ulong2*>(op.res + i) = v;
+}
+
+void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
+  if (n_seg == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_seg), block(256);
+  hipLaunchKernelGGL(hw_batch_ew_kernel, grid, block, 0, s, c, args);
+}
+
+void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
+  if (n_ops == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_ops), block(256);
+  hipLaunchKernelGGL(hw_batch_rotate_kernel, grid, block, 0, s, c.N, args);
+}
+
+}  // namespace acehip

@@ -92,6 +92,21 @@ struct LimbConsts {
   u64 w[64];
 };
 // r[pos] = a[pos] * w[pos - pos0] mod prime(pos)   (Scalars_integer_multiply_poly polynomial.c:234-268)
+// hw_batch.hip: a list of per-limb ops in one launch (kernel argument block, < 4 KB)
+constexpr u32 HW_BATCH_MAX = 112;
+enum : u32 { HW_OP_ADD = 0, HW_OP_MUL = 1, HW_OP_ROTATE = 2, HW_OP_COPY = 3, HW_OP_ZERO = 4 };
+struct HwBatchOp {
+  u64* res;
+  const u64* a;
+  const u64* b;   // second operand; the u32 automorphism table for HW_OP_ROTATE
+  u32 kind, gi;
+};
+struct HwBatchArgs {
+  HwBatchOp op[HW_BATCH_MAX];
+  uint16_t seg_start[HW_BATCH_MAX + 1];  // chain segments of the elementwise kernel: ops [seg_start[y], seg_start[y+1])
+};
+void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s);
+void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s);
 // embed.hip: rounded, scaled inverse canonical embedding (device FP64, bit-identical to the reference host code)
 struct cd;
 void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,

@@ -32,8 +32,12 @@
       abort();                                            \
     }                                                     \
   } while (0)
+// Every device call of the shim goes through HIPCHK, which first hands over the per-limb Hw_* calls
+// that are still queued (rt_poly.cpp hw_queue): the device sees all work in program order.
+namespace rt { void hw_flush(); }
 #define HIPCHK(expr)                                                                       \
   do {                                                                                     \
+    rt::hw_flush();                                                                        \
     int rc_ = (expr);                                                                      \
     if (rc_ < 0) {                                                                         \
       fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
@@ -102,6 +106,8 @@ void poly_ntt(POLYNOMIAL* p, bool inverse);                            // Conv_p
 void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx);        // Rotate_poly (NTT domain)
 void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transform_values_at_level(without_mod)
 void sync();
+// queue `n_limbs` consecutive limbs of a per-limb op (ACEHIP_HW_*) instead of launching it now
+void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs = 1);
 double wall_s();
 
 // ---- sampling (random_sample.c) ----

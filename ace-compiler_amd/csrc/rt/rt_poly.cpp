@@ -22,6 +22,41 @@ static std::map<size_t, std::vector<u64*>> pool_free;
 static std::map<u64*, size_t> pool_live;
 static size_t pool_live_bytes = 0;
 
+// ---- deferred per-limb ops ----
+// Generated code calls Hw_modadd / Hw_modmul / Hw_rotate once per RNS limb and component inside host loops
+// (resnet20_cifar10_pre.onnx.inc:1492-1503).  They are queued here and handed to acehip_hw_batch when any other
+// device work is issued (HIPCHK), so a whole loop nest becomes a few launches; zero fills and limb copies
+// that sit between such loops ride in the same queue.  Single-threaded like the reference runtime.
+namespace {
+std::vector<acehip_hw_op> g_hwq;
+}
+void hw_flush() {
+  if (g_hwq.empty()) return;
+  const int rc = acehip_hw_batch(ctx().hip, g_hwq.data(), g_hwq.size(), nullptr);
+  g_hwq.clear();
+  RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());
+}
+void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs) {
+  const size_t N = ctx().N;
+  for (size_t l = 0; l < n_limbs; ++l)
+    g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
+                                 b ? (const void*)((const u64*)b + l * N) : nullptr});
+  if (g_hwq.size() >= 8192) hw_flush();
+}
+// zero fill / copy of whole limbs through the queue (anything else goes the direct way)
+static void fill_zero(u64* p, size_t words) {
+  const size_t N = ctx().N;
+  if (words % N == 0) hw_queue(ACEHIP_HW_ZERO, 0, p, nullptr, nullptr, words / N);
+  else HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
+}
+static void copy_limbs(u64* dst, const u64* src, size_t words) {
+  const size_t N = ctx().N;
+  if (dst == src) return;
+  const size_t gap = dst < src ? src - dst : dst - src;
+  if (words % N == 0 && gap >= words) hw_queue(ACEHIP_HW_COPY, 0, dst, src, nullptr, words / N);
+  else HIPCHK(acehip_memcpy_d2d(dst, src, words * sizeof(u64), nullptr));
+}
+
 u64* dalloc(size_t words, bool zero) {
   if (words == 0) words = 1;
   u64* p = nullptr;
@@ -42,7 +77,7 @@ u64* dalloc(size_t words, bool zero) {
     pool_live[p] = words;
     pool_live_bytes += words * sizeof(u64);
   }
-  if (zero) HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
+  if (zero) fill_zero(p, words);
   return p;
 }
 
@@ -101,7 +136,7 @@ void poly_init_like(POLYNOMIAL* res, POLYNOMIAL* like) {
       poly_free(res);
       poly_alloc(res, N, nq, np);
     } else {
-      HIPCHK(acehip_memset(res->_data, 0, res->_num_alloc_primes * (size_t)res->_ring_degree * 8, nullptr));
+      fill_zero((u64*)res->_data, res->_num_alloc_primes * (size_t)res->_ring_degree);
       res->_ring_degree = N;
       res->_num_primes = nq;
       res->_num_primes_p = np;
@@ -121,8 +156,8 @@ void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src) {
   res->_num_primes = src->_num_primes;
   res->_num_primes_p = src->_num_primes_p;
   res->_is_ntt = src->_is_ntt;
-  if (src->_num_primes) HIPCHK(acehip_memcpy_d2d(q_limbs(res), q_limbs(src), src->_num_primes * N * 8, nullptr));
-  if (src->_num_primes_p) HIPCHK(acehip_memcpy_d2d(p_limbs(res), p_limbs(src), src->_num_primes_p * N * 8, nullptr));
+  if (src->_num_primes) copy_limbs(q_limbs(res), q_limbs(src), src->_num_primes * N);
+  if (src->_num_primes_p) copy_limbs(p_limbs(res), p_limbs(src), src->_num_primes_p * N);
 }
 
 void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p) {
@@ -200,17 +235,17 @@ void Copy_poly(POLY res, POLY poly) { poly_copy(res, poly); }
 void Set_coeffs(POLY dst, uint32_t level, uint32_t degree, int64_t* src) {
   int64_t* d = Coeffs(dst, level, degree);
   if (d == src) return;  // generated code does self-copies (resnet20 .inc:1546)
-  HIPCHK(acehip_memcpy_d2d(d, src, (size_t)degree * 8, nullptr));
+  copy_limbs((u64*)d, (const u64*)src, degree);
 }
 size_t Num_decomp(POLY poly) { return acehip_num_decomp(ctx().hip, (uint32_t)poly->_num_primes); }
 
 // ---- poly_arith.c:14-56: one limb per call, modulus = Q_modulus()+i or P_modulus()+i ----
 int64_t* Hw_modadd(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
-  HIPCHK(acehip_hw_modadd(ctx().hip, (u64*)res, (u64*)a, (u64*)b, m->_gi, nullptr));
+  hw_queue(ACEHIP_HW_ADD, m->_gi, (u64*)res, (const u64*)a, b);
   return res + degree;
 }
 int64_t* Hw_modmul(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
-  HIPCHK(acehip_hw_modmul(ctx().hip, (u64*)res, (u64*)a, (u64*)b, m->_gi, nullptr));
+  hw_queue(ACEHIP_HW_MUL, m->_gi, (u64*)res, (const u64*)a, b);
   return res + degree;
 }
 int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, uint32_t degree) {
@@ -220,7 +255,7 @@ int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, u
     HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, tmp, (const uint32_t*)rot_precomp, m->_gi, nullptr));
     dfree(tmp);
   } else {
-    HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, (u64*)a, (const uint32_t*)rot_precomp, m->_gi, nullptr));
+    hw_queue(ACEHIP_HW_ROTATE, m->_gi, (u64*)res, (const u64*)a, rot_precomp);  // one limb: the table is not advanced
   }
   return res + degree;
 }
@@ -239,6 +274,7 @@ POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
     res->_num_primes = n2;
     res->_num_primes_p = 0;
   }
+  hw_flush();
   int rc = acehip_decomp(c.hip, q_limbs(res), q_limbs(poly), level, q_part_idx, nullptr);
   HIPCHK(rc);
   res->_is_ntt = poly->_is_ntt;

@@ -119,6 +119,23 @@ int acehip_hw_modadd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, cons
 int acehip_hw_modmul(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t prime_gi, acehip_stream stream);
 int acehip_hw_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint32_t* d_perm, uint32_t prime_gi, acehip_stream stream);
 
+/* A list of such per-limb calls handed over at once.  Result: exactly what issuing ops[0..n) one by one would
+ * give (limbs are N words; two limb pointers are either equal or disjoint in every case the reference code
+ * produces -- partially overlapping limbs are still handled, op by op).  The library groups the ops into
+ * dependency chains and runs them in a few launches instead of n: generated code calls Hw_* once per RNS limb
+ * and component, ~600k times per ResNet-20 image.
+ *   ADD/MUL: res = a (+|*) b mod prime(prime_gi);  ROTATE: res[j] = a[perm[j]], b = table of
+ *   acehip_auto_order(), res must not alias a;  COPY: res = a;  ZERO: res = 0. */
+enum { ACEHIP_HW_ADD = 0, ACEHIP_HW_MUL = 1, ACEHIP_HW_ROTATE = 2, ACEHIP_HW_COPY = 3, ACEHIP_HW_ZERO = 4 };
+typedef struct acehip_hw_op {
+  uint32_t        op;        /* ACEHIP_HW_* */
+  uint32_t        prime_gi;  /* ADD/MUL: global prime index (q: 0..L-1, p: L..L+K-1) */
+  uint64_t*       res;
+  const uint64_t* a;
+  const void*     b;         /* second operand (uint64 limb), or the uint32 automorphism table for ROTATE */
+} acehip_hw_op;
+int acehip_hw_batch(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, acehip_stream stream);
+
 /* ---- RNS basis operations (NTT-domain in, NTT-domain out) ----
  * Decomp_modup (src/poly/poly_eval.c:28 -> Decompose_modup polynomial.c:1241-1335): digit `digit` of
  *   d_in (level q-limbs) raised to the level+K limbs of d_out.

@@ -1,0 +1,180 @@
+"""acehip_hw_batch (include/acehip.h): a list of per-limb Hw_modadd / Hw_modmul / Hw_rotate / copy / zero ops
+must give exactly what issuing them one by one gives (the reference's call sequence, poly_arith.c:14-56), for any
+mix of dependencies: accumulation chains, in-place operands, shared read-only operands, chains longer than one
+launch, rotation runs with aliasing, partially overlapping limb pointers.  Checked bit-exactly against the oracle
+applying the same program sequentially on the host."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N, L, Q0, SF, DNUM = 4096, 6, 60, 50, 3
+
+
+@pytest.fixture(scope="module")
+def env():
+    import ace_compiler_amd as A
+    from ace_compiler_amd import binding as B
+
+    o = O.Oracle(N, L, Q0, SF, DNUM)
+    rt = A.AceHip(N, L, Q0, SF, DNUM, device=0)
+    yield o, rt, B
+    rt.close()
+    o.close()
+
+
+def _arena(o, rows, seed):
+    """rows x T limbs; column g holds residues of prime g"""
+    T = o.L + o.K
+    out = np.empty((rows * T, N), dtype=np.uint64)
+    rng = np.random.default_rng(seed)
+    for s in range(rows * T):
+        out[s] = rng.integers(0, o.primes[s % T], size=N, dtype=np.uint64)
+    return out
+
+
+def _apply_host(o, B, arena, prog, perms):
+    flat = arena.reshape(-1)
+
+    def limb(off):
+        return flat[off:off + N]
+
+    for op, gi, r, a, b in prog:
+        if op == B.HW_ADD:
+            res = o.hw_modadd(limb(a).reshape(1, N).copy(), limb(b).reshape(1, N).copy(), [gi])[0]
+        elif op == B.HW_MUL:
+            res = o.hw_modmul(limb(a).reshape(1, N).copy(), limb(b).reshape(1, N).copy(), [gi])[0]
+        elif op == B.HW_ROTATE:
+            res = limb(a)[perms[b]].copy()
+        elif op == B.HW_COPY:
+            res = limb(a).copy()
+        else:
+            res = np.zeros(N, dtype=np.uint64)
+        flat[r:r + N] = res
+
+
+def _run_device(rt, B, arena, prog, perm_bufs):
+    d = rt.to_device(arena)
+    ops = []
+    for op, gi, r, a, b in prog:
+        bp = perm_bufs[b].ptr if op == B.HW_ROTATE else (d.at(b) if op in (B.HW_ADD, B.HW_MUL) else None)
+        ops.append((op, gi, d.at(r), d.at(a) if op != B.HW_ZERO else None, bp))
+    rt.hw_batch(ops)
+    out = d.download(arena.shape)
+    d.free()
+    return out
+
+
+def _random_program(o, B, rows, n_ops, seed, rot_keys):
+    T = o.L + o.K
+    rng = np.random.default_rng(seed)
+    prog = []
+    while len(prog) < n_ops:
+        kind = rng.choice(["ew", "ew", "ew", "rot"]) if rot_keys else "ew"
+        if kind == "ew":
+            for _ in range(int(rng.integers(1, 40))):
+                gi = int(rng.integers(0, T))
+                r, a, b = (int((gi + T * rng.integers(0, rows)) * N) for _ in range(3))
+                op = int(rng.choice([B.HW_ADD, B.HW_ADD, B.HW_MUL, B.HW_MUL, B.HW_COPY, B.HW_ZERO]))
+                prog.append((op, gi, r, a, b))
+        else:
+            k = int(rng.choice(rot_keys))
+            for _ in range(int(rng.integers(1, 12))):
+                gi = int(rng.integers(0, T))
+                r, a = (int((gi + T * rng.integers(0, rows)) * N) for _ in range(2))
+                if r != a:
+                    prog.append((B.HW_ROTATE, gi, r, a, k))
+    return prog[:n_ops]
+
+
+def _check(env, prog, rows, seed, rot_keys=()):
+    o, rt, B = env
+    arena = _arena(o, rows, seed)
+    perms = {k: np.asarray(o.automorphism(k, True), dtype=np.int64) for k in rot_keys}
+    bufs = {}
+    for k in rot_keys:
+        bufs[k] = rt.buf(N, np.uint32).upload(perms[k].astype(np.uint32))
+    want = arena.copy()
+    _apply_host(o, B, want, prog, perms)
+    got = _run_device(rt, B, arena, prog, bufs)
+    for b in bufs.values():
+        b.free()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_programs(env, seed):
+    o, rt, B = env
+    ks = [rt.auto_index(1), rt.auto_index(-3), rt.auto_index(64)]
+    _check(env, _random_program(o, B, rows=3, n_ops=700, seed=seed, rot_keys=ks), rows=3, seed=10 + seed, rot_keys=ks)
+
+
+def test_generated_conv_loop_shape(env):
+    """the per-limb loop body of a generated conv (resnet20_cifar10_pre.onnx.inc:1492-1503): tmp = ct * pt on c0 and
+    c1, acc += tmp -- 4 ops per limb, repeated for 9 kernel taps without a flush in between"""
+    o, rt, B = env
+    T = o.L + o.K
+
+    def at(row, g):
+        return (row * T + g) * N
+
+    prog = []
+    for tap in range(9):
+        for g in range(o.L):
+            prog += [(B.HW_MUL, g, at(4, g), at(0, g), at(2, g)), (B.HW_MUL, g, at(5, g), at(1, g), at(2, g)),
+                     (B.HW_ADD, g, at(6, g), at(6, g), at(4, g)), (B.HW_ADD, g, at(7, g), at(7, g), at(5, g))]
+    _check(env, prog, rows=8, seed=5)
+
+
+def test_long_accumulation_chain(env):
+    """one chain of 300 dependent ops (more than one launch can hold) on a single limb"""
+    o, rt, B = env
+    T = o.L + o.K
+    g = 1
+    acc, x, y = g * N, (T + g) * N, (2 * T + g) * N
+    prog = []
+    for i in range(150):
+        prog += [(B.HW_MUL, g, x, x, y), (B.HW_ADD, g, acc, acc, x)]
+    _check(env, prog, rows=3, seed=6)
+
+
+def test_partially_overlapping_limbs_keep_call_order(env):
+    """limb pointers that overlap by half a limb cannot be reordered: the result must still be the sequential one"""
+    o, rt, B = env
+    g = 0
+    prog = [(B.HW_ADD, g, 0, 0, N // 2), (B.HW_COPY, g, N // 2, 0, 0), (B.HW_MUL, g, 2 * N, N // 2, 0),
+            (B.HW_ZERO, g, N + N // 2, 0, 0), (B.HW_ADD, g, N, N // 2, 2 * N)]
+    arena = np.empty((4, N), dtype=np.uint64)
+    arena[:] = np.random.default_rng(3).integers(0, o.primes[0], size=(4, N), dtype=np.uint64)
+    want = arena.copy()
+    _apply_host(o, B, want, prog, {})
+    got = _run_device(rt, B, arena, prog, {})
+    assert np.array_equal(got, want)
+
+
+def test_rotation_runs_with_aliasing(env):
+    """a rotation whose source is the result of an earlier rotation of the same list, and results reused as sources"""
+    o, rt, B = env
+    T = o.L + o.K
+    k = rt.auto_index(5)
+    prog = []
+    for g in range(T):
+        a, b, c = g * N, (T + g) * N, (2 * T + g) * N
+        prog += [(B.HW_ROTATE, g, b, a, k), (B.HW_ROTATE, g, c, b, k), (B.HW_ROTATE, g, a, c, k)]
+    _check(env, prog, rows=3, seed=8, rot_keys=[k])
+
+
+def test_bad_arguments_fail_loudly(env):
+    o, rt, B = env
+    import ace_compiler_amd as A
+
+    d = rt.buf(2 * N)
+    with pytest.raises(A.AceHipError, match="in-place rotation"):
+        rt.hw_batch([(B.HW_ROTATE, 0, d.at(0), d.at(0), d.at(N))])
+    with pytest.raises(A.AceHipError, match="prime index"):
+        rt.hw_batch([(B.HW_ADD, 99, d.at(0), d.at(0), d.at(N))])
+    with pytest.raises(A.AceHipError, match="null operand"):
+        rt.hw_batch([(B.HW_MUL, 0, d.at(0), d.at(0), None)])
+    d.free()
