@@ -103,7 +103,7 @@ class HwOp(C.Structure):
     _fields_ = [("op", C.c_uint32), ("prime_gi", C.c_uint32), ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p)]
 
 
-HW_ADD, HW_MUL, HW_ROTATE, HW_COPY, HW_ZERO = range(5)
+HW_ADD, HW_MUL, HW_ROTATE, HW_COPY, HW_ZERO, HW_SUB, HW_MULADD, HW_MULC, HW_ADDC = range(9)
 
 
 class DeviceBuffer:

@@ -487,7 +487,10 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
 thread_local HwScratch g_hw;
 
 inline bool hw_has_a(u32 k) { return k != ACEHIP_HW_ZERO; }
-inline bool hw_has_b(u32 k) { return k == ACEHIP_HW_ADD || k == ACEHIP_HW_MUL; }
+inline bool hw_has_b(u32 k) {  // second operand is a limb in memory
+  return k == ACEHIP_HW_ADD || k == ACEHIP_HW_MUL || k == ACEHIP_HW_SUB || k == ACEHIP_HW_MULADD;
+}
+inline bool hw_uses_prime(u32 k) { return hw_has_b(k) || k == ACEHIP_HW_MULC || k == ACEHIP_HW_ADDC; }
 
 u32 uf_find(std::vector<u32>& p, u32 x) {
   while (p[x] != x) {
@@ -652,10 +655,12 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
   const u64 span = (u64)c->hp.N * 8;
   for (size_t k = 0; k < n; ++k) {
     const acehip_hw_op& o = ops[k];
-    if (o.op > ACEHIP_HW_ZERO) return fail(ACEHIP_EINVAL, "acehip_hw_batch: unknown op");
+    if (o.op > ACEHIP_HW_ADDC) return fail(ACEHIP_EINVAL, "acehip_hw_batch: unknown op");
     if (!o.res || (hw_has_a(o.op) && !o.a) || ((hw_has_b(o.op) || o.op == ACEHIP_HW_ROTATE) && !o.b))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: null operand");
-    if (hw_has_b(o.op) && o.prime_gi >= T) return fail(ACEHIP_EINVAL, "prime index out of range");
+    if (hw_uses_prime(o.op) && o.prime_gi >= T) return fail(ACEHIP_EINVAL, "prime index out of range");
+    if ((o.op == ACEHIP_HW_MULC || o.op == ACEHIP_HW_ADDC) && (u64)(uintptr_t)o.b >= c->hp.primes[o.prime_gi].q)
+      return fail(ACEHIP_EINVAL, "acehip_hw_batch: scalar operand is not a residue of the prime");
     if (o.op == ACEHIP_HW_ROTATE && limbs_overlap(o.res, o.a, span))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: in-place rotation is not supported");
   }

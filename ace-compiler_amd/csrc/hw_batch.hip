@@ -27,14 +27,33 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs 
       if (op.kind == HW_OP_COPY) {
         vr = va;
       } else {
-        const ulong2 vb = *reinterpret_cast<const ulong2*>(op.b + i);
         const DevPrime P = c.primes[op.gi];
-        if (op.kind == HW_OP_ADD) {
-          vr.x = add_mod(va.x, vb.x, P.q);
-          vr.y = add_mod(va.y, vb.y, P.q);
+        ulong2 vb;
+        if (op.kind == HW_OP_MULC || op.kind == HW_OP_ADDC) {  // the second operand is an immediate
+          vb.x = vb.y = (u64)(uintptr_t)op.b;
         } else {
-          vr.x = mul_mod(va.x, vb.x, P);
-          vr.y = mul_mod(va.y, vb.y, P);
+          vb = *reinterpret_cast<const ulong2*>(op.b + i);
+        }
+        switch (op.kind) {
+          case HW_OP_ADD:
+          case HW_OP_ADDC:
+            vr.x = add_mod(va.x, vb.x, P.q);
+            vr.y = add_mod(va.y, vb.y, P.q);
+            break;
+          case HW_OP_SUB:
+            vr.x = sub_mod(va.x, vb.x, P.q);
+            vr.y = sub_mod(va.y, vb.y, P.q);
+            break;
+          case HW_OP_MULADD: {
+            const ulong2 acc = *reinterpret_cast<const ulong2*>(op.res + i);
+            vr.x = add_mod(acc.x, mul_mod(va.x, vb.x, P), P.q);
+            vr.y = add_mod(acc.y, mul_mod(va.y, vb.y, P), P.q);
+            break;
+          }
+          default:  // HW_OP_MUL, HW_OP_MULC
+            vr.x = mul_mod(va.x, vb.x, P);
+            vr.y = mul_mod(va.y, vb.y, P);
+            break;
         }
       }
     }

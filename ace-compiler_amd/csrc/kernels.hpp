@@ -94,7 +94,10 @@ struct LimbConsts {
 // r[pos] = a[pos] * w[pos - pos0] mod prime(pos)   (Scalars_integer_multiply_poly polynomial.c:234-268)
 // hw_batch.hip: a list of per-limb ops in one launch (kernel argument block, < 4 KB)
 constexpr u32 HW_BATCH_MAX = 112;
-enum : u32 { HW_OP_ADD = 0, HW_OP_MUL = 1, HW_OP_ROTATE = 2, HW_OP_COPY = 3, HW_OP_ZERO = 4 };
+enum : u32 {
+  HW_OP_ADD = 0, HW_OP_MUL = 1, HW_OP_ROTATE = 2, HW_OP_COPY = 3, HW_OP_ZERO = 4,
+  HW_OP_SUB = 5, HW_OP_MULADD = 6, HW_OP_MULC = 7, HW_OP_ADDC = 8
+};
 struct HwBatchOp {
   u64* res;
   const u64* a;

@@ -444,14 +444,14 @@ void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool 
   if (add_first) {
     std::vector<u64> pm = p_mod_q(l);
     u64* psi = dalloc((size_t)l * c.N, false);
-    HIPCHK(acehip_mul_scalars(c.hip, psi, q_limbs(&in.c._c0_poly), pm.data(), l, 0, l, nullptr));
-    HIPCHK(acehip_modadd(c.hip, t0, t0, psi, l, 0, l, nullptr));
+    q_scalars(ACEHIP_HW_MULC, psi, q_limbs(&in.c._c0_poly), pm.data(), l, 0, l);
+    q_ew(ACEHIP_HW_ADD, t0, t0, psi, l, 0, l);
     dfree(psi);
   }
   ev::init(rot, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots);
   const uint32_t* perm = acehip_auto_order(c.hip, k);
-  HIPCHK(acehip_rotate(c.hip, q_limbs(&rot.c._c0_poly), t0, perm, l, 0, l + c.K, nullptr));
-  HIPCHK(acehip_rotate(c.hip, q_limbs(&rot.c._c1_poly), t1, perm, l, 0, l + c.K, nullptr));
+  q_rotate(q_limbs(&rot.c._c0_poly), t0, perm, l, 0, l + c.K);
+  q_rotate(q_limbs(&rot.c._c1_poly), t1, perm, l, 0, l + c.K);
 }
 
 // Switch_key_ext :462-490 with add_first: (P*c0, P*c1) on the q-limbs, zero p-limbs
@@ -460,8 +460,8 @@ void switch_key_ext(Ct& res, Ct& in) {
   const u32 l = in.level();
   ev::init(res, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots);  // zero-filled
   std::vector<u64> pm = p_mod_q(l);
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&res.c._c0_poly), q_limbs(&in.c._c0_poly), pm.data(), l, 0, l, nullptr));
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&res.c._c1_poly), q_limbs(&in.c._c1_poly), pm.data(), l, 0, l, nullptr));
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&res.c._c0_poly), q_limbs(&in.c._c0_poly), pm.data(), l, 0, l);
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&res.c._c1_poly), q_limbs(&in.c._c1_poly), pm.data(), l, 0, l);
 }
 
 // Mul_plaintext in the PQ basis with a plaintext encoded at a level >= the ciphertext's (Derive_plain)
@@ -515,7 +515,7 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
       if (giant + j != num_rot) mul_plain_ext(inner, fast_rot[j], conj_pre[step][giant + j], true);
     if (i == 0) {
       poly_copy(&first, &inner.c._c0_poly);
-      HIPCHK(acehip_memset(inner.c._c0_poly._data, 0, E * 8, nullptr));
+      fill_zero((u64*)inner.c._c0_poly._data, E);
       ev::copy(outer, inner);
     } else {
       const int32_t val = rot_out[step][i];
@@ -525,13 +525,13 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         HIPCHK(acehip_mod_down(c.hip, c1q, q_limbs(&inner.c._c1_poly), l, nullptr));
         const u32 k = ensure_rot_key(val);
         const uint32_t* perm = acehip_auto_order(c.hip, k);
-        HIPCHK(acehip_rotate(c.hip, q_limbs(&temp_poly), q_limbs(&inner.c._c0_poly), perm, l, 0, l + c.K, nullptr));
+        q_rotate(q_limbs(&temp_poly), q_limbs(&inner.c._c0_poly), perm, l, 0, l + c.K);
         poly_add_ext(&first, &first, &temp_poly);
         u64* idig = dalloc(nd * E, false);
         HIPCHK(acehip_modup_digits(c.hip, idig, c1q, l, nullptr));
         Ct red, tmp;
         ev::init(red, l, 0, inner.c._scaling_factor, inner.c._sf_degree, inner.c._slots);
-        HIPCHK(acehip_memcpy_d2d(q_limbs(&red.c._c1_poly), c1q, (size_t)l * c.N * 8, nullptr));
+        copy_limbs((u64*)q_limbs(&red.c._c1_poly), (const u64*)c1q, (size_t)l * c.N);
         fast_rotate_ext(tmp, red, val, idig, false);
         dfree(idig);
         dfree(c1q);

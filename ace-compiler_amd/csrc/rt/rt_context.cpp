@@ -71,14 +71,14 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) 
     u64* b = sk->data + ((size_t)j * 2 + 0) * poly_words;
     u64* a = sk->data + ((size_t)j * 2 + 1) * poly_words;
     HIPCHK(acehip_sample_uniform(c.hip, a, c.L, 0, T, c.rng(), nullptr));            // a_j (NTT domain)
-    HIPCHK(acehip_modmul(c.hip, b, a, old_key_ntt, c.L, 0, T, nullptr));            // a_j * old
+    q_ew(ACEHIP_HW_MUL, b, a, old_key_ntt, c.L, 0, T);            // a_j * old
     for (u32 i = 0; i < T; ++i) scal[i] = (i < c.L && i / c.alpha == j) ? p_mod(c.primes[i]) : 0;
-    HIPCHK(acehip_mul_scalars(c.hip, pm, new_key_ntt, scal.data(), c.L, 0, T, nullptr));  // P*new on digit j
+    q_scalars(ACEHIP_HW_MULC, pm, new_key_ntt, scal.data(), c.L, 0, T);  // P*new on digit j
     sample_triangle(tri);
     poly_from_small(&e, tri);
     poly_ntt(&e, false);
-    HIPCHK(acehip_modadd(c.hip, pm, pm, (u64*)e._data, c.L, 0, T, nullptr));        // e + P*new
-    HIPCHK(acehip_modsub(c.hip, b, pm, b, c.L, 0, T, nullptr));                     // b = e + P*new - a*old
+    q_ew(ACEHIP_HW_ADD, pm, pm, (u64*)e._data, c.L, 0, T);        // e + P*new
+    q_ew(ACEHIP_HW_SUB, b, pm, b, c.L, 0, T);                     // b = e + P*new - a*old
     auto set = [&](POLYNOMIAL& p, u64* d) {
       p._ring_degree = c.N;
       p._num_alloc_primes = T;
@@ -118,7 +118,7 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   u64* old_key = dalloc((size_t)T * c.N, false);
   const uint32_t* perm = acehip_auto_order(c.hip, (u32)inv);
   RT_ASSERT(perm, "automorphism table: %s", acehip_last_error());
-  HIPCHK(acehip_rotate(c.hip, old_key, c.sk_ntt, perm, c.L, 0, T, nullptr));
+  q_rotate(old_key, c.sk_ntt, perm, c.L, 0, T);
   SwitchKeyStore* k = make_switch_key(c.sk_ntt, old_key);
   dfree(old_key);
   c.auto_keys[auto_idx] = k;
@@ -157,12 +157,12 @@ void generate_keys() {
   sample_triangle(tri);
   poly_from_small(&e, tri);
   poly_ntt(&e, false);
-  HIPCHK(acehip_modmul(c.hip, c.pk0, c.pk1, c.sk_ntt, c.L, 0, c.L, nullptr));
-  HIPCHK(acehip_modsub(c.hip, c.pk0, (u64*)e._data, c.pk0, c.L, 0, c.L, nullptr));
+  q_ew(ACEHIP_HW_MUL, c.pk0, c.pk1, c.sk_ntt, c.L, 0, c.L);
+  q_ew(ACEHIP_HW_SUB, c.pk0, (u64*)e._data, c.pk0, c.L, 0, c.L);
   poly_free(&e);
   // relinearisation key (Generate_relin_key :204-216): new = s^2 (q-limbs; p-limbs stay 0), old = s
   u64* s2 = dalloc((size_t)T * N, true);
-  HIPCHK(acehip_modmul(c.hip, s2, c.sk_ntt, c.sk_ntt, c.L, 0, c.L, nullptr));
+  q_ew(ACEHIP_HW_MUL, s2, c.sk_ntt, c.sk_ntt, c.L, 0, c.L);
   SwitchKeyStore* rk = make_switch_key(s2, c.sk_ntt);
   dfree(s2);
   c.relin = *rk;
@@ -262,6 +262,10 @@ void Finalize_context() {
   delete g_ctx;
   g_ctx = nullptr;
 }
+
+// Extension for callers that touch Coeffs() memory themselves (acehip_* / HIP calls on the raw device
+// pointers): hands over everything the shim still holds back and waits for the device.
+void Acehip_rt_sync(void) { sync(); }
 
 // ---- key accessors (key_gen.h:28-75) ----
 uint32_t Auto_idx(int32_t rot_idx) { return ensure_rot_key(rot_idx); }

@@ -177,8 +177,8 @@ void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree) {
     for (u32 i = 0; i < level; ++i) consts[i] = mulmod(consts[i], approx[i], c.primes[i]);
   }
   // every coefficient of limb i equals consts[i] (a constant polynomial in the NTT domain)
-  HIPCHK(acehip_memset(q_limbs(&res->_poly), 0, (size_t)level * N * 8, nullptr));
-  HIPCHK(acehip_add_scalars(c.hip, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level, nullptr));
+  fill_zero((u64*)q_limbs(&res->_poly), (size_t)level * N);
+  q_scalars(ACEHIP_HW_ADDC, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level);
   res->_poly._is_ntt = true;
 }
 
@@ -320,11 +320,11 @@ void encrypt(CIPHERTEXT* res, PLAINTEXT* plain) {
   sample_triangle(tri); poly_from_small(&e2, tri); poly_ntt(&e2, false);
   u64* c0 = q_limbs(&res->_c0_poly);
   u64* c1 = q_limbs(&res->_c1_poly);
-  HIPCHK(acehip_modmul(c.hip, c0, c.pk0, q_limbs(&v), l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, c0, q_limbs(&e1), c0, l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, c0, c0, q_limbs(m), l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, c1, c.pk1, q_limbs(&v), l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, c1, q_limbs(&e2), c1, l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_MUL, c0, c.pk0, q_limbs(&v), l, 0, l);
+  q_ew(ACEHIP_HW_ADD, c0, q_limbs(&e1), c0, l, 0, l);
+  q_ew(ACEHIP_HW_ADD, c0, c0, q_limbs(m), l, 0, l);
+  q_ew(ACEHIP_HW_MUL, c1, c.pk1, q_limbs(&v), l, 0, l);
+  q_ew(ACEHIP_HW_ADD, c1, q_limbs(&e2), c1, l, 0, l);
   res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = true;
   poly_free(&v);
   poly_free(&e1);
@@ -338,8 +338,8 @@ void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph) {
   const u32 l = (u32)ciph->_c0_poly._num_primes;
   init_plaintext(res, ciph->_slots, l, ciph->_c0_poly._num_primes_p, ciph->_scaling_factor, ciph->_sf_degree);
   u64* r = q_limbs(&res->_poly);
-  HIPCHK(acehip_modmul(c.hip, r, q_limbs(&ciph->_c1_poly), c.sk_ntt, l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, r, q_limbs(&ciph->_c0_poly), r, l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_MUL, r, q_limbs(&ciph->_c1_poly), c.sk_ntt, l, 0, l);
+  q_ew(ACEHIP_HW_ADD, r, q_limbs(&ciph->_c0_poly), r, l, 0, l);
   res->_poly._is_ntt = true;
 }
 

@@ -49,8 +49,8 @@ void set_level(Ct& a, u32 level) {
   if (a.np() && level != a.level()) {
     // keep the "p-limbs follow the q-limbs" layout the kernels assume: compact the p part
     Context& c = ctx();
-    HIPCHK(acehip_memcpy_d2d(q_limbs(&a.c._c0_poly) + (size_t)level * c.N, p_limbs(&a.c._c0_poly), (size_t)a.np() * c.N * 8, nullptr));
-    HIPCHK(acehip_memcpy_d2d(q_limbs(&a.c._c1_poly) + (size_t)level * c.N, p_limbs(&a.c._c1_poly), (size_t)a.np() * c.N * 8, nullptr));
+    copy_limbs((u64*)q_limbs(&a.c._c0_poly) + (size_t)level * c.N, (const u64*)p_limbs(&a.c._c0_poly), (size_t)a.np() * c.N);
+    copy_limbs((u64*)q_limbs(&a.c._c1_poly) + (size_t)level * c.N, (const u64*)p_limbs(&a.c._c1_poly), (size_t)a.np() * c.N);
     a.c._c0_poly._num_alloc_primes = a.c._c1_poly._num_alloc_primes = level + a.np();
   }
   a.c._c0_poly._num_primes = a.c._c1_poly._num_primes = level;
@@ -120,7 +120,7 @@ void add_const(Ct& r, Ct& a, double v) {
   if (&r != &a) copy(r, a);
   const u32 l = r.level();
   std::vector<u64> k = const_residues(v, l, r.c._sf_degree);
-  HIPCHK(acehip_add_scalars(c.hip, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), k.data(), l, 0, l, nullptr));
+  q_scalars(ACEHIP_HW_ADDC, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), k.data(), l, 0, l);
 }
 
 void mul_const(Ct& r, Ct& a, double v) {
@@ -128,8 +128,8 @@ void mul_const(Ct& r, Ct& a, double v) {
   if (&r != &a) copy(r, a);
   const u32 l = r.level();
   std::vector<u64> k = const_residues(v, l, 1);
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), k.data(), l, 0, l, nullptr));
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), k.data(), l, 0, l, nullptr));
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), k.data(), l, 0, l);
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), k.data(), l, 0, l);
   r.c._scaling_factor = r.c._scaling_factor * c.sf;
   r.c._sf_degree += 1;
 }
@@ -146,13 +146,13 @@ void mul(Ct& r, Ct& a, Ct& b) {
   u64* k1 = dalloc((size_t)l * c.N, false);
   u64 *a0 = q_limbs(&a.c._c0_poly), *a1 = q_limbs(&a.c._c1_poly), *b0 = q_limbs(&b.c._c0_poly), *b1 = q_limbs(&b.c._c1_poly);
   u64 *o0 = q_limbs(&out.c._c0_poly), *o1 = q_limbs(&out.c._c1_poly);
-  HIPCHK(acehip_modmul(c.hip, o0, a0, b0, l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, o1, a0, b1, l, 0, l, nullptr));
-  HIPCHK(acehip_modmuladd(c.hip, o1, a1, b0, l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, c2, a1, b1, l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_MUL, o0, a0, b0, l, 0, l);
+  q_ew(ACEHIP_HW_MUL, o1, a0, b1, l, 0, l);
+  q_ew(ACEHIP_HW_MULADD, o1, a1, b0, l, 0, l);
+  q_ew(ACEHIP_HW_MUL, c2, a1, b1, l, 0, l);
   HIPCHK(acehip_key_switch(c.hip, k0, k1, c2, c.relin.data, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, o0, o0, k0, l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, o1, o1, k1, l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_ADD, o0, o0, k0, l, 0, l);
+  q_ew(ACEHIP_HW_ADD, o1, o1, k1, l, 0, l);
   dfree(c2);
   dfree(k0);
   dfree(k1);
@@ -177,12 +177,12 @@ void mul_integer(Ct& r, Ct& a, u64 k) {
   const u32 l = r.level();
   std::vector<u64> s(l + c.K);
   for (u32 i = 0; i < l; ++i) s[i] = k % c.primes[i];
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), s.data(), l, 0, l, nullptr));
-  HIPCHK(acehip_mul_scalars(c.hip, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), s.data(), l, 0, l, nullptr));
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), s.data(), l, 0, l);
+  q_scalars(ACEHIP_HW_MULC, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), s.data(), l, 0, l);
   if (r.np()) {
     for (u32 j = 0; j < c.K; ++j) s[j] = k % c.primes[c.L + j];
-    HIPCHK(acehip_mul_scalars(c.hip, p_limbs(&r.c._c0_poly), p_limbs(&r.c._c0_poly), s.data(), 0, 0, c.K, nullptr));
-    HIPCHK(acehip_mul_scalars(c.hip, p_limbs(&r.c._c1_poly), p_limbs(&r.c._c1_poly), s.data(), 0, 0, c.K, nullptr));
+    q_scalars(ACEHIP_HW_MULC, p_limbs(&r.c._c0_poly), p_limbs(&r.c._c0_poly), s.data(), 0, 0, c.K);
+    q_scalars(ACEHIP_HW_MULC, p_limbs(&r.c._c1_poly), p_limbs(&r.c._c1_poly), s.data(), 0, 0, c.K);
   }
 }
 
@@ -204,8 +204,8 @@ void mul_monomial(Ct& r, Ct& a, u32 power) {
   }
   if (&r != &a) copy(r, a);
   const u32 l = r.level();
-  HIPCHK(acehip_modmul(c.hip, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), mono, l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), mono, l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_MUL, q_limbs(&r.c._c0_poly), q_limbs(&r.c._c0_poly), mono, l, 0, l);
+  q_ew(ACEHIP_HW_MUL, q_limbs(&r.c._c1_poly), q_limbs(&r.c._c1_poly), mono, l, 0, l);
 }
 void clear_monomial_cache() { g_monomials.clear(); }
 
@@ -219,11 +219,11 @@ static void switch_and_permute(Ct& r, Ct& a, u32 auto_idx) {
   u64* k0 = dalloc((size_t)l * c.N, false);
   u64* k1 = dalloc((size_t)l * c.N, false);
   HIPCHK(acehip_key_switch(c.hip, k0, k1, q_limbs(&a.c._c1_poly), key->data, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, k0, k0, q_limbs(&a.c._c0_poly), l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_ADD, k0, k0, q_limbs(&a.c._c0_poly), l, 0, l);
   const uint32_t* perm = acehip_auto_order(c.hip, auto_idx);
   RT_ASSERT(perm, "automorphism table: %s", acehip_last_error());
-  HIPCHK(acehip_rotate(c.hip, q_limbs(&out.c._c0_poly), k0, perm, l, 0, l, nullptr));
-  HIPCHK(acehip_rotate(c.hip, q_limbs(&out.c._c1_poly), k1, perm, l, 0, l, nullptr));
+  q_rotate(q_limbs(&out.c._c0_poly), k0, perm, l, 0, l);
+  q_rotate(q_limbs(&out.c._c1_poly), k1, perm, l, 0, l);
   dfree(k0);
   dfree(k1);
   r.take(out);
@@ -282,10 +282,10 @@ CIPHER3 Mul_ciph3(CIPHER3 res, CIPHER a, CIPHER b) {
   Init_ciph3_up_scale(res, a, b);
   Context& c = ctx();
   const u32 l = (u32)res->_c0_poly._num_primes;
-  HIPCHK(acehip_modmul(c.hip, q_limbs(&res->_c0_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c0_poly), l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, q_limbs(&res->_c1_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c1_poly), l, 0, l, nullptr));
-  HIPCHK(acehip_modmuladd(c.hip, q_limbs(&res->_c1_poly), q_limbs(&a->_c1_poly), q_limbs(&b->_c0_poly), l, 0, l, nullptr));
-  HIPCHK(acehip_modmul(c.hip, q_limbs(&res->_c2_poly), q_limbs(&a->_c1_poly), q_limbs(&b->_c1_poly), l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_MUL, q_limbs(&res->_c0_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c0_poly), l, 0, l);
+  q_ew(ACEHIP_HW_MUL, q_limbs(&res->_c1_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c1_poly), l, 0, l);
+  q_ew(ACEHIP_HW_MULADD, q_limbs(&res->_c1_poly), q_limbs(&a->_c1_poly), q_limbs(&b->_c0_poly), l, 0, l);
+  q_ew(ACEHIP_HW_MUL, q_limbs(&res->_c2_poly), q_limbs(&a->_c1_poly), q_limbs(&b->_c1_poly), l, 0, l);
   return res;
 }
 // Relinearize_ciph3 :266-322 == generated Relinearize()
@@ -298,8 +298,8 @@ CIPHER Relin(CIPHER res, CIPHER3 ct3) {
   u64* k0 = dalloc((size_t)l * c.N, false);
   u64* k1 = dalloc((size_t)l * c.N, false);
   HIPCHK(acehip_key_switch(c.hip, k0, k1, q_limbs(&ct3->_c2_poly), c.relin.data, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, q_limbs(&out._c0_poly), k0, q_limbs(&ct3->_c0_poly), l, 0, l, nullptr));
-  HIPCHK(acehip_modadd(c.hip, q_limbs(&out._c1_poly), k1, q_limbs(&ct3->_c1_poly), l, 0, l, nullptr));
+  q_ew(ACEHIP_HW_ADD, q_limbs(&out._c0_poly), k0, q_limbs(&ct3->_c0_poly), l, 0, l);
+  q_ew(ACEHIP_HW_ADD, q_limbs(&out._c1_poly), k1, q_limbs(&ct3->_c1_poly), l, 0, l);
   dfree(k0);
   dfree(k1);
   Free_ciph_poly(res, 1);

@@ -108,6 +108,13 @@ void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transf
 void sync();
 // queue `n_limbs` consecutive limbs of a per-limb op (ACEHIP_HW_*) instead of launching it now
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs = 1);
+// queued multi-limb forms, argument meaning as acehip_modadd & co: limbs [pos0, pos0+n) of polynomials extended
+// at `level` (limb p < level is prime p, the others are p primes); scalars[i] belongs to limb pos0+i
+void q_ew(u32 op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n);
+void q_scalars(u32 op, u64* r, const u64* a, const u64* scalars, u32 level, u32 pos0, u32 n);
+void q_rotate(u64* r, const u64* a, const uint32_t* perm, u32 level, u32 pos0, u32 n);
+void fill_zero(u64* p, size_t words);                    // queued when whole limbs, else memset
+void copy_limbs(u64* dst, const u64* src, size_t words); // queued when whole disjoint limbs, else d2d copy
 double wall_s();
 
 // ---- sampling (random_sample.c) ----

@@ -43,13 +43,27 @@ void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_
                                  b ? (const void*)((const u64*)b + l * N) : nullptr});
   if (g_hwq.size() >= 8192) hw_flush();
 }
+static inline u32 limb_gi(u32 pos, u32 level) { return pos < level ? pos : ctx().L + (pos - level); }
+void q_ew(u32 op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n) {
+  const size_t N = ctx().N;
+  for (u32 p = pos0; p < pos0 + n; ++p) hw_queue(op, limb_gi(p, level), r + p * N, a + p * N, b + p * N);
+}
+void q_scalars(u32 op, u64* r, const u64* a, const u64* scalars, u32 level, u32 pos0, u32 n) {
+  const size_t N = ctx().N;
+  for (u32 i = 0; i < n; ++i)
+    hw_queue(op, limb_gi(pos0 + i, level), r + (pos0 + i) * N, a + (pos0 + i) * N, (const void*)(uintptr_t)scalars[i]);
+}
+void q_rotate(u64* r, const u64* a, const uint32_t* perm, u32 level, u32 pos0, u32 n) {
+  const size_t N = ctx().N;
+  for (u32 p = pos0; p < pos0 + n; ++p) hw_queue(ACEHIP_HW_ROTATE, limb_gi(p, level), r + p * N, a + p * N, perm);
+}
 // zero fill / copy of whole limbs through the queue (anything else goes the direct way)
-static void fill_zero(u64* p, size_t words) {
+void fill_zero(u64* p, size_t words) {
   const size_t N = ctx().N;
   if (words % N == 0) hw_queue(ACEHIP_HW_ZERO, 0, p, nullptr, nullptr, words / N);
   else HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
 }
-static void copy_limbs(u64* dst, const u64* src, size_t words) {
+void copy_limbs(u64* dst, const u64* src, size_t words) {
   const size_t N = ctx().N;
   if (dst == src) return;
   const size_t gap = dst < src ? src - dst : dst - src;
@@ -161,14 +175,11 @@ void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src) {
 }
 
 void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p) {
-  Context& c = ctx();
-  auto fn = op == Op::Add ? acehip_modadd : op == Op::Sub ? acehip_modsub : op == Op::Mul ? acehip_modmul : acehip_modmuladd;
+  const u32 kind = op == Op::Add ? ACEHIP_HW_ADD : op == Op::Sub ? ACEHIP_HW_SUB : op == Op::Mul ? ACEHIP_HW_MUL : ACEHIP_HW_MULADD;
   const u32 l = (u32)res->_num_primes;
-  if (l) HIPCHK(fn(c.hip, q_limbs(res), q_limbs(a), q_limbs(b), l, 0, l, nullptr));
-  if (with_p && res->_num_primes_p) {
-    // level 0: position j -> prime p_j
-    HIPCHK(fn(c.hip, p_limbs(res), p_limbs(a), p_limbs(b), 0, 0, (u32)res->_num_primes_p, nullptr));
-  }
+  if (l) q_ew(kind, q_limbs(res), q_limbs(a), q_limbs(b), l, 0, l);
+  // level 0: position j -> prime p_j
+  if (with_p && res->_num_primes_p) q_ew(kind, p_limbs(res), p_limbs(a), p_limbs(b), 0, 0, (u32)res->_num_primes_p);
 }
 
 void poly_ntt(POLYNOMIAL* p, bool inverse) {
@@ -185,8 +196,8 @@ void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx) {
   const uint32_t* perm = acehip_auto_order(c.hip, auto_idx);
   RT_ASSERT(perm != nullptr, "automorphism table: %s", acehip_last_error());
   const u32 l = (u32)a->_num_primes;
-  if (l) HIPCHK(acehip_rotate(c.hip, q_limbs(res), q_limbs(a), perm, l, 0, l, nullptr));
-  if (a->_num_primes_p) HIPCHK(acehip_rotate(c.hip, p_limbs(res), p_limbs(a), perm, 0, 0, (u32)a->_num_primes_p, nullptr));
+  if (l) q_rotate(q_limbs(res), q_limbs(a), perm, l, 0, l);
+  if (a->_num_primes_p) q_rotate(p_limbs(res), p_limbs(a), perm, 0, 0, (u32)a->_num_primes_p);
   res->_is_ntt = a->_is_ntt;
 }
 
@@ -251,7 +262,7 @@ int64_t* Hw_modmul(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t de
 int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, uint32_t degree) {
   if (res == a) {  // the reference loop would read overwritten data too; keep it well defined
     u64* tmp = dalloc(degree, false);
-    HIPCHK(acehip_memcpy_d2d(tmp, a, (size_t)degree * 8, nullptr));
+    copy_limbs((u64*)tmp, (const u64*)a, (size_t)degree);
     HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, tmp, (const uint32_t*)rot_precomp, m->_gi, nullptr));
     dfree(tmp);
   } else {
@@ -274,9 +285,7 @@ POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
     res->_num_primes = n2;
     res->_num_primes_p = 0;
   }
-  hw_flush();
-  int rc = acehip_decomp(c.hip, q_limbs(res), q_limbs(poly), level, q_part_idx, nullptr);
-  HIPCHK(rc);
+  copy_limbs(q_limbs(res), q_limbs(poly) + (size_t)start * c.N, (size_t)n2 * c.N);  // = acehip_decomp, queued
   res->_is_ntt = poly->_is_ntt;
   return res;
 }
@@ -317,7 +326,7 @@ POLY Rescale(POLY res, POLY poly) {
   if (res == poly || res->_data == poly->_data) {
     u64* tmp = dalloc((size_t)(level - 1) * c.N, false);
     HIPCHK(acehip_rescale(c.hip, tmp, q_limbs(poly), level, nullptr));
-    HIPCHK(acehip_memcpy_d2d(q_limbs(res), tmp, (size_t)(level - 1) * c.N * 8, nullptr));
+    copy_limbs((u64*)q_limbs(res), (const u64*)tmp, (size_t)(level - 1) * c.N);
     dfree(tmp);
   } else {
     HIPCHK(acehip_rescale(c.hip, q_limbs(res), q_limbs(poly), level, nullptr));

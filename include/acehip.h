@@ -124,15 +124,20 @@ int acehip_hw_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, cons
  * produces -- partially overlapping limbs are still handled, op by op).  The library groups the ops into
  * dependency chains and runs them in a few launches instead of n: generated code calls Hw_* once per RNS limb
  * and component, ~600k times per ResNet-20 image.
- *   ADD/MUL: res = a (+|*) b mod prime(prime_gi);  ROTATE: res[j] = a[perm[j]], b = table of
+ *   ADD/SUB/MUL: res = a (+|-|*) b mod prime(prime_gi);  MULADD: res += a*b (Multiply_add polynomial.c:148);
+ *   MULC/ADDC: res = a (*|+) k with the residue k < prime passed as an integer in `b`
+ *   (Scalar_integer_multiply_poly polynomial.c:190);  ROTATE: res[j] = a[perm[j]], b = table of
  *   acehip_auto_order(), res must not alias a;  COPY: res = a;  ZERO: res = 0. */
-enum { ACEHIP_HW_ADD = 0, ACEHIP_HW_MUL = 1, ACEHIP_HW_ROTATE = 2, ACEHIP_HW_COPY = 3, ACEHIP_HW_ZERO = 4 };
+enum {
+  ACEHIP_HW_ADD = 0, ACEHIP_HW_MUL = 1, ACEHIP_HW_ROTATE = 2, ACEHIP_HW_COPY = 3, ACEHIP_HW_ZERO = 4,
+  ACEHIP_HW_SUB = 5, ACEHIP_HW_MULADD = 6, ACEHIP_HW_MULC = 7, ACEHIP_HW_ADDC = 8
+};
 typedef struct acehip_hw_op {
   uint32_t        op;        /* ACEHIP_HW_* */
   uint32_t        prime_gi;  /* ADD/MUL: global prime index (q: 0..L-1, p: L..L+K-1) */
   uint64_t*       res;
   const uint64_t* a;
-  const void*     b;         /* second operand (uint64 limb), or the uint32 automorphism table for ROTATE */
+  const void*     b;         /* second operand (uint64 limb); uint32 automorphism table (ROTATE); residue (MULC/ADDC) */
 } acehip_hw_op;
 int acehip_hw_batch(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, acehip_stream stream);
 

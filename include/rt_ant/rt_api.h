@@ -7,6 +7,10 @@ extern "C" {
 #endif
 CIPHERTEXT Get_input_data(const char* name, size_t idx);
 void       Set_output_data(const char* name, size_t idx, CIPHER data);
+/* Extension (not in the reference): Coeffs() pointers are HBM addresses and per-limb Hw_* calls are executed
+ * lazily in batches.  Code that touches that memory itself (HIP / acehip_* calls on the raw pointers) calls
+ * this first: it submits everything still queued and waits for the device. */
+void       Acehip_rt_sync(void);
 #ifdef __cplusplus
 }
 #endif

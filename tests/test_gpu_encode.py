@@ -46,6 +46,7 @@ def stub(tmp_path_factory):
 
 
 def _download(lib, pt, N):
+    lib.Acehip_rt_sync()  # the shim batches per-limb work lazily; raw reads of Coeffs() memory sync first
     level = lib.Stub_plain_level(pt)
     out = np.empty((level, N), dtype=np.uint64)
     assert lib.acehip_memcpy_d2h(out.ctypes.data, lib.Stub_plain_data(pt), out.nbytes, None) == 0

@@ -46,6 +46,16 @@ def _apply_host(o, B, arena, prog, perms):
             res = o.hw_modadd(limb(a).reshape(1, N).copy(), limb(b).reshape(1, N).copy(), [gi])[0]
         elif op == B.HW_MUL:
             res = o.hw_modmul(limb(a).reshape(1, N).copy(), limb(b).reshape(1, N).copy(), [gi])[0]
+        elif op == B.HW_SUB:
+            neg = (np.uint64(o.primes[gi]) - limb(b)) % np.uint64(o.primes[gi])
+            res = o.hw_modadd(limb(a).reshape(1, N).copy(), neg.reshape(1, N).copy(), [gi])[0]
+        elif op == B.HW_MULADD:
+            t = o.hw_modmul(limb(a).reshape(1, N).copy(), limb(b).reshape(1, N).copy(), [gi])
+            res = o.hw_modadd(limb(r).reshape(1, N).copy(), t, [gi])[0]
+        elif op in (B.HW_MULC, B.HW_ADDC):
+            k = np.full((1, N), b, dtype=np.uint64)   # b carries the residue itself
+            fn = o.hw_modmul if op == B.HW_MULC else o.hw_modadd
+            res = fn(limb(a).reshape(1, N).copy(), k, [gi])[0]
         elif op == B.HW_ROTATE:
             res = limb(a)[perms[b]].copy()
         elif op == B.HW_COPY:
@@ -59,7 +69,14 @@ def _run_device(rt, B, arena, prog, perm_bufs):
     d = rt.to_device(arena)
     ops = []
     for op, gi, r, a, b in prog:
-        bp = perm_bufs[b].ptr if op == B.HW_ROTATE else (d.at(b) if op in (B.HW_ADD, B.HW_MUL) else None)
+        if op == B.HW_ROTATE:
+            bp = perm_bufs[b].ptr
+        elif op in (B.HW_MULC, B.HW_ADDC):
+            bp = b                      # immediate residue
+        elif op in (B.HW_ADD, B.HW_MUL, B.HW_SUB, B.HW_MULADD):
+            bp = d.at(b)
+        else:
+            bp = None
         ops.append((op, gi, d.at(r), d.at(a) if op != B.HW_ZERO else None, bp))
     rt.hw_batch(ops)
     out = d.download(arena.shape)
@@ -77,7 +94,10 @@ def _random_program(o, B, rows, n_ops, seed, rot_keys):
             for _ in range(int(rng.integers(1, 40))):
                 gi = int(rng.integers(0, T))
                 r, a, b = (int((gi + T * rng.integers(0, rows)) * N) for _ in range(3))
-                op = int(rng.choice([B.HW_ADD, B.HW_ADD, B.HW_MUL, B.HW_MUL, B.HW_COPY, B.HW_ZERO]))
+                op = int(rng.choice([B.HW_ADD, B.HW_ADD, B.HW_MUL, B.HW_MUL, B.HW_COPY, B.HW_ZERO, B.HW_SUB, B.HW_MULADD,
+                                     B.HW_MULADD, B.HW_MULC, B.HW_ADDC]))
+                if op in (B.HW_MULC, B.HW_ADDC):
+                    b = int(rng.integers(0, o.primes[gi]))
                 prog.append((op, gi, r, a, b))
         else:
             k = int(rng.choice(rot_keys))
@@ -175,6 +195,8 @@ def test_bad_arguments_fail_loudly(env):
         rt.hw_batch([(B.HW_ROTATE, 0, d.at(0), d.at(0), d.at(N))])
     with pytest.raises(A.AceHipError, match="prime index"):
         rt.hw_batch([(B.HW_ADD, 99, d.at(0), d.at(0), d.at(N))])
+    with pytest.raises(A.AceHipError, match="not a residue"):
+        rt.hw_batch([(B.HW_MULC, 0, d.at(0), d.at(0), rt.primes[0])])
     with pytest.raises(A.AceHipError, match="null operand"):
         rt.hw_batch([(B.HW_MUL, 0, d.at(0), d.at(0), None)])
     d.free()
