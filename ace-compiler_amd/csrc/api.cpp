@@ -74,6 +74,8 @@ struct acehip_ctx {
   u64* ws = nullptr;
   size_t ws_words = 0;
   // encode (embed.hip): twiddles cos/sin(2 pi j / 2N) from the host libm, 5^i mod 2N, scratch, sticky overflow flag
+  u64* hw_scratch = nullptr;       // acehip_hw_batch: private limbs for renamed intermediate versions
+  size_t hw_scratch_limbs = 0;
   cd* emb_rou = nullptr;
   u32* emb_rot = nullptr;
   cd* emb_work = nullptr;
@@ -173,6 +175,7 @@ void acehip_ctx_destroy(acehip_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   for (void* p : ctx->owned) (void)hipFree(p);
+  if (ctx->hw_scratch) (void)hipFree(ctx->hw_scratch);
   delete ctx;
 }
 
@@ -337,6 +340,17 @@ int acehip_event_destroy(void* e) {
 }  // extern "C"
 
 // ---- argument checks shared by the launch entry points ----
+// ---- call statistics: algorithmic bytes of SURVEY 8(d) per entry point (tables and scratch excluded) ----
+enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_COUNT };
+static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
+                                                "mod_down", "rescale", "key_switch", "encode"};
+static acehip_stat g_stat[ST_COUNT];
+static inline void stat(int k, u64 units, u64 bytes) {
+  g_stat[k].calls++;
+  g_stat[k].units += units;
+  g_stat[k].bytes += bytes;
+}
+
 static int check_dev(acehip_ctx* c) {
   if (!c) return fail(ACEHIP_EINVAL, "null context");
   if (!c->on_device) return fail(ACEHIP_ENODEV, "context was created without a GPU; the HIP path has no CPU fallback");
@@ -419,11 +433,13 @@ extern "C" {
 int acehip_ntt_forward(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
   launch_ntt(c->dc, d, level, pos0, n, false, (hipStream_t)s);
+  stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
 int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
   launch_ntt(c->dc, d, level, pos0, n, true, (hipStream_t)s);
+  stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
 
@@ -433,10 +449,12 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
   if (n_polys == 0) return ACEHIP_OK;
   if (n_polys > 65535) return fail(ACEHIP_EINVAL, "acehip_ntt_batch: at most 65535 polynomials per launch");
   launch_ntt(c->dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+  stat(ST_NTT, (u64)n * n_polys, 16ull * c->hp.N * n * n_polys);
   return post_launch();
 }
 
 static int ew(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n, acehip_stream s) {
+  if (c) stat(ST_EW, n, (op == EwOp::MulAdd ? 32ull : 24ull) * c->hp.N * n);
   if (int e = check_range(c, level, pos0, n)) return e;
   launch_ew(c->dc, op, r, a, b, level, pos0, n, (hipStream_t)s);
   return post_launch();
@@ -481,8 +499,9 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
     u32 node;
   };
   std::vector<Slot> table;
-  std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b;
-  std::vector<char> written;
+  std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b, cur, last_pure;
+  std::vector<u64> node_ptr;  // address of every node (limb)
+  std::vector<char> written, dead, state;
 };
 thread_local HwScratch g_hw;
 
@@ -520,7 +539,7 @@ u32 hw_node(HwScratch& h, u64 ptr, u64 span, u64 mask) {
   if (found != UINT32_MAX) return found;
   const u32 node = (u32)h.parent.size();
   h.parent.push_back(node);
-  h.written.push_back(0);
+  h.node_ptr.push_back(ptr);
   for (u64 i = ((b + 1) * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
     HwScratch::Slot& sl = h.table[i & mask];
     if (sl.key == 0) {
@@ -540,7 +559,31 @@ void hw_issue_one(acehip_ctx* c, const acehip_hw_op& o, hipStream_t st) {
   else launch_hw_batch_ew(c->dc, args, 1, st);
 }
 
-// elementwise run ops[0, m): chains = connected components over limbs that some op of the run writes
+// scratch limbs for renamed intermediate versions (see hw_run_ew); grown on demand, owned by the context
+static u64* hw_scratch(acehip_ctx* c, size_t limbs) {
+  if (limbs <= c->hw_scratch_limbs) return c->hw_scratch;
+  size_t want = std::max<size_t>(256, c->hw_scratch_limbs);
+  while (want < limbs) want *= 2;
+  (void)hipDeviceSynchronize();  // launches that still use the old arena
+  if (c->hw_scratch) (void)hipFree(c->hw_scratch);
+  c->hw_scratch = nullptr;
+  c->hw_scratch_limbs = 0;
+  void* p = nullptr;
+  if (hipMalloc(&p, want * c->hp.N * sizeof(u64)) != hipSuccess) return nullptr;
+  c->hw_scratch = (u64*)p;
+  c->hw_scratch_limbs = want;
+  return c->hw_scratch;
+}
+constexpr size_t kHwScratchMaxLimbs = 2048;
+
+// Elementwise run ops[0, m).  The list is executed as if one by one, but:
+//  * a zero fill / copy whose limb is completely rewritten later in the list before anything reads it is dropped
+//    (Alloc_poly and Init_ciph_* zero-fill every result that the next Hw_* loop overwrites);
+//  * a limb that is purely overwritten several times (generated code funnels every limb of a key inner product
+//    through ONE scratch limb: resnet20_cifar10_pre.onnx.inc:7011-7036) gets a private scratch limb for each
+//    version but the last, which removes the false write-after-read / write-after-write dependencies;
+//  * ops are then grouped into chains = connected components over limbs that some op writes, program order
+//    kept inside a chain, and each chain segment runs in one blockIdx.y of hw_batch_ew_kernel.
 void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st) {
   HwScratch& h = g_hw;
   const u64 span = (u64)c->hp.N * 8;
@@ -550,39 +593,103 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
   std::memset(h.table.data(), 0, cap * sizeof(HwScratch::Slot));
   const u64 mask = cap - 1;
   h.parent.clear();
-  h.written.clear();
+  h.node_ptr.clear();
   h.n_res.resize(m);
   h.n_a.resize(m);
   h.n_b.resize(m);
-  bool reorder_ok = true;
-  for (size_t k = 0; k < m && reorder_ok; ++k) {
+  for (size_t k = 0; k < m; ++k) {
     const acehip_hw_op& o = ops[k];
     const u32 nr = hw_node(h, (u64)o.res, span, mask);
     const u32 na = hw_has_a(o.op) ? hw_node(h, (u64)o.a, span, mask) : 0;
     const u32 nb = hw_has_b(o.op) ? hw_node(h, (u64)o.b, span, mask) : 0;
     if (nr == UINT32_MAX || na == UINT32_MAX || nb == UINT32_MAX) {
-      reorder_ok = false;
-      break;
+      // partially overlapping limbs: keep the caller's order, one launch per op
+      for (size_t j = 0; j < m; ++j) hw_issue_one(c, ops[j], st);
+      return;
     }
     h.n_res[k] = nr;
     h.n_a[k] = na;
     h.n_b[k] = nb;
-    h.written[nr] = 1;
   }
-  if (!reorder_ok) {  // partially overlapping limbs: keep the caller's order, one launch per op
-    for (size_t k = 0; k < m; ++k) hw_issue_one(c, ops[k], st);
-    return;
+  const u32 n_base = (u32)h.parent.size();
+  auto pure_overwrite = [&](size_t k) {  // writes its result limb without reading it
+    const u32 op = ops[k].op, nr = h.n_res[k];
+    return op != ACEHIP_HW_MULADD && !(hw_has_a(op) && h.n_a[k] == nr) && !(hw_has_b(op) && h.n_b[k] == nr);
+  };
+  // backwards: dead stores, and the last pure overwrite of every limb (the version that stays in place)
+  h.dead.assign(m, 0);
+  h.state.assign(n_base, 0);  // 1 = overwritten by a later op with no read in between
+  h.last_pure.assign(n_base, UINT32_MAX);
+  size_t live = m;
+  bool rename_useful = false;
+  for (size_t k = m; k-- > 0;) {
+    const u32 op = ops[k].op, nr = h.n_res[k];
+    if ((op == ACEHIP_HW_ZERO || op == ACEHIP_HW_COPY) && h.state[nr]) {
+      h.dead[k] = 1;
+      --live;
+      continue;
+    }
+    const bool pure = pure_overwrite(k);
+    if (pure) {
+      if (h.last_pure[nr] == UINT32_MAX) h.last_pure[nr] = (u32)k;
+      else rename_useful = true;
+    }
+    h.state[nr] = pure;
+    if (hw_has_a(op)) h.state[h.n_a[k]] = 0;
+    if (hw_has_b(op)) h.state[h.n_b[k]] = 0;
   }
+  if (live == 0) return;
+  // forwards: give intermediate versions private scratch limbs
+  size_t n_scratch = 0;
+  if (rename_useful) {
+    h.cur.resize(n_base);
+    for (u32 i = 0; i < n_base; ++i) h.cur[i] = i;
+    h.state.assign(n_base, 0);  // reused: 1 = the limb was touched earlier in the list
+    for (size_t k = 0; k < m; ++k) {
+      if (h.dead[k]) continue;
+      const u32 op = ops[k].op, nr0 = h.n_res[k];
+      const bool pure = pure_overwrite(k);
+      const u32 na = hw_has_a(op) ? h.cur[h.n_a[k]] : 0, nb = hw_has_b(op) ? h.cur[h.n_b[k]] : 0;
+      if (hw_has_a(op)) h.state[h.n_a[k]] = 1;
+      if (hw_has_b(op)) h.state[h.n_b[k]] = 1;
+      if (pure) {
+        if (h.last_pure[nr0] != k && h.state[nr0] && n_scratch < kHwScratchMaxLimbs) {
+          h.cur[nr0] = (u32)h.parent.size();
+          h.parent.push_back(h.cur[nr0]);
+          h.node_ptr.push_back(n_scratch++);  // index into the scratch arena, resolved below
+        } else {
+          h.cur[nr0] = nr0;
+        }
+      }
+      h.state[nr0] = 1;
+      h.n_res[k] = h.cur[nr0];
+      h.n_a[k] = na;
+      h.n_b[k] = nb;
+    }
+    if (n_scratch) {
+      u64* base = hw_scratch(c, n_scratch);
+      if (!base) {  // no memory for the arena: run the list in order instead
+        for (size_t j = 0; j < m; ++j) hw_issue_one(c, ops[j], st);
+        return;
+      }
+      for (size_t i = n_base; i < h.node_ptr.size(); ++i) h.node_ptr[i] = (u64)base + h.node_ptr[i] * span;
+    }
+  }
+  const u32 n_nodes = (u32)h.parent.size();
+  h.written.assign(n_nodes, 0);
+  for (size_t k = 0; k < m; ++k)
+    if (!h.dead[k]) h.written[h.n_res[k]] = 1;
   for (size_t k = 0; k < m; ++k) {
+    if (h.dead[k]) continue;
     const u32 r = uf_find(h.parent, h.n_res[k]);
     if (hw_has_a(ops[k].op) && h.written[h.n_a[k]]) h.parent[uf_find(h.parent, h.n_a[k])] = r;
     if (hw_has_b(ops[k].op) && h.written[h.n_b[k]]) h.parent[uf_find(h.parent, h.n_b[k])] = uf_find(h.parent, r);
   }
   // chains numbered by first appearance; ops of a chain keep their program order
-  const u32 n_nodes = (u32)h.parent.size();
   h.comp_of_node.assign(n_nodes, UINT32_MAX);
   h.cnt.clear();
   for (size_t k = 0; k < m; ++k) {
+    if (h.dead[k]) continue;
     const u32 root = uf_find(h.parent, h.n_res[k]);
     if (h.comp_of_node[root] == UINT32_MAX) {
       h.comp_of_node[root] = (u32)h.cnt.size();
@@ -596,13 +703,14 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     x = run;
     run += t;
   }
-  h.ord.resize(m);
-  for (size_t k = 0; k < m; ++k) h.ord[h.cnt[h.comp_of_node[uf_find(h.parent, h.n_res[k])]]++] = (u32)k;
+  h.ord.resize(live);
+  for (size_t k = 0; k < m; ++k)
+    if (!h.dead[k]) h.ord[h.cnt[h.comp_of_node[uf_find(h.parent, h.n_res[k])]]++] = (u32)k;
   // after the scatter cnt[j] = end offset of chain j
   HwBatchArgs args;
   u32 n_ops = 0, n_seg = 0, chain = 0, prev_chain = UINT32_MAX;
   args.seg_start[0] = 0;
-  for (size_t t = 0; t < m; ++t) {
+  for (size_t t = 0; t < live; ++t) {
     while (t >= h.cnt[chain]) ++chain;
     if (n_ops == HW_BATCH_MAX) {  // a chain cut here continues in the next launch, which is ordered after this one
       args.seg_start[++n_seg] = (uint16_t)n_ops;
@@ -613,8 +721,10 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     }
     if (n_ops && chain != prev_chain) args.seg_start[++n_seg] = (uint16_t)n_ops;
     prev_chain = chain;
-    const acehip_hw_op& o = ops[h.ord[t]];
-    args.op[n_ops++] = HwBatchOp{o.res, o.a, (const u64*)o.b, o.op, o.prime_gi};
+    const u32 k = h.ord[t];
+    const acehip_hw_op& o = ops[k];
+    args.op[n_ops++] = HwBatchOp{(u64*)h.node_ptr[h.n_res[k]], hw_has_a(o.op) ? (const u64*)h.node_ptr[h.n_a[k]] : nullptr,
+                                 hw_has_b(o.op) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b, o.op, o.prime_gi};
   }
   args.seg_start[++n_seg] = (uint16_t)n_ops;
   launch_hw_batch_ew(c->dc, args, n_seg, st);
@@ -653,9 +763,14 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
   if (!ops) return fail(ACEHIP_EINVAL, "acehip_hw_batch: null op list");
   const u32 T = c->hp.L + c->hp.K;
   const u64 span = (u64)c->hp.N * 8;
+  // limbs moved per op (24N per add/mul, 16N per rotate; copy 16N, zero 8N, muladd 32N, scalar forms 16N)
+  static const u64 kHwWords[9] = {3, 3, 2, 2, 1, 3, 4, 2, 2};
+  u64 alg_words = 0, n_rot = 0;
   for (size_t k = 0; k < n; ++k) {
     const acehip_hw_op& o = ops[k];
     if (o.op > ACEHIP_HW_ADDC) return fail(ACEHIP_EINVAL, "acehip_hw_batch: unknown op");
+    alg_words += kHwWords[o.op];
+    n_rot += o.op == ACEHIP_HW_ROTATE;
     if (!o.res || (hw_has_a(o.op) && !o.a) || ((hw_has_b(o.op) || o.op == ACEHIP_HW_ROTATE) && !o.b))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: null operand");
     if (hw_uses_prime(o.op) && o.prime_gi >= T) return fail(ACEHIP_EINVAL, "prime index out of range");
@@ -675,6 +790,11 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
     else hw_run_ew(c, ops + i, j - i, st);
     i = j;
   }
+  stat(ST_EW, n - n_rot, (alg_words - 2 * n_rot) * span);
+  if (n_rot) {
+    stat(ST_ROTATE, n_rot, 2 * n_rot * span);
+    g_stat[ST_ROTATE].calls--;  // one entry point call, counted under elementwise
+  }
   return post_launch();
 }
 
@@ -682,6 +802,7 @@ int acehip_decomp_modup(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp_modup: bad level/digit");
   (void)hipSetDevice(c->device);
+  stat(ST_MODUP, 1, 8ull * c->hp.N * (std::min(c->hp.alpha, level - c->hp.alpha * digit) + level + c->hp.K));
   return do_decomp_modup(c, out, in, level, digit, ws_at(c, 0), (hipStream_t)s);
 }
 
@@ -689,6 +810,7 @@ int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t l
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down: bad level");
   if (out == in) return fail(ACEHIP_EINVAL, "acehip_mod_down: out must not alias in");
+  stat(ST_MODDOWN, 1, 8ull * c->hp.N * (2 * level + c->hp.K));
   return do_mod_down(c, out, in, level, ws_at(c, 0), (hipStream_t)s);
 }
 
@@ -706,6 +828,7 @@ int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t le
   launch_rescale_spread(c->dc, t, last, c->qlql + row, c->qlql_prec + row, level, s);
   launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s);
   launch_rescale_tail(c->dc, out, in, t, c->ql_inv + row, c->ql_inv_prec + row, level, s);
+  stat(ST_RESCALE, 1, 8ull * N * (2 * level - 1));
   return post_launch();
 }
 
@@ -785,6 +908,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s);
   launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
   launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
+  stat(ST_KEYSWITCH, 1, acehip_key_switch_bytes(c, level));
   return post_launch();
 }
 
@@ -867,6 +991,7 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
   }
   launch_ntt(c->dc, d_q, level, 0, level, false, st);
   if (n_p) launch_ntt(c->dc, d_p, 0, 0, n_p, false, st);
+  stat(ST_ENCODE, 1, 8ull * N * (level + n_p) + len * (kind == 0 ? 4 : kind == 1 ? 8 : 16));
   return post_launch();
 }
 
@@ -926,6 +1051,7 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
     const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
     HIP_TRY(hipMemcpyAsync(ext + d * E + (size_t)start * N, in + (size_t)start * N, (size_t)n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
   }
+  stat(ST_MODUP, nd, 8ull * N * (level + (u64)nd * (level + hp.K)));
   return post_launch();
 }
 // Fast_switch_key_ext (ckks_evaluator.c:418-460): acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K limbs, no ModDown
@@ -934,8 +1060,16 @@ int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, cons
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_inner_product: bad level");
   const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
   launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s);
+  stat(ST_KEYMAC, 1, 8ull * E * (3ull * c->hp.num_decomp(level) + 2));
   return post_launch();
 }
+
+int acehip_stats(acehip_stat* out, int n, int reset) {
+  for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = g_stat[i];
+  if (reset) std::memset(g_stat, 0, sizeof(g_stat));
+  return ST_COUNT;
+}
+const char* acehip_stat_name(int i) { return i >= 0 && i < ST_COUNT ? kStatName[i] : nullptr; }
 
 uint64_t acehip_key_switch_bytes(const acehip_ctx* c, uint32_t level) {
   const HostParams& hp = c->hp;

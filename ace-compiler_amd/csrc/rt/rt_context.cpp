@@ -251,7 +251,19 @@ void Finalize_context() {
          (long)rot_cnt, (long)rot_bytes, (long)total);
   printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)c.weight_plain_cnt,
          (long)c.weight_plain_bytes);
-  if (c.profile) printf("[ACEHIP] host seconds: encode (launch side) %.3f, Main_graph %.3f\n", c.t_encode, c.t_main);
+  if (c.profile) {
+    printf("[ACEHIP] host seconds: encode (launch side) %.3f, Main_graph %.3f\n", c.t_encode, c.t_main);
+    hw_stats_print();
+    acehip_stat st[16];
+    const int nf = acehip_stats(st, 16, 0);
+    unsigned long long total = 0;
+    for (int i = 0; i < nf && i < 16; ++i) {
+      printf("[ACEHIP] %-18s calls %9llu units %10llu algorithmic GB %10.3f\n", acehip_stat_name(i),
+             (unsigned long long)st[i].calls, (unsigned long long)st[i].units, st[i].bytes / 1e9);
+      total += st[i].bytes;
+    }
+    printf("[ACEHIP] algorithmic bytes since process start: %.3f GB\n", total / 1e9);
+  }
   for (auto& kv : c.auto_keys) free_switch_key(kv.second);
   c.auto_keys.clear();
   bootstrap_release();

@@ -107,6 +107,7 @@ void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx);        // Rotate
 void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transform_values_at_level(without_mod)
 void sync();
 // queue `n_limbs` consecutive limbs of a per-limb op (ACEHIP_HW_*) instead of launching it now
+void hw_stats_print();
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs = 1);
 // queued multi-limb forms, argument meaning as acehip_modadd & co: limbs [pos0, pos0+n) of polynomials extended
 // at `level` (limb p < level is prime p, the others are p primes); scalars[i] belongs to limb pos0+i

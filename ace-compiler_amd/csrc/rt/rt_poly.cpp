@@ -29,9 +29,31 @@ static size_t pool_live_bytes = 0;
 // that sit between such loops ride in the same queue.  Single-threaded like the reference runtime.
 namespace {
 std::vector<acehip_hw_op> g_hwq;
+struct HwqStats {
+  size_t flushes = 0, ops = 0, by_kind[9] = {}, hist[8] = {};  // hist: <=1, <=4, <=16, <=64, <=256, <=1024, <=4096, more
+} g_hwq_stats;
+}
+void hw_stats_print() {
+  const HwqStats& s = g_hwq_stats;
+  printf("[ACEHIP] hw queue: %zu flushes, %zu limb-ops (add %zu mul %zu rot %zu copy %zu zero %zu sub %zu muladd %zu mulc %zu addc %zu); "
+         "ops per flush <=1:%zu <=4:%zu <=16:%zu <=64:%zu <=256:%zu <=1024:%zu <=4096:%zu more:%zu\n",
+         s.flushes, s.ops, s.by_kind[0], s.by_kind[1], s.by_kind[2], s.by_kind[3], s.by_kind[4], s.by_kind[5], s.by_kind[6],
+         s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
 }
 void hw_flush() {
   if (g_hwq.empty()) return;
+  if (ctx().profile) {
+    HwqStats& st = g_hwq_stats;
+    st.flushes++;
+    st.ops += g_hwq.size();
+    for (const auto& o : g_hwq) st.by_kind[o.op]++;
+    size_t b = 0, lim = 1;
+    while (b < 7 && g_hwq.size() > lim) {
+      ++b;
+      lim *= 4;
+    }
+    st.hist[b]++;
+  }
   const int rc = acehip_hw_batch(ctx().hip, g_hwq.data(), g_hwq.size(), nullptr);
   g_hwq.clear();
   RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());

@@ -157,6 +157,17 @@ int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint3
 int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in,
                       const uint64_t* d_key, uint32_t level, acehip_stream stream);
 
+/* ---- call statistics (process-wide): per entry-point family, the number of calls, the units processed (limbs,
+ * digits, key-switches ...) and the ALGORITHMIC bytes of SURVEY 8(d) (tables, scratch and re-reads excluded).
+ * bench.py divides the per-image sum by the wall time for the whole-workload roofline.  Returns the number of
+ * families; acehip_stat_name(i) names family i ("ntt", "elementwise", "rotate", "decomp_modup",
+ * "key_inner_product", "mod_down", "rescale", "key_switch", "encode"). */
+typedef struct acehip_stat {
+  uint64_t calls, units, bytes;
+} acehip_stat;
+int         acehip_stats(acehip_stat* out, int n_out, int reset);
+const char* acehip_stat_name(int family);
+
 /* ---- setup-side entry points (key generation, encryption, encoding: SURVEY 8 rows a15-a18) ----
  * d_poly[pos][n] = d_vals[n] mod prime(pos), d_vals signed 64-bit on the device
  *   (Transform_values_to_rns polynomial.c:362-392 / Transform_values_at_level :432). */

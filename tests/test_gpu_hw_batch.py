@@ -148,6 +148,28 @@ def test_generated_conv_loop_shape(env):
     _check(env, prog, rows=8, seed=5)
 
 
+def test_generated_key_inner_product_shape(env):
+    """the key inner product loop of the generated Rotate() (resnet20_cifar10_pre.onnx.inc:7011-7036): every limb's
+    product goes through ONE scratch limb (tmp[0]) before it is accumulated -- false dependencies that the batch
+    breaks by renaming; the final content of the scratch limb must still be the last product"""
+    o, rt, B = env
+    T = o.L + o.K
+
+    def at(row, g):
+        return (row * T + g) * N
+
+    tmp = at(9, 0)
+    prog = []
+    for g in range(T):
+        prog += [(B.HW_MUL, g, tmp, at(2, g), at(0, g)), (B.HW_ADD, g, at(4, g), at(4, g), tmp),
+                 (B.HW_MUL, g, tmp, at(3, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
+    _check(env, prog, rows=10, seed=12)
+    # the same with zero fills of the accumulators in front and a reader of the scratch limb behind
+    prog2 = [(B.HW_ZERO, 0, at(4, g), 0, 0) for g in range(T)] + [(B.HW_ZERO, 0, at(5, g), 0, 0) for g in range(T)] + prog
+    prog2 += [(B.HW_COPY, 0, at(8, 0), tmp, 0), (B.HW_ADD, T - 1, at(7, T - 1), tmp, tmp)]
+    _check(env, prog2, rows=10, seed=13)
+
+
 def test_long_accumulation_chain(env):
     """one chain of 300 dependent ops (more than one launch can hold) on a single limb"""
     o, rt, B = env
