@@ -814,22 +814,66 @@ int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t l
   return do_mod_down(c, out, in, level, ws_at(c, 0), (hipStream_t)s);
 }
 
-int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, acehip_stream s_) {
+static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level);
+// Mod_down of two extended polynomials (the two accumulators of a key-switch) in the same launches
+int acehip_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in0, const uint64_t* in1, uint32_t level,
+                     acehip_stream s_) {
   if (int e = check_dev(c)) return e;
-  if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale: level must be in [2, L]");
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down2: bad level");
+  if (!out0 || !out1 || !in0 || !in1 || out0 == in0 || out1 == in1 || out0 == in1 || out1 == in0 || out0 == out1)
+    return fail(ACEHIP_EINVAL, "acehip_mod_down2: outputs must not alias inputs or each other");
   const HostParams& hp = c->hp;
   hipStream_t s = (hipStream_t)s_;
-  const size_t N = hp.N;
-  u64* last = ws_at(c, 0);
-  u64* t = ws_at(c, 1);
-  HIP_TRY(hipMemcpyAsync(last, in + (size_t)(level - 1) * N, N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1);
-  const size_t row = (size_t)(level - 2) * hp.L;
-  launch_rescale_spread(c->dc, t, last, c->qlql + row, c->qlql_prec + row, level, s);
-  launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s);
-  launch_rescale_tail(c->dc, out, in, t, c->ql_inv + row, c->ql_inv_prec + row, level, s);
-  stat(ST_RESCALE, 1, 8ull * N * (2 * level - 1));
+  const KsPlan* plan = get_ks_plan(c, level);
+  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
+  const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N;
+  u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
+  u64* tmp = pc + 2 * PK;     // [2][level][N]
+  HIP_TRY(hipMemcpyAsync(pc, in0 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(pc + PK, in1 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, 2, PK);  // level 0: position j -> prime p_j
+  // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
+  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, 2, level, s);
+  launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, QL);
+  launch_moddown_tail2(c->dc, out0, out1, in0, in1, tmp, tmp + QL, c->pinv, c->pinv_prec, level, s);
+  stat(ST_MODDOWN, 2, 16ull * N * (2 * level + hp.K));
   return post_launch();
+}
+
+// one or two polynomials (c0, c1 of a ciphertext) through Rescale_poly in the same launches
+static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s) {
+  const HostParams& hp = c->hp;
+  const size_t N = hp.N;
+  const u32 np = in1 ? 2 : 1;
+  u64* last = ws_at(c, 0);   // [np][N]
+  u64* t = ws_at(c, 2);      // [np][level-1][N]
+  const size_t t_stride = (size_t)(level - 1) * N;
+  HwBatchArgs cp;            // the last limbs into scratch, one launch
+  for (u32 z = 0; z < np; ++z) {
+    cp.op[z] = HwBatchOp{last + z * N, (z ? in1 : in0) + (size_t)(level - 1) * N, nullptr, HW_OP_COPY, 0};
+    cp.seg_start[z] = (uint16_t)z;
+  }
+  cp.seg_start[np] = (uint16_t)np;
+  launch_hw_batch_ew(c->dc, cp, np, s);
+  launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N);
+  const size_t row = (size_t)(level - 2) * hp.L;
+  launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
+  launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride);
+  launch_rescale_tail(c->dc, out0, out1, in0, in1, t, t_stride, c->ql_inv + row, c->ql_inv_prec + row, level, np, s);
+  stat(ST_RESCALE, np, 8ull * N * (2 * level - 1) * np);
+  return post_launch();
+}
+int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale: level must be in [2, L]");
+  return do_rescale(c, out, nullptr, in, nullptr, level, (hipStream_t)s);
+}
+int acehip_rescale2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in0, const uint64_t* in1, uint32_t level,
+                    acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale2: level must be in [2, L]");
+  if (!out0 || !out1 || !in0 || !in1) return fail(ACEHIP_EINVAL, "acehip_rescale2: null polynomial");
+  return do_rescale(c, out0, out1, in0, in1, level, (hipStream_t)s);
 }
 
 static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
@@ -1047,9 +1091,16 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
   launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
   launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
   launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E, hp.alpha);
-  for (u32 d = 0; d < nd; ++d) {  // digit limbs pass through (polynomial.c:1265-1273)
-    const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
-    HIP_TRY(hipMemcpyAsync(ext + d * E + (size_t)start * N, in + (size_t)start * N, (size_t)n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
+    HwBatchArgs cp;
+    u32 n_ops = 0;
+    for (u32 pos = 0; pos < level; ++pos) {
+      if (n_ops == HW_BATCH_MAX) return fail(ACEHIP_EINVAL, "acehip_modup_digits: too many limbs");
+      cp.seg_start[n_ops] = (uint16_t)n_ops;
+      cp.op[n_ops++] = HwBatchOp{ext + (pos / hp.alpha) * E + (size_t)pos * N, in + (size_t)pos * N, nullptr, HW_OP_COPY, 0};
+    }
+    cp.seg_start[n_ops] = (uint16_t)n_ops;
+    launch_hw_batch_ew(c->dc, cp, n_ops, s);
   }
   stat(ST_MODUP, nd, 8ull * N * (level + (u64)nd * (level + hp.K)));
   return post_launch();

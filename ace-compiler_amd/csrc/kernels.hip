@@ -284,47 +284,52 @@ void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pin
   hipLaunchKernelGGL(moddown_tail_kernel, grid, block, 0, s, c, out, x, pinv, pinv_prec);
 }
 
-// Rescale (Rescale_poly polynomial.c:1132-1144): spread the iNTT'd last limb to every remaining limb
-__global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* __restrict__ t, const u64* __restrict__ last,
+// Rescale (Rescale_poly polynomial.c:1132-1144): spread the iNTT'd last limb to every remaining limb.
+// blockIdx.z = polynomial (c0 / c1 of a ciphertext are rescaled together)
+__global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* __restrict__ t, size_t t_stride,
+                                                             const u64* __restrict__ last, size_t last_stride,
                                                              const u64* __restrict__ c1, const u64* __restrict__ c1p,
                                                              u32 level) {
   const u32 l = blockIdx.y;
   const u64 q = c.primes[l].q, ql = c.primes[level - 1].q, w = c1[l], wp = c1p[l];
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
-  ulong2 v = *reinterpret_cast<const ulong2*>(last + i);
+  ulong2 v = *reinterpret_cast<const ulong2*>(last + blockIdx.z * last_stride + i);
   v.x = mul_shoup(switch_modulus(v.x, ql, q), w, wp, q);
   v.y = mul_shoup(switch_modulus(v.y, ql, q), w, wp, q);
-  *reinterpret_cast<ulong2*>(t + (size_t)l * c.N + i) = v;
+  *reinterpret_cast<ulong2*>(t + blockIdx.z * t_stride + (size_t)l * c.N + i) = v;
 }
 
-void launch_rescale_spread(const DevCtx& c, u64* t, const u64* last, const u64* c1, const u64* c1p, u32 level,
-                           hipStream_t s) {
-  dim3 grid((c.N / 2 + 255) / 256, level - 1), block(256);
-  hipLaunchKernelGGL(rescale_spread_kernel, grid, block, 0, s, c, t, last, c1, c1p, level);
+void launch_rescale_spread(const DevCtx& c, u64* t, size_t t_stride, const u64* last, size_t last_stride, const u64* c1,
+                           const u64* c1p, u32 level, u32 n_polys, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
+  hipLaunchKernelGGL(rescale_spread_kernel, grid, block, 0, s, c, t, t_stride, last, last_stride, c1, c1p, level);
 }
 
 // Rescale tail (polynomial.c:1145-1158): out = x * q_l^-1 + t
-__global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ x,
-                                                           const u64* __restrict__ t, const u64* __restrict__ inv,
-                                                           const u64* __restrict__ invp) {
+__global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __restrict__ out0, u64* __restrict__ out1,
+                                                           const u64* __restrict__ x0, const u64* __restrict__ x1,
+                                                           const u64* __restrict__ t, size_t t_stride,
+                                                           const u64* __restrict__ inv, const u64* __restrict__ invp) {
   const u32 l = blockIdx.y;
   const u64 q = c.primes[l].q, w = inv[l], wp = invp[l];
   const size_t base = (size_t)l * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
+  const u64* x = blockIdx.z ? x1 : x0;
+  u64* out = blockIdx.z ? out1 : out0;
   const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
-  const ulong2 vt = *reinterpret_cast<const ulong2*>(t + base + i);
+  const ulong2 vt = *reinterpret_cast<const ulong2*>(t + blockIdx.z * t_stride + base + i);
   ulong2 vo;
   vo.x = add_mod(mul_shoup(vx.x, w, wp, q), vt.x, q);
   vo.y = add_mod(mul_shoup(vx.y, w, wp, q), vt.y, q);
   *reinterpret_cast<ulong2*>(out + base + i) = vo;
 }
 
-void launch_rescale_tail(const DevCtx& c, u64* out, const u64* x, const u64* t, const u64* inv, const u64* invp,
-                         u32 level, hipStream_t s) {
-  dim3 grid((c.N / 2 + 255) / 256, level - 1), block(256);
-  hipLaunchKernelGGL(rescale_tail_kernel, grid, block, 0, s, c, out, x, t, inv, invp);
+void launch_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
+                         const u64* inv, const u64* invp, u32 level, u32 n_polys, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
+  hipLaunchKernelGGL(rescale_tail_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t, t_stride, inv, invp);
 }
 
 // key inner product for one digit (generated code inc:7011-7036 == Multiply_add polynomial.c:148-183)

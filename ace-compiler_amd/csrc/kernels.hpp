@@ -80,9 +80,11 @@ void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, 
 // ModDown tail: out[i] = shoup(x[i] - out[i], pinv[i]) for i < level
 void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s);
 // Rescale: t[i][n] = shoup(switch_modulus(last[n], q_last, q_i), c1[i]) for i < level-1
-void launch_rescale_spread(const DevCtx& c, u64* t, const u64* last, const u64* c1, const u64* c1p, u32 level, hipStream_t s);
+void launch_rescale_spread(const DevCtx& c, u64* t, size_t t_stride, const u64* last, size_t last_stride, const u64* c1,
+                           const u64* c1p, u32 level, u32 n_polys, hipStream_t s);
 // Rescale tail: out[i] = shoup(x[i], inv[i]) + t[i]
-void launch_rescale_tail(const DevCtx& c, u64* out, const u64* x, const u64* t, const u64* inv, const u64* invp, u32 level, hipStream_t s);
+void launch_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
+                         const u64* inv, const u64* invp, u32 level, u32 n_polys, hipStream_t s);
 // ---- setup-side kernels (keygen / encode), rt_kernels.hip ----
 // out[pos][n] = vals[n] mod prime(pos) for signed 64-bit vals (Transform_values_to_rns polynomial.c:362-392)
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);

@@ -40,7 +40,38 @@ void hw_stats_print() {
          s.flushes, s.ops, s.by_kind[0], s.by_kind[1], s.by_kind[2], s.by_kind[3], s.by_kind[4], s.by_kind[5], s.by_kind[6],
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
 }
+// ---- pairing of Mod_down / Rescale calls, speculative ModUp of all digits ----
+// Generated code handles the two polynomials of a ciphertext with two consecutive calls (Mod_down(c0); Mod_down(c1),
+// Rescale(c0); Rescale(c1)) and raises one digit per Decomp_modup call into the same buffer.  The first call of a
+// pair is held back until the next API call shows whether its partner follows (then both run in the same
+// launches: acehip_mod_down2 / acehip_rescale2); the first Decomp_modup of a polynomial raises every digit at once
+// (acehip_modup_digits) and the following calls copy their digit out of that result.
+namespace {
+struct PendingPair {
+  int kind = 0;  // 0 none, 1 Mod_down, 2 Rescale
+  u64* out = nullptr;
+  const u64* in = nullptr;
+  u32 level = 0;
+} g_pend;
+struct ModupCache {
+  const u64* src = nullptr;  // q-limbs of the polynomial the digits were raised from
+  u32 level = 0, next_part = 0;
+  u64* ext = nullptr;        // [nd][level+K][N]
+  size_t ext_words = 0;
+  bool valid = false;
+} g_muc;
+void pending_flush() {
+  if (!g_pend.kind) return;
+  const PendingPair p = g_pend;
+  g_pend.kind = 0;
+  const int rc = p.kind == 1 ? acehip_mod_down(ctx().hip, p.out, p.in, p.level, nullptr)
+                             : acehip_rescale(ctx().hip, p.out, p.in, p.level, nullptr);
+  RT_ASSERT(rc >= 0, "deferred %s failed: %s", p.kind == 1 ? "Mod_down" : "Rescale", acehip_last_error());
+}
+}  // namespace
 void hw_flush() {
+  pending_flush();   // it was issued after everything flushed earlier and before everything queued since
+  g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
   if (g_hwq.empty()) return;
   if (ctx().profile) {
     HwqStats& st = g_hwq_stats;
@@ -60,6 +91,8 @@ void hw_flush() {
 }
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs) {
   const size_t N = ctx().N;
+  pending_flush();
+  if (g_muc.valid && res + n_limbs * N > g_muc.src && res < g_muc.src + (size_t)g_muc.level * N) g_muc.valid = false;
   for (size_t l = 0; l < n_limbs; ++l)
     g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
                                  b ? (const void*)((const u64*)b + l * N) : nullptr});
@@ -122,6 +155,7 @@ void dfree(u64* p) {
   std::lock_guard<std::mutex> lk(pool_mu);
   auto it = pool_live.find(p);
   RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
+  if (g_muc.valid && g_muc.src >= p && g_muc.src < p + it->second) g_muc.valid = false;
   pool_live_bytes -= it->second * sizeof(u64);
   pool_free[it->second].push_back(p);
   pool_live.erase(it);
@@ -129,6 +163,7 @@ void dfree(u64* p) {
 
 void pool_release_all() {
   std::lock_guard<std::mutex> lk(pool_mu);
+  g_muc = ModupCache{};
   for (auto& kv : pool_free)
     for (u64* p : kv.second) acehip_free(p);
   pool_free.clear();
@@ -327,7 +362,32 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
   RT_ASSERT(res->_num_primes == level && res->_num_primes_p == c.K && res->_num_alloc_primes == level + c.K,
             "Decomp_modup: result must be allocated with Alloc_poly(degree, Poly_level(poly), 1)");
   RT_ASSERT(poly->_is_ntt, "Decomp_modup: coefficient-domain input is not supported by the HIP path");
-  HIPCHK(acehip_decomp_modup(c.hip, q_limbs(res), q_limbs(poly), level, q_part_idx, nullptr));
+  const u32 nd = acehip_num_decomp(c.hip, level);
+  RT_ASSERT(q_part_idx < nd, "Decomp_modup: part index out of range");
+  const size_t E = (size_t)(level + c.K) * c.N;
+  const u64* src = q_limbs(poly);
+  const bool hit = q_part_idx > 0 && g_muc.valid && g_muc.src == src && g_muc.level == level && g_muc.next_part == q_part_idx;
+  if (!hit) {
+    if (g_muc.ext_words < nd * E) {
+      if (g_muc.ext) dfree(g_muc.ext);
+      g_muc.ext = dalloc(nd * E, false);
+      g_muc.ext_words = nd * E;
+    }
+    if (q_part_idx == 0) {
+      HIPCHK(acehip_modup_digits(c.hip, g_muc.ext, src, level, nullptr));  // every digit in one go
+      g_muc.src = src;
+      g_muc.level = level;
+      g_muc.valid = true;
+    } else {  // a digit asked for out of sequence
+      HIPCHK(acehip_decomp_modup(c.hip, q_limbs(res), src, level, q_part_idx, nullptr));
+      res->_is_ntt = true;
+      return res;
+    }
+  }
+  g_muc.next_part = q_part_idx + 1;
+  const bool keep = g_muc.valid;  // copy_limbs -> hw_queue must not see the copy as foreign work
+  copy_limbs(q_limbs(res), g_muc.ext + (size_t)q_part_idx * E, E);
+  g_muc.valid = keep;
   res->_is_ntt = true;
   return res;
 }
@@ -336,7 +396,19 @@ POLY Mod_down(POLY res, POLY poly) {
   const u32 level = (u32)poly->_num_primes;
   RT_ASSERT(res->_num_primes == level && poly->_num_primes_p == c.K, "reduce_rns_base: result size not match");
   RT_ASSERT(poly->_num_alloc_primes - c.K == level, "Mod_down: p-limbs must follow the q-limbs");
-  HIPCHK(acehip_mod_down(c.hip, q_limbs(res), q_limbs(poly), level, nullptr));
+  u64* out = q_limbs(res);
+  const u64* in = q_limbs(poly);
+  if (g_pend.kind == 1 && g_pend.level == level && g_pend.out != out && g_pend.in != in && g_pend.out != in && g_pend.in != out) {
+    const PendingPair p = g_pend;
+    g_pend.kind = 0;
+    HIPCHK(acehip_mod_down2(c.hip, p.out, out, p.in, in, level, nullptr));
+  } else {
+    hw_flush();  // everything issued so far, including an unpaired predecessor
+    g_pend.kind = 1;
+    g_pend.out = out;
+    g_pend.in = in;
+    g_pend.level = level;
+  }
   res->_is_ntt = poly->_is_ntt;
   return res;
 }
@@ -351,7 +423,19 @@ POLY Rescale(POLY res, POLY poly) {
     copy_limbs((u64*)q_limbs(res), (const u64*)tmp, (size_t)(level - 1) * c.N);
     dfree(tmp);
   } else {
-    HIPCHK(acehip_rescale(c.hip, q_limbs(res), q_limbs(poly), level, nullptr));
+    u64* out = q_limbs(res);
+    const u64* in = q_limbs(poly);
+    if (g_pend.kind == 2 && g_pend.level == level && g_pend.out != out && g_pend.in != in && g_pend.out != in && g_pend.in != out) {
+      const PendingPair p = g_pend;
+      g_pend.kind = 0;
+      HIPCHK(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr));
+    } else {
+      hw_flush();
+      g_pend.kind = 2;
+      g_pend.out = out;
+      g_pend.in = in;
+      g_pend.level = level;
+    }
   }
   res->_is_ntt = true;
   res->_num_primes = level - 1;  // Mod_down_q_primes polynomial.h:300

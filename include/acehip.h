@@ -150,6 +150,11 @@ int acehip_decomp_modup(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, 
 int acehip_mod_down(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 
+/* Mod_down / Rescale of the two polynomials of a ciphertext in the same launches (generated code calls
+ * Mod_down(c0); Mod_down(c1) and Rescale(c0); Rescale(c1) back to back: resnet20_cifar10_pre.onnx.inc:7035-7036,
+ * :1552-1553).  Results are those of the single-polynomial calls. */
+int acehip_mod_down2(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in0, const uint64_t* d_in1, uint32_t level, acehip_stream stream);
+int acehip_rescale2(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in0, const uint64_t* d_in1, uint32_t level, acehip_stream stream);
 /* ---- key-switch core of the generated Rotate()/Relinearize()
  * (dataset/resnet20_cifar10_pre.onnx.inc:6972-7146; Fast_switch_key ckks_evaluator.c:391-416):
  *   out0 = Mod_down(sum_d key0[d] * Decomp_modup(in, d)),  out1 likewise with key1.

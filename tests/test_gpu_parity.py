@@ -116,6 +116,40 @@ def test_decomp_modup_moddown_rescale(pair):
             assert np.array_equal(rt.rescale(a, level), o.rescale(a, level)), level
 
 
+def test_pair_forms_and_all_digit_modup(pair):
+    """acehip_mod_down2 / acehip_rescale2 (c0 and c1 of a ciphertext in the same launches) and acehip_modup_digits
+    (every digit at once) against the single-polynomial oracle results"""
+    o, rt, levels = pair
+    N, K = o.N, o.K
+    for level in levels:
+        x0, x1 = o.uniform(level + K, level, 71 + level), o.uniform(level + K, level, 72 + level)
+        d0, d1, r0, r1 = rt.to_device(x0), rt.to_device(x1), rt.buf(level * N), rt.buf(level * N)
+        rt.check(rt.lib.acehip_mod_down2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+        assert np.array_equal(r0.download((level, N)), o.mod_down(x0, level)), level
+        assert np.array_equal(r1.download((level, N)), o.mod_down(x1, level)), level
+        assert np.array_equal(d0.download(x0.shape), x0) and np.array_equal(d1.download(x1.shape), x1)  # inputs intact
+        assert rt.lib.acehip_mod_down2(rt.h, r0.ptr, r0.ptr, d0.ptr, d1.ptr, level, None) == -1
+        for d in (d0, d1, r0, r1):
+            d.free()
+        a0, a1 = o.uniform(level, level, 73 + level), o.uniform(level, level, 74 + level)
+        if level > 1:
+            d0, d1, r0, r1 = rt.to_device(a0), rt.to_device(a1), rt.buf((level - 1) * N), rt.buf((level - 1) * N)
+            rt.check(rt.lib.acehip_rescale2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+            assert np.array_equal(r0.download((level - 1, N)), o.rescale(a0, level)), level
+            assert np.array_equal(r1.download((level - 1, N)), o.rescale(a1, level)), level
+            assert np.array_equal(d0.download(a0.shape), a0) and np.array_equal(d1.download(a1.shape), a1)
+            for d in (d0, d1, r0, r1):
+                d.free()
+        nd = o.num_decomp(level)
+        da, de = rt.to_device(a0), rt.buf(nd * (level + K) * N)
+        rt.check(rt.lib.acehip_modup_digits(rt.h, de.ptr, da.ptr, level, None))
+        ext = de.download((nd, level + K, N))
+        for d in range(nd):
+            assert np.array_equal(ext[d], o.decomp_modup(a0, level, d)), (level, d)
+        da.free()
+        de.free()
+
+
 def test_key_switch(pair):
     o, rt, levels = pair
     key = o.make_key(1000)
