@@ -10,20 +10,26 @@
 
 namespace acehip {
 
-// every lane owns coefficients (i, i+1) of all limbs of its segment: read-after-write between ops of a chain
-// goes through the lane's own stores, which it observes in order
+// Every lane owns coefficients (i, i+1) of all limbs of its segment: read-after-write between ops of a chain goes
+// through the lane itself.  The previous result stays in registers: an operand that is the previous op's result
+// limb is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
+// (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run always stores, so
+// every later reader -- in this segment, another launch or the host -- finds the final value in memory).
 __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs args) {
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
+  const u64* prev_res = nullptr;
+  ulong2 vprev{0, 0};
   for (u32 k = beg; k < end; ++k) {
     const HwBatchOp op = args.op[k];
+    const bool keep_in_regs = k + 1 < end && args.op[k + 1].res == op.res;
     ulong2 vr;
     if (op.kind == HW_OP_ZERO) {
       vr.x = 0;
       vr.y = 0;
     } else {
-      const ulong2 va = *reinterpret_cast<const ulong2*>(op.a + i);
+      const ulong2 va = op.a == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.a + i);
       if (op.kind == HW_OP_COPY) {
         vr = va;
       } else {
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs 
         if (op.kind == HW_OP_MULC || op.kind == HW_OP_ADDC) {  // the second operand is an immediate
           vb.x = vb.y = (u64)(uintptr_t)op.b;
         } else {
-          vb = *reinterpret_cast<const ulong2*>(op.b + i);
+          vb = op.b == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.b + i);
         }
         switch (op.kind) {
           case HW_OP_ADD:
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs 
             vr.y = sub_mod(va.y, vb.y, P.q);
             break;
           case HW_OP_MULADD: {
-            const ulong2 acc = *reinterpret_cast<const ulong2*>(op.res + i);
+            const ulong2 acc = op.res == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.res + i);
             vr.x = add_mod(acc.x, mul_mod(va.x, vb.x, P), P.q);
             vr.y = add_mod(acc.y, mul_mod(va.y, vb.y, P), P.q);
             break;
@@ -57,7 +63,9 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs 
         }
       }
     }
-    *reinterpret_cast<ulong2*>(op.res + i) = vr;
+    if (!keep_in_regs) *reinterpret_cast<ulong2*>(op.res + i) = vr;
+    prev_res = op.res;
+    vprev = vr;
   }
 }
 
