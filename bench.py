@@ -113,20 +113,13 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
+    import ace_compiler_amd as A
+    from ace_compiler_amd.dist import Ranks
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ranks = Ranks()  # one process per GPU; RCCL ("nccl") carries only the barrier and the max over ranks
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
 
     import numpy as np
-
-    import ace_compiler_amd as A
 
     bmod = sys.modules["ace_compiler_amd.build"]
     use_model = args.workload != "keyswitch" and os.path.exists(MODEL_LIB) and os.path.exists(bmod.RT_LIB)
@@ -137,9 +130,16 @@ def main():
     lib, h = rt.lib, rt.h
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         rt.sync()
+
+    class Stat(C.Structure):
+        _fields_ = [("calls", C.c_uint64), ("units", C.c_uint64), ("bytes", C.c_uint64)]
+
+    def read_stats(reset):
+        arr = (Stat * 16)()
+        n = lib.acehip_stats(arr, 16, 1 if reset else 0)
+        return {lib.acehip_stat_name(i).decode(): (arr[i].calls, arr[i].units, arr[i].bytes) for i in range(n)}
 
     # ---------------- headline: ResNet-20 images/s (or the C3 key-switch fallback) ----------------
     T = L + rt.K
@@ -203,18 +203,15 @@ def main():
     for _ in range(args.warmup):
         logits = step()
     barrier()
+    read_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logits = step()
     rt.sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    stats = read_stats(reset=False)
     barrier()
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(elapsed_local)
     value = world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     if use_model:
@@ -277,14 +274,21 @@ def main():
                            "achieved_GBs": round(ks_bytes / (ks_ms * 1e-3) / 1e9, 2),
                            "frac_of_hbm_peak": round(ks_bytes / (ks_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        # whole-workload view: algorithmic bytes of every entry-point call of the timed region on this rank
+        alg = sum(v[2] for v in stats.values())
+        out["workload_roofline"] = {
+            "algorithmic_bytes_per_step": int(alg / args.steps), "achieved_GBs": round(alg / elapsed_local / 1e9, 2),
+            "frac_of_hbm_peak": round(alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
+            "calls_per_step": {k: round(v[0] / args.steps, 1) for k, v in stats.items() if v[0]},
+            "GB_per_step": {k: round(v[2] / args.steps / 1e9, 2) for k, v in stats.items() if v[2]},
+            "note": "sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) / wall time"}
         if logits is not None:
             out["config"]["last_logits"] = [round(v, 5) for v in logits]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(use_model)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
     rt.close()
 
 
