@@ -81,6 +81,7 @@ struct acehip_ctx {
   cd* emb_work = nullptr;
   int64_t* emb_msg = nullptr;
   int* emb_err = nullptr;
+  std::map<std::pair<u64, u32>, u64*> enc_scales;  // (Delta, sf_degree) -> [L] Delta^(sf_degree-1) mod q_i
 
   template <typename T>
   T* up(const std::vector<T>& v) {
@@ -393,6 +394,8 @@ static const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit) {
 
 // workspace carving (in limbs of N words)
 static u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
+static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level);
+static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s);
 
 static int do_decomp_modup(acehip_ctx* c, u64* out, const u64* in, u32 level, u32 digit, u64* scratch, hipStream_t s) {
   const HostParams& hp = c->hp;
@@ -810,34 +813,57 @@ int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t l
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down: bad level");
   if (out == in) return fail(ACEHIP_EINVAL, "acehip_mod_down: out must not alias in");
+  if (c->dc.logN == 16) return do_mod_down_n(c, out, nullptr, in, nullptr, level, (hipStream_t)s);
   stat(ST_MODDOWN, 1, 8ull * c->hp.N * (2 * level + c->hp.K));
   return do_mod_down(c, out, in, level, ws_at(c, 0), (hipStream_t)s);
 }
 
-static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level);
-// Mod_down of two extended polynomials (the two accumulators of a key-switch) in the same launches
+// Mod_down of one or two extended polynomials (the two accumulators of a key-switch) in the same launches
+static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s) {
+  const HostParams& hp = c->hp;
+  const KsPlan* plan = get_ks_plan(c, level);
+  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
+  const u32 np = in1 ? 2 : 1;
+  const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N;
+  u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
+  u64* tmp = pc + 2 * PK;     // [2][level][N]
+  if (c->dc.logN == 16) {
+    NttFuse fi;
+    fi.src0 = in0 + QL;
+    fi.src1 = in1 ? in1 + QL : nullptr;
+    launch_ntt_fused(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
+  } else {
+    HIP_TRY(hipMemcpyAsync(pc, in0 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    if (in1) HIP_TRY(hipMemcpyAsync(pc + PK, in1 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
+  }
+  // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
+  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s);
+  if (c->dc.logN == 16) {
+    NttFuse fo;
+    fo.epi = 2;
+    fo.out0 = out0;
+    fo.out1 = out1;
+    fo.x0 = in0;
+    fo.x1 = in1;
+    fo.w = c->pinv;
+    fo.wp = c->pinv_prec;
+    launch_ntt_fused(c->dc, tmp, level, 0, level, false, s, 0, np, QL, 0, fo);
+  } else {
+    launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, np, QL);
+    launch_moddown_tail2(c->dc, out0, out1 ? out1 : out0, in0, in1 ? in1 : in0, tmp, tmp + (in1 ? QL : 0), c->pinv, c->pinv_prec,
+                         level, s, np);
+  }
+  stat(ST_MODDOWN, np, 8ull * np * N * (2 * level + hp.K));
+  return post_launch();
+}
 int acehip_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in0, const uint64_t* in1, uint32_t level,
-                     acehip_stream s_) {
+                     acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down2: bad level");
   if (!out0 || !out1 || !in0 || !in1 || out0 == in0 || out1 == in1 || out0 == in1 || out1 == in0 || out0 == out1)
     return fail(ACEHIP_EINVAL, "acehip_mod_down2: outputs must not alias inputs or each other");
-  const HostParams& hp = c->hp;
-  hipStream_t s = (hipStream_t)s_;
-  const KsPlan* plan = get_ks_plan(c, level);
-  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
-  const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N;
-  u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
-  u64* tmp = pc + 2 * PK;     // [2][level][N]
-  HIP_TRY(hipMemcpyAsync(pc, in0 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(pc + PK, in1 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, 2, PK);  // level 0: position j -> prime p_j
-  // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
-  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, 2, level, s);
-  launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, QL);
-  launch_moddown_tail2(c->dc, out0, out1, in0, in1, tmp, tmp + QL, c->pinv, c->pinv_prec, level, s);
-  stat(ST_MODDOWN, 2, 16ull * N * (2 * level + hp.K));
-  return post_launch();
+  return do_mod_down_n(c, out0, out1, in0, in1, level, (hipStream_t)s);
 }
 
 // one or two polynomials (c0, c1 of a ciphertext) through Rescale_poly in the same launches
@@ -854,12 +880,29 @@ static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const
     cp.seg_start[z] = (uint16_t)z;
   }
   cp.seg_start[np] = (uint16_t)np;
-  launch_hw_batch_ew(c->dc, cp, np, s);
-  launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N);
   const size_t row = (size_t)(level - 2) * hp.L;
-  launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
-  launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride);
-  launch_rescale_tail(c->dc, out0, out1, in0, in1, t, t_stride, c->ql_inv + row, c->ql_inv_prec + row, level, np, s);
+  if (c->dc.logN == 16) {  // fused: iNTT reads the last limbs in place of a copy, the forward NTT applies the tail
+    NttFuse fi;
+    fi.src0 = in0 + (size_t)(level - 1) * N;
+    fi.src1 = in1 ? in1 + (size_t)(level - 1) * N : nullptr;
+    launch_ntt_fused(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N, 0, fi);
+    launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
+    NttFuse fo;
+    fo.epi = 1;
+    fo.out0 = out0;
+    fo.out1 = out1;
+    fo.x0 = in0;
+    fo.x1 = in1;
+    fo.w = c->ql_inv + row;
+    fo.wp = c->ql_inv_prec + row;
+    launch_ntt_fused(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride, 0, fo);
+  } else {
+    launch_hw_batch_ew(c->dc, cp, np, s);
+    launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N);
+    launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
+    launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride);
+    launch_rescale_tail(c->dc, out0, out1, in0, in1, t, t_stride, c->ql_inv + row, c->ql_inv_prec + row, level, np, s);
+  }
   stat(ST_RESCALE, np, 8ull * N * (2 * level - 1) * np);
   return post_launch();
 }
@@ -938,8 +981,15 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   u64* acc1 = acc0 + E;
   u64* tmp = acc1 + E;
   // 1. all digit limbs to the coefficient domain in one launch (polynomial.c:1276-1283 for every part)
-  HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  const bool fused = c->dc.logN == 16;
+  if (fused) {
+    NttFuse fi;
+    fi.src0 = in;
+    launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
+  } else {
+    HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  }
   // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the load), one launch
   launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
   // 3. NTT of every digit's complement limbs, one launch (own digit limbs are skipped)
@@ -950,8 +1000,20 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   // 5. ModDown of both accumulators together (polynomial.c:928-967)
   launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
   launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s);
-  launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
-  launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
+  if (fused) {  // the ModDown tail rides in the last NTT pass
+    NttFuse fo;
+    fo.epi = 2;
+    fo.out0 = out0;
+    fo.out1 = out1;
+    fo.x0 = acc0;
+    fo.x1 = acc1;
+    fo.w = c->pinv;
+    fo.wp = c->pinv_prec;
+    launch_ntt_fused(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N, 0, fo);
+  } else {
+    launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
+    launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
+  }
   stat(ST_KEYSWITCH, 1, acehip_key_switch_bytes(c, level));
   return post_launch();
 }
@@ -1017,24 +1079,50 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
   if (int e = ensure_embed_tables(c)) return e;
   hipStream_t st = (hipStream_t)s;
   launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
-  launch_values_to_rns(c->dc, d_q, c->emb_msg, level, 0, level, st);
-  if (n_p) launch_values_to_rns(c->dc, d_p, c->emb_msg, 0, 0, n_p, st);
-  if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
-    const u64 sfi = (u64)sf;
-    for (u32 l0 = 0; l0 < level; l0 += 64) {
-      LimbConsts w{};
-      const u32 n = std::min(64u, level - l0);
-      for (u32 i = 0; i < n; ++i) {
-        const u64 q = c->hp.primes[l0 + i].q;
-        u64 pw = sfi % q;
-        for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
-        w.w[i] = pw;
+  const u64 sfi = (u64)sf;
+  if (c->dc.logN == 16) {  // the first NTT pass reduces (and scales) the message itself: no residue pass over memory
+    NttFuse f;
+    f.msg = c->emb_msg;
+    if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
+      std::lock_guard<std::mutex> g(c->mu);
+      u64*& tab = c->enc_scales[{sfi, sf_degree}];
+      if (!tab) {
+        std::vector<u64> w(c->hp.L);
+        for (u32 i = 0; i < c->hp.L; ++i) {
+          const u64 q = c->hp.primes[i].q;
+          u64 pw = sfi % q;
+          for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+          w[i] = pw;
+        }
+        tab = c->up(w);
+        if (!tab) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
       }
-      launch_mul_scalars(c->dc, d_q, d_q, w, level, l0, n, st);
+      f.msg_scale = tab;
     }
+    launch_ntt_fused(c->dc, d_q, level, 0, level, false, st, 0, 1, 0, 0, f);
+    if (n_p) {
+      f.msg_scale = nullptr;
+      launch_ntt_fused(c->dc, d_p, 0, 0, n_p, false, st, 0, 1, 0, 0, f);
+    }
+  } else {
+    launch_values_to_rns(c->dc, d_q, c->emb_msg, level, 0, level, st);
+    if (n_p) launch_values_to_rns(c->dc, d_p, c->emb_msg, 0, 0, n_p, st);
+    if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
+      for (u32 l0 = 0; l0 < level; l0 += 64) {
+        LimbConsts w{};
+        const u32 n = std::min(64u, level - l0);
+        for (u32 i = 0; i < n; ++i) {
+          const u64 q = c->hp.primes[l0 + i].q;
+          u64 pw = sfi % q;
+          for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+          w.w[i] = pw;
+        }
+        launch_mul_scalars(c->dc, d_q, d_q, w, level, l0, n, st);
+      }
+    }
+    launch_ntt(c->dc, d_q, level, 0, level, false, st);
+    if (n_p) launch_ntt(c->dc, d_p, 0, 0, n_p, false, st);
   }
-  launch_ntt(c->dc, d_q, level, 0, level, false, st);
-  if (n_p) launch_ntt(c->dc, d_p, 0, 0, n_p, false, st);
   stat(ST_ENCODE, 1, 8ull * N * (level + n_p) + len * (kind == 0 ? 4 : kind == 1 ? 8 : 16));
   return post_launch();
 }
@@ -1087,8 +1175,14 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
   const size_t N = hp.N, E = (size_t)(level + hp.K) * N;
   const u32 nd = plan->nd;
   u64* coef = c->ws;
-  HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  if (c->dc.logN == 16) {
+    NttFuse fi;
+    fi.src0 = in;
+    launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
+  } else {
+    HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  }
   launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
   launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E, hp.alpha);
   {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch

@@ -47,9 +47,32 @@ struct ConvDesc {
 
 enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 
+// Work fused into the first / last pass of an N = 2^16 NTT (ntt_fast.hip), so that the neighbours of a transform
+// in Rescale / ModDown / ModUp / encode need no launch and no pass over memory of their own.
+struct NttFuse {
+  // inverse, first pass: read polynomial z from src_z instead of transforming in place (limb layout as `poly`)
+  const u64* src0 = nullptr;
+  const u64* src1 = nullptr;
+  // forward, first pass: every limb starts from the same signed message, reduced mod its prime and multiplied by
+  // scale[pos] when given (Encode_impl ckks_encoder.c:262-285)
+  const int64_t* msg = nullptr;
+  const u64* msg_scale = nullptr;
+  // forward, last pass: v = NTT value; 1: out = x*w + v (Rescale tail polynomial.c:1145-1158),
+  // 2: out = (x - v)*w (ModDown tail :956-965); x_z, out_z are polynomials of q-limbs, w/wp per limb
+  int epi = 0;
+  u64* out0 = nullptr;
+  u64* out1 = nullptr;
+  const u64* x0 = nullptr;
+  const u64* x1 = nullptr;
+  const u64* w = nullptr;
+  const u64* wp = nullptr;
+};
 // NTT over limb positions [pos0, pos0+n) of poly at `level`
 // the limb at position pos lives at poly + (pos - pos_off)*N
 // n_polys polynomials poly_stride words apart are transformed in the same launch
+// N = 2^16 only: NTT with fused neighbours (f.src*/f.msg for the first pass, f.epi for the last)
+void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                      u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f);
 void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off = 0,
                 u32 n_polys = 1, size_t poly_stride = 0, u32 skip_alpha = 0);
 // register-tiled passes (ntt_fast.hip)
@@ -76,7 +99,7 @@ void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s);
 // ModDown tail for two polynomials: out_z = shoup(x_z - t_z, pinv), z in {0,1}
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
-                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s);
+                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys = 2);
 // ModDown tail: out[i] = shoup(x[i] - out[i], pinv[i]) for i < level
 void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s);
 // Rescale: t[i][n] = shoup(switch_modulus(last[n], q_last, q_i), c1[i]) for i < level-1

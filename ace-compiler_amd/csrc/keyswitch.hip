@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __res
 }
 
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
-                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s) {
-  dim3 grid((c.N / 2 + 255) / 256, level, 2), block(256);
+                          const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys) {
+  dim3 grid((c.N / 2 + 255) / 256, level, n_polys), block(256);
   hipLaunchKernelGGL(moddown_tail2_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t0, t1, pinv, pinv_prec);
 }
 

@@ -12,6 +12,7 @@
 //
 // Integer-multiply throughput (v_mad_u64_u32 at half rate, v_mul_lo/hi_u32 at quarter rate:
 // tools/ubench_int.hip) is the VALU ceiling of these kernels; see DESIGN.md.
+#include "device_arith.hpp"
 #include "kernels.hpp"
 
 namespace acehip {
@@ -100,9 +101,10 @@ __device__ __forceinline__ u32 cpad(u32 rho) { return rho + (rho >> 4); }
 // columns col = chunk*16 + cc.  Round A lanes (g = tid>>4, cc = tid&15) hold rows 16k+g;
 // round B lanes (h = tid>>4, cc) hold rows 16h+g'.
 // ------------------------------------------------------------------------------------------------
-template <bool INVERSE>
+// FROM_MSG (forward only): the input of every limb is the signed message f.msg reduced mod the limb's prime
+template <bool INVERSE, bool FROM_MSG>
 __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
-                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha) {
+                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f) {
   __shared__ u64 lds[256 * kRowPitch];
   u32 pos;
   if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
@@ -119,8 +121,20 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
 
   if (!INVERSE) {
     // round A: stages 0..3 (uniform twiddles TW[1..15])
+    if (FROM_MSG) {
+      const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * k + hg) << log_s) + col];
+      for (int k = 0; k < 16; ++k) {
+        const int64_t v = f.msg[((size_t)(16 * k + hg) << log_s) + col];
+        const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+        u64 r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
+        if (v < 0 && r != 0) r = q - r;
+        x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * k + hg) << log_s) + col];
+    }
     load_tw(TW, 0, 0, t0, t1, t2, t3);
     radix16_fwd(x, t0, t1, t2, t3, q, q2);
 #pragma unroll
@@ -171,9 +185,11 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
 // CANON_OUT (inverse only): write canonical values instead of lazy [0,2q) (needed when a generic
 // pass follows instead of the strided fast pass).
 // ------------------------------------------------------------------------------------------------
-template <bool INVERSE, bool CANON_OUT>
+// FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
+// f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
+template <bool INVERSE, bool CANON_OUT, int FUSE>
 __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
-                                                          u32 level, u32 pos0, u32 pos_off, u32 skip_alpha) {
+                                                          u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f) {
   __shared__ u64 lds[16 * kBlkPitch];
   u32 pos;
   if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
@@ -211,19 +227,34 @@ __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restr
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
     __syncthreads();
+    const size_t tail_off = (size_t)pos * c.N + (size_t)blockIdx.x * 4096;  // q-limb `pos` of x_z / out_z
+    const u64* __restrict__ xin = FUSE ? (blockIdx.z ? f.x1 : f.x0) + tail_off : nullptr;
+    u64* __restrict__ dst = FUSE ? (blockIdx.z ? f.out1 : f.out0) + tail_off : X;
+    const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte stores
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
       ulong2 v;
       v.x = lds[bb * kBlkPitch + cpad(rho)];
       v.y = lds[bb * kBlkPitch + cpad(rho) + 1];
-      *reinterpret_cast<ulong2*>(X + e) = v;
+      if (FUSE == 1) {
+        const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + e);
+        v.x = add_mod(mul_shoup(xv.x, tw_w, tw_p, q), v.x, q);
+        v.y = add_mod(mul_shoup(xv.y, tw_w, tw_p, q), v.y, q);
+      } else if (FUSE == 2) {
+        const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + e);
+        v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
+        v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
+      }
+      *reinterpret_cast<ulong2*>(dst + e) = v;
     }
   } else {
+    const u64* __restrict__ S =
+        FUSE ? (blockIdx.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)blockIdx.x * 4096 : X;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-      const ulong2 v = *reinterpret_cast<const ulong2*>(X + e);
+      const ulong2 v = *reinterpret_cast<const ulong2*>(S + e);
       lds[bb * kBlkPitch + cpad(rho)] = v.x;
       lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
     }
@@ -257,22 +288,34 @@ __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restr
 // any logN >= 13 (the generic LDS kernel does the leading logN-8 stages).
 void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
                      u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
-  dim3 block(256);
-  dim3 grid_s(c.N >> 12, n_limbs, n_polys), grid_c(c.N >> 12, n_limbs, n_polys);
+  launch_ntt_fused(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, NttFuse{});
+}
+
+void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                      u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
+  if (n_limbs == 0) return;
+  dim3 block(256), grid(c.N >> 12, n_limbs, n_polys);
+#define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f
   if (!inverse) {
-    hipLaunchKernelGGL(ntt8_strided_kernel<false>, grid_s, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
-    hipLaunchKernelGGL((ntt8_contig_kernel<false, true>), grid_c, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+    if (f.msg) hipLaunchKernelGGL((ntt8_strided_kernel<false, true>), ACEHIP_NTT_ARGS);
+    else       hipLaunchKernelGGL((ntt8_strided_kernel<false, false>), ACEHIP_NTT_ARGS);
+    if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1>), ACEHIP_NTT_ARGS);
+    else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2>), ACEHIP_NTT_ARGS);
+    else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), ACEHIP_NTT_ARGS);
   } else {
-    hipLaunchKernelGGL((ntt8_contig_kernel<true, false>), grid_c, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
-    hipLaunchKernelGGL(ntt8_strided_kernel<true>, grid_s, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+    if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1>), ACEHIP_NTT_ARGS);
+    else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0>), ACEHIP_NTT_ARGS);
+    hipLaunchKernelGGL((ntt8_strided_kernel<true, false>), ACEHIP_NTT_ARGS);
   }
+#undef ACEHIP_NTT_ARGS
 }
 
 void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
                         u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
   dim3 block(256), grid(c.N >> 12, n_limbs, n_polys);
-  if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
-  else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha);
+  const NttFuse f{};
+  if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f);
+  else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f);
 }
 
 }  // namespace acehip

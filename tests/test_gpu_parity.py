@@ -254,3 +254,48 @@ def test_full_size_properties():
     finally:
         rt.close()
         o.close()
+
+
+def test_fused_ntt_paths_n65536():
+    """N = 2^16 takes the fused transforms (ntt_fast.hip NttFuse: out-of-place first pass, Rescale / ModDown tail in the
+    last pass): single and pair forms of Mod_down / Rescale, all-digit ModUp and the key-switch against the oracle."""
+    N, L, q0, sf, dnum = 65536, 5, 60, 56, 2
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        K = o.K
+        for level in (5, 3, 2):
+            x0, x1 = o.uniform(level + K, level, 171 + level), o.uniform(level + K, level, 172 + level)
+            e0, e1 = o.mod_down(x0, level), o.mod_down(x1, level)
+            assert np.array_equal(rt.mod_down(x0, level), e0)
+            d0, d1, r0, r1 = rt.to_device(x0), rt.to_device(x1), rt.buf(level * N), rt.buf(level * N)
+            rt.check(rt.lib.acehip_mod_down2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+            assert np.array_equal(r0.download((level, N)), e0) and np.array_equal(r1.download((level, N)), e1)
+            assert np.array_equal(d0.download(x0.shape), x0) and np.array_equal(d1.download(x1.shape), x1)
+            for d in (d0, d1, r0, r1):
+                d.free()
+            a0, a1 = o.uniform(level, level, 173 + level), o.uniform(level, level, 174 + level)
+            f0, f1 = o.rescale(a0, level), o.rescale(a1, level)
+            assert np.array_equal(rt.rescale(a0, level), f0)
+            d0, d1, r0, r1 = rt.to_device(a0), rt.to_device(a1), rt.buf((level - 1) * N), rt.buf((level - 1) * N)
+            rt.check(rt.lib.acehip_rescale2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+            assert np.array_equal(r0.download((level - 1, N)), f0) and np.array_equal(r1.download((level - 1, N)), f1)
+            assert np.array_equal(d0.download(a0.shape), a0) and np.array_equal(d1.download(a1.shape), a1)
+            for d in (d0, d1, r0, r1):
+                d.free()
+            nd = o.num_decomp(level)
+            da, de = rt.to_device(a0), rt.buf(nd * (level + K) * N)
+            rt.check(rt.lib.acehip_modup_digits(rt.h, de.ptr, da.ptr, level, None))
+            ext = de.download((nd, level + K, N))
+            for d in range(nd):
+                assert np.array_equal(ext[d], o.decomp_modup(a0, level, d)), (level, d)
+            assert np.array_equal(da.download(a0.shape), a0)
+            da.free()
+            de.free()
+            key = o.make_key(2000)
+            c0, c1 = rt.key_switch(a0, key, level)
+            g0, g1 = o.key_switch(a0, key, level)
+            assert np.array_equal(c0, g0) and np.array_equal(c1, g1), level
+    finally:
+        rt.close()
+        o.close()
