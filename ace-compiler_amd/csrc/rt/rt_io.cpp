@@ -203,6 +203,7 @@ static float* synth_entry(uint32_t index, size_t len) {
   return buf.data();
 }
 
+static void pt_cache_clear();
 bool Pt_mgr_init(const char* fname) {
   if (const char* e = getenv("ACEHIP_RT_DATA_SYNTH")) {
     if (atoi(e) != 0) {
@@ -239,6 +240,7 @@ bool Pt_mgr_init(const char* fname) {
 }
 void Pt_mgr_fini() {
   rt::sync();
+  pt_cache_clear();
   if (g_pt.dbuf) acehip_free(g_pt.dbuf);
   g_pt.dbuf = nullptr;
   for (auto& kv : g_pt.synth_dev) acehip_free(kv.second.first);
@@ -283,12 +285,49 @@ static const float* pt_entry_dev(uint32_t index, size_t len) {
   g_pt.synth_dev[index] = {d, len};
   return d;
 }
+// ACEHIP_PT_CACHE=1 (off by default): keep every encoded weight plaintext in HBM, keyed by
+// (entry, length, level, sf_degree), and copy it out on later requests instead of encoding again -- the
+// device-side counterpart of the reference's pre-encoded DE_PLAINTEXT data files (pt_mgr.c:63-159).
+// ResNet-20 holds 6044 plaintexts = 12.3 GB, a fraction of the 288 GB of one MI355X.  The first image fills it.
+struct PtKey {
+  uint32_t index, level, scale;
+  size_t len;
+  bool operator<(const PtKey& o) const {
+    return std::tie(index, level, scale, len) < std::tie(o.index, o.level, o.scale, o.len);
+  }
+};
+static std::map<PtKey, rt::u64*> g_pt_cache;
+static int g_pt_cache_on = -1;
+static void pt_cache_clear() {
+  for (auto& kv : g_pt_cache) acehip_free(kv.second);
+  g_pt_cache.clear();
+  g_pt_cache_on = -1;
+}
 static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
   if (len == 1) {  // plain_eval.c:25-33: a single value is a constant polynomial
     Encode_plain_from_float(plain, pt_entry(index, len), len, scale, level);
     return;
   }
-  rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+  if (g_pt_cache_on < 0) g_pt_cache_on = getenv("ACEHIP_PT_CACHE") && atoi(getenv("ACEHIP_PT_CACHE")) != 0;
+  if (g_pt_cache_on) {
+    rt::Context& c = rt::ctx();
+    const uint32_t lv = level ? level : c.L;
+    const size_t words = (size_t)lv * c.N;
+    auto it = g_pt_cache.find(PtKey{index, lv, scale, len});
+    if (it == g_pt_cache.end()) {
+      rt::encode_device(plain, pt_entry_dev(index, len), 0, len, lv, 0, scale, 0);
+      rt::u64* keep = (rt::u64*)acehip_malloc(words * 8);
+      RT_ASSERT(keep, "plaintext cache: %s", acehip_last_error());
+      HIPCHK(acehip_memcpy_d2d(keep, rt::q_limbs(&plain->_poly), words * 8, nullptr));
+      g_pt_cache[PtKey{index, lv, scale, len}] = keep;
+    } else {
+      rt::init_plaintext(plain, c.N / 2, lv, 0, pow(c.sf, (double)scale), scale);
+      rt::copy_limbs(rt::q_limbs(&plain->_poly), it->second, words);
+      plain->_poly._is_ntt = true;
+    }
+  } else {
+    rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+  }
   rt::ctx().weight_plain_cnt++;
   rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }

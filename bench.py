@@ -214,8 +214,27 @@ def main():
     elapsed = ranks.max_over_ranks(elapsed_local)
     value = world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    cache_run = None
     if use_model:
         fhe.Finalize_context()
+        if world == 1:
+            # secondary, NOT the headline: the same workload with the encoded weight plaintexts kept in HBM
+            # (ACEHIP_PT_CACHE=1, 12.3 GB; the reference's pre-encoded DE_PLAINTEXT mode)
+            os.environ["ACEHIP_PT_CACHE"] = "1"
+            fhe.Prepare_context()
+            step()  # fills the cache
+            rt.sync()
+            tc = time.perf_counter()
+            for _ in range(2):
+                step()
+            rt.sync()
+            dt = (time.perf_counter() - tc) / 2
+            fhe.Finalize_context()
+            os.environ["ACEHIP_PT_CACHE"] = "0"
+            cache_run = {"images_per_s": round(1.0 / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
+                         "note": "ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB); "
+                                 "reported beside the headline, which encodes all 6044 plaintexts for every image "
+                                 "like the reference run does"}
 
     # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
     n_polys = 2 * N_CT
@@ -282,6 +301,8 @@ def main():
             "calls_per_step": {k: round(v[0] / args.steps, 1) for k, v in stats.items() if v[0]},
             "GB_per_step": {k: round(v[2] / args.steps / 1e9, 2) for k, v in stats.items() if v[2]},
             "note": "sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) / wall time"}
+        if cache_run is not None:
+            out["with_plaintext_cache"] = cache_run
         if logits is not None:
             out["config"]["last_logits"] = [round(v, 5) for v in logits]
         if world == 1 and not args.no_cpu_baseline:
