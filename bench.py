@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["auto", "resnet20", "keyswitch"], default="auto")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
+                         "launch of the process then has the timed batch's size)")
     args = ap.parse_args()
 
     # the runtime library prints the reference's stdout contract ([RT_STAT] ..., ckks_param: ...) from C;
@@ -122,7 +125,8 @@ def main():
     import numpy as np
 
     bmod = sys.modules["ace_compiler_amd.build"]
-    use_model = args.workload != "keyswitch" and os.path.exists(MODEL_LIB) and os.path.exists(bmod.RT_LIB)
+    use_model = (args.workload != "keyswitch" and not args.roofline_only and os.path.exists(MODEL_LIB) and
+                 os.path.exists(bmod.RT_LIB))
     if args.workload == "resnet20" and not use_model:
         raise SystemExit("bench: %s or libFHErt_ant.so missing (build with tools/build_models.py / __graft_entry__.build())" % MODEL_LIB)
 
@@ -191,6 +195,12 @@ def main():
         workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
                     "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
                     "N(0,0.05); one image per step per GPU")
+    elif args.roofline_only:
+        def step():
+            return None
+
+        unit, metric = "steps/s", "none (--roofline-only: see roofline)"
+        workload = "--roofline-only: no headline workload was run"
     else:
         def step():
             ks()
@@ -264,9 +274,10 @@ def main():
     limbs = n_polys * T
     bytes_per_dir = 16 * N * limbs  # algorithmic: read + write every limb once
 
-    for _ in range(3):
-        ks()
-    ks_ms = rt.time_ms(ks, 20)
+    if not args.roofline_only:
+        for _ in range(3):
+            ks()
+    ks_ms = rt.time_ms(ks, 20) if not args.roofline_only else float("nan")
     ks_bytes = lib.acehip_key_switch_bytes(h, L)
 
     if rank == 0:
@@ -305,7 +316,10 @@ def main():
             out["with_plaintext_cache"] = cache_run
         if logits is not None:
             out["config"]["last_logits"] = [round(v, 5) for v in logits]
-        if world == 1 and not args.no_cpu_baseline:
+        if args.roofline_only:
+            out.pop("key_switch")
+            out.pop("workload_roofline")
+        if world == 1 and not args.no_cpu_baseline and not args.roofline_only:
             out["cpu_baseline"] = cpu_baseline(use_model)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
