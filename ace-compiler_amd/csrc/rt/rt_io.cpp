@@ -187,6 +187,7 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
 // sources name /app/release/...); ACEHIP_RT_DATA_SYNTH=1 replaces the file by deterministic synthetic
 // weights N(0, 0.05) (there is no weight file in the reference tree: SURVEY 8d, C4).
 static bool g_pt_synth = false;
+static double g_pt_synth_sigma = 0.05;  // ACEHIP_RT_DATA_SYNTH_SIGMA overrides
 static float* synth_entry(uint32_t index, size_t len) {
   static thread_local std::vector<float> buf;
   buf.resize(len);
@@ -196,7 +197,7 @@ static float* synth_entry(uint32_t index, size_t len) {
     const double u1 = ((z >> 11) + 1.0) / 9007199254740993.0;
     z ^= z << 13; z ^= z >> 7; z ^= z << 17;
     const double u2 = (z >> 11) / 9007199254740992.0;
-    const double r = sqrt(-2.0 * log(u1)) * 0.05;
+    const double r = sqrt(-2.0 * log(u1)) * g_pt_synth_sigma;
     buf[i] = (float)(r * cos(2 * M_PI * u2));
     if (i + 1 < len) buf[i + 1] = (float)(r * sin(2 * M_PI * u2));
   }
@@ -208,6 +209,7 @@ bool Pt_mgr_init(const char* fname) {
   if (const char* e = getenv("ACEHIP_RT_DATA_SYNTH")) {
     if (atoi(e) != 0) {
       g_pt_synth = true;
+      if (const char* sg = getenv("ACEHIP_RT_DATA_SYNTH_SIGMA")) g_pt_synth_sigma = atof(sg);
       g_pt.open = true;
       return true;
     }

@@ -17,6 +17,7 @@ SETS=(
  "c1_n16384_l4    16384 4  60 50 2"
  "bl_n65536_l25   65536 25 60 56 4"
  "rn_n65536_l34   65536 34 51 50 3"
+ "r110_n65536_l34 65536 34 51 48 3"
 )
 for s in "${SETS[@]}"; do
   set -- $s
@@ -37,6 +38,7 @@ OPS=(
  "bl_n65536_l25_lv25 65536 25 60 56 4 25 11"
  "bl_n65536_l25_lv17 65536 25 60 56 4 17 12"
  "rn_n65536_l34_lv34 65536 34 51 50 3 34 13"
+ "r110_n65536_l34_lv21 65536 34 51 48 3 21 14"
 )
 for s in "${OPS[@]}"; do
   set -- $s

@@ -75,3 +75,24 @@ def test_resnet20_logits_match_reference_cpu_run(tmp_path):
     assert max(abs(a - b) for a, b in zip(got, ref)) <= 2e-4, (got, ref)
     assert "rot_key_cnt = 227," in r.stdout            # same rotation-key set as the reference log
     assert "Total memory size for weight plain: cnt = 6044," in r.stdout
+
+
+@pytest.mark.parametrize("cfg", ["4096 33 51 50 3 192 2048 15", "4096 33 51 48 3 192 2048 15", "4096 33 51 48 3 192 512 17"],
+                         ids=["delta50_full", "delta48_full", "delta48_sparse"])
+def test_bootstrap_at_generated_model_parameters(tmp_path, cfg):
+    """Bootstrap at the prime sizes the generated ResNets use (q0=51 with Delta=50: ResNet-20/32, Delta=48: ResNet-110),
+    fully and sparsely packed, through tests/c/bootstrap_params.c (encrypt, burn levels down to 2 limbs, Bootstrap,
+    decrypt, compare with the reference examples' tolerance 1e-3).  The reference's own bootstrap examples only cover
+    q0=60/Delta=51 at N=16."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "bootstrap_params")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-O1", os.path.join(ROOT, "tests", "c", "bootstrap_params.c"), "-I", inc, "-I",
+                           os.path.join(inc, "rt_ant"), "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm",
+                           "-Wl,-rpath," + bmod.LIBDIR, "-o", exe])
+    r = subprocess.run([exe] + cfg.split(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
