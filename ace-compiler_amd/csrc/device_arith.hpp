@@ -48,8 +48,11 @@ __device__ __forceinline__ u64 mul_shoup_lazy(u64 a, u64 w, u64 wp, u64 q) {
 // a*b mod q for a,b < q < 2^61: single-word Barrett on the shifted product.
 //   x = a*b < 2^(2n); x1 = x >> (n-1); qhat = mulhi(x1, mu << (63-n)) = floor(x1*mu / 2^(n+1));
 //   x - qhat*q in [0, 3q)
+// (full products are written as one unsigned __int128 multiply: the compiler then emits 4 v_mad_u64_u32 and shares
+// the partial products between the halves; a separate a*b and __umul64hi(a,b) costs 2 extra quarter-rate v_mul_lo_u32)
 __device__ __forceinline__ u64 mul_mod(u64 a, u64 b, u64 q, u64 mu, u32 nbits) {
-  u64 lo = a * b, hi = mulhi64(a, b);
+  const unsigned __int128 p = (unsigned __int128)a * b;
+  u64 lo = (u64)p, hi = (u64)(p >> 64);
   u32 sh = nbits - 1;
   u64 x1 = (hi << (64 - sh)) | (lo >> sh);
   u64 qh = mulhi64(x1, mu);
@@ -66,22 +69,19 @@ struct U128 {
   u64 lo, hi;
 };
 __device__ __forceinline__ void mac128(U128& acc, u64 a, u64 b) {
-  u64 plo = a * b, phi = mulhi64(a, b);
-  u64 lo = acc.lo + plo;
-  acc.hi += phi + (lo < plo ? 1 : 0);
-  acc.lo = lo;
+  unsigned __int128 v = ((unsigned __int128)acc.hi << 64) | acc.lo;
+  v += (unsigned __int128)a * b;
+  acc.lo = (u64)v;
+  acc.hi = (u64)(v >> 64);
 }
 
 // (hi:lo) mod q with mu = floor(2^128/q) = (mh:ml); same quotient estimate as the reference's
 // Mod_barrett_128 (fhe_utils.h:241-280); the estimate is at most 2 below the true quotient.
 __device__ __forceinline__ u64 reduce128(U128 v, u64 q, u64 ml, u64 mh) {
-  u64 left_h = mulhi64(v.lo, ml);
-  u64 mid_l = v.lo * mh, mid_h = mulhi64(v.lo, mh);
-  u64 t1 = mid_l + left_h;
-  u64 t2 = mid_h + (t1 < left_h ? 1 : 0);
-  u64 m2_l = v.hi * ml, m2_h = mulhi64(v.hi, ml);
-  u64 carry = (m2_l + t1) < t1 ? 1 : 0;
-  u64 qhat = v.hi * mh + t2 + m2_h + carry;
+  // qhat = floor( (v.hi:v.lo) * (mh:ml) / 2^128 ) up to the dropped low partial product
+  const unsigned __int128 mid = (unsigned __int128)v.lo * mh + mulhi64(v.lo, ml);  // < 2^128
+  const unsigned __int128 m2 = (unsigned __int128)v.hi * ml + (u64)mid;            // carries into bit 64
+  u64 qhat = v.hi * mh + (u64)(mid >> 64) + (u64)(m2 >> 64);
   u64 r = v.lo - qhat * q;
   while (r >= q) r -= q;
   return r;
