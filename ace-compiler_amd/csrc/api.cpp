@@ -866,6 +866,42 @@ int acehip_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64
   return do_mod_down_n(c, out0, out1, in0, in1, level, (hipStream_t)s);
 }
 
+// ModRaise of bootstrapping (Transform_values_from_level0 ckks_bootstrap_context.c:1527-1551): limb 0 of each
+// polynomial (NTT domain) -> coefficient domain -> centred lift -> residues on `level_out` limbs -> NTT domain
+int acehip_mod_raise(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in0, const uint64_t* in1,
+                     uint32_t level_out, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  if (level_out == 0 || level_out > c->hp.L || !out0 || !in0 || (in1 != nullptr) != (out1 != nullptr))
+    return fail(ACEHIP_EINVAL, "acehip_mod_raise: bad arguments");
+  const HostParams& hp = c->hp;
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = hp.N;
+  const u32 np = in1 ? 2 : 1;
+  u64* last = ws_at(c, 0);  // [np][N]
+  if (c->dc.logN == 16) {
+    NttFuse fi;
+    fi.src0 = in0;
+    fi.src1 = in1;
+    fi.center_out = true;
+    launch_ntt_fused(c->dc, last, hp.L, 0, 1, true, s, 0, np, N, 0, fi);
+    NttFuse fo;
+    fo.msg = (const int64_t*)last;
+    fo.msg_stride = N;
+    launch_ntt_fused(c->dc, out0, level_out, 0, level_out, false, s, 0, np, (size_t)(out1 - out0), 0, fo);
+  } else {
+    for (u32 z = 0; z < np; ++z) {
+      HIP_TRY(hipMemcpyAsync(last + z * N, z ? in1 : in0, N * sizeof(u64), hipMemcpyDeviceToDevice, s));
+      launch_ntt(c->dc, last + z * N, hp.L, 0, 1, true, s);
+      launch_center(c->dc, (int64_t*)(last + z * N), last + z * N, 0, s);
+      u64* out = z ? out1 : out0;
+      launch_values_to_rns(c->dc, out, (const int64_t*)(last + z * N), level_out, 0, level_out, s);
+      launch_ntt(c->dc, out, level_out, 0, level_out, false, s);
+    }
+  }
+  stat(ST_RESCALE, np, 8ull * N * (1 + level_out) * np);
+  return post_launch();
+}
+
 // one or two polynomials (c0, c1 of a ciphertext) through Rescale_poly in the same launches
 static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s) {
   const HostParams& hp = c->hp;
@@ -881,13 +917,19 @@ static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const
   }
   cp.seg_start[np] = (uint16_t)np;
   const size_t row = (size_t)(level - 2) * hp.L;
-  if (c->dc.logN == 16) {  // fused: iNTT reads the last limbs in place of a copy, the forward NTT applies the tail
+  if (c->dc.logN == 16) {
+    // fused: the iNTT reads the last limbs where they lie and leaves their centred lift; the forward NTT of the
+    // remaining limbs starts from that lift (modulus switch and constant folded into its first pass) and applies
+    // the Rescale tail in its last pass: 4 launches, no intermediate polynomial in memory
     NttFuse fi;
     fi.src0 = in0 + (size_t)(level - 1) * N;
     fi.src1 = in1 ? in1 + (size_t)(level - 1) * N : nullptr;
+    fi.center_out = true;
     launch_ntt_fused(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N, 0, fi);
-    launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
     NttFuse fo;
+    fo.msg = (const int64_t*)last;
+    fo.msg_stride = N;
+    fo.msg_scale = c->qlql + row;
     fo.epi = 1;
     fo.out0 = out0;
     fo.out1 = out1;

@@ -56,7 +56,11 @@ struct NttFuse {
   // forward, first pass: every limb starts from the same signed message, reduced mod its prime and multiplied by
   // scale[pos] when given (Encode_impl ckks_encoder.c:262-285)
   const int64_t* msg = nullptr;
+  size_t msg_stride = 0;          // polynomial z reads msg + z*msg_stride
   const u64* msg_scale = nullptr;
+  // inverse, last pass: store the centred representative (x > q/2 ? x - q : x, as int64) instead of x, i.e. the
+  // `msg` of a following forward transform over other primes (Rescale, ModRaise)
+  bool center_out = false;
   // forward, last pass: v = NTT value; 1: out = x*w + v (Rescale tail polynomial.c:1145-1158),
   // 2: out = (x - v)*w (ModDown tail :956-965); x_z, out_z are polynomials of q-limbs, w/wp per limb
   int epi = 0;
@@ -110,6 +114,7 @@ void launch_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, c
                          const u64* inv, const u64* invp, u32 level, u32 n_polys, hipStream_t s);
 // ---- setup-side kernels (keygen / encode), rt_kernels.hip ----
 // out[pos][n] = vals[n] mod prime(pos) for signed 64-bit vals (Transform_values_to_rns polynomial.c:362-392)
+void launch_center(const DevCtx& c, int64_t* out, const u64* in, u32 gi, hipStream_t s);
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // uniform residues from a counter-based generator (Sample_uniform_poly polynomial.c:1349-1371)
 void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
       const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int64_t v = f.msg[((size_t)(16 * k + hg) << log_s) + col];
+        const int64_t v = f.msg[blockIdx.z * f.msg_stride + ((size_t)(16 * k + hg) << log_s) + col];
         const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
         u64 r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
         if (v < 0 && r != 0) r = q - r;
@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
       u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);
       x[k] = a >= q ? a - q : a;
       x[k + 8] = b >= q ? b - q : b;
+    }
+    if (f.center_out) {
+      const u64 half = q >> 1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = x[k] > half ? x[k] - q : x[k];  // two's complement of the negative lift
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[((size_t)(16 * k + hg) << log_s) + col] = x[k];

@@ -166,8 +166,8 @@ void rescale(Ct& r, Ct& a) {
   RT_ASSERT(a.np() == 0, "rescale: extended operand");
   Ct out;
   init(out, l - 1, 0, a.c._scaling_factor / c.sf, a.c._sf_degree - 1, a.c._slots);
-  HIPCHK(acehip_rescale(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&a.c._c0_poly), l, nullptr));
-  HIPCHK(acehip_rescale(c.hip, q_limbs(&out.c._c1_poly), q_limbs(&a.c._c1_poly), l, nullptr));
+  HIPCHK(acehip_rescale2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&a.c._c0_poly),
+                         q_limbs(&a.c._c1_poly), l, nullptr));
   r.take(out);
 }
 

@@ -80,7 +80,8 @@ struct Context {
   // statistics
   size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
   bool profile = false;                          // ACEHIP_PROFILE=1: host-side timers below are printed
-  double t_encode = 0, t_main = 0, t_issue = 0;
+  double t_encode = 0, t_main = 0, t_issue = 0, t_bootstrap = 0;
+  size_t n_bootstrap = 0;
 };
 
 extern Context* g_ctx;

@@ -18,6 +18,17 @@ __global__ __launch_bounds__(256) void values_to_rns_kernel(DevCtx c, u64* __res
   out[(size_t)pos * c.N + n] = r;
 }
 
+// out[n] = centred representative of in[n] mod prime gi (as int64); in place allowed
+__global__ __launch_bounds__(256) void center_kernel(DevCtx c, int64_t* __restrict__ out, const u64* __restrict__ in, u32 gi) {
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= c.N) return;
+  const u64 q = c.primes[gi].q, v = in[n];
+  out[n] = (int64_t)(v > (q >> 1) ? v - q : v);
+}
+void launch_center(const DevCtx& c, int64_t* out, const u64* in, u32 gi, hipStream_t s) {
+  hipLaunchKernelGGL(center_kernel, dim3((c.N + 255) / 256), dim3(256), 0, s, c, out, in, gi);
+}
+
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
   if (n_limbs == 0) return;
   dim3 grid((c.N + 255) / 256, n_limbs), block(256);

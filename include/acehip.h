@@ -150,6 +150,10 @@ int acehip_decomp_modup(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, 
 int acehip_mod_down(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 
+/* ModRaise of bootstrapping (Transform_values_from_level0 ckks_bootstrap_context.c:1527-1551): limb 0 of d_in0
+ * (and d_in1, may both be NULL with d_out1) in the NTT domain is taken to the coefficient domain, lifted to its
+ * centred representative and spread to `level_out` limbs (NTT domain) at d_out0 / d_out1. */
+int acehip_mod_raise(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in0, const uint64_t* d_in1, uint32_t level_out, acehip_stream stream);
 /* Mod_down / Rescale of the two polynomials of a ciphertext in the same launches (generated code calls
  * Mod_down(c0); Mod_down(c1) and Rescale(c0); Rescale(c1) back to back: resnet20_cifar10_pre.onnx.inc:7035-7036,
  * :1552-1553).  Results are those of the single-polynomial calls. */

@@ -299,3 +299,36 @@ def test_fused_ntt_paths_n65536():
     finally:
         rt.close()
         o.close()
+
+
+@pytest.mark.parametrize("cfg", [(64, 7, 60, 51, 3, 6), (8192, 4, 60, 50, 2, 4), (65536, 5, 51, 50, 2, 4)], ids=["n64", "n8192", "n65536"])
+def test_mod_raise(cfg):
+    """acehip_mod_raise (bootstrap ModRaise, ckks_bootstrap_context.c:1527-1551) against the oracle: iNTT of limb 0, centred
+    lift, reduction mod every prime of the raised level, NTT -- generic path (small N) and the fused N=2^16 path."""
+    N, L, q0, sf, dnum, lv = cfg
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        a0, a1 = o.uniform(1, 1, 301), o.uniform(1, 1, 302)
+        want = []
+        for a in (a0, a1):
+            coef = o.ntt_inv(a, [0])[0]
+            q = np.uint64(o.primes[0])
+            neg = coef > (q >> np.uint64(1))
+            rows = np.empty((lv, N), dtype=np.uint64)
+            for l in range(lv):
+                ql = np.uint64(o.primes[l])
+                pos = coef % ql
+                rows[l] = np.where(neg, (ql - ((q - coef) % ql)) % ql, pos)
+            want.append(o.ntt_fwd(rows, list(range(lv))))
+        d0, d1, r = rt.to_device(a0), rt.to_device(a1), rt.buf(2 * lv * N)
+        rt.check(rt.lib.acehip_mod_raise(rt.h, r.at(0), r.at(lv * N), d0.ptr, d1.ptr, lv, None))
+        got = r.download((2, lv, N))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        rt.check(rt.lib.acehip_mod_raise(rt.h, r.at(0), None, d1.ptr, None, lv, None))   # single polynomial form
+        assert np.array_equal(r.download((2, lv, N))[0], want[1])
+        for d in (d0, d1, r):
+            d.free()
+    finally:
+        rt.close()
+        o.close()
