@@ -438,7 +438,7 @@ void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool 
   const u32 k = ensure_rot_key(rotation);
   SwitchKeyStore* key = ensure_auto_key(k);
   Ct tmp;
-  ev::init(tmp, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots);
+  ev::init(tmp, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots, false);  // the inner product writes every limb
   u64 *t0 = q_limbs(&tmp.c._c0_poly), *t1 = q_limbs(&tmp.c._c1_poly);
   HIPCHK(acehip_key_inner_product(c.hip, t0, t1, key->data, digits, l, nullptr));
   if (add_first) {
@@ -448,7 +448,7 @@ void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool 
     q_ew(ACEHIP_HW_ADD, t0, t0, psi, l, 0, l);
     dfree(psi);
   }
-  ev::init(rot, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots);
+  ev::init(rot, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots, false);  // the automorphism writes every limb
   const uint32_t* perm = acehip_auto_order(c.hip, k);
   q_rotate(q_limbs(&rot.c._c0_poly), t0, perm, l, 0, l + c.K);
   q_rotate(q_limbs(&rot.c._c1_poly), t1, perm, l, 0, l + c.K);
@@ -545,7 +545,7 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
   }
   poly_add_ext(&outer.c._c0_poly, &outer.c._c0_poly, &first);
   Ct out;
-  ev::init(out, l, 0, outer.c._scaling_factor, outer.c._sf_degree, outer.c._slots);
+  ev::init(out, l, 0, outer.c._scaling_factor, outer.c._sf_degree, outer.c._slots, false);
   HIPCHK(acehip_mod_down2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&outer.c._c0_poly),
                           q_limbs(&outer.c._c1_poly), l, nullptr));
   poly_free(&first);
@@ -924,7 +924,7 @@ void bootstrap(Ct& res, Ct& ciph, u32 raise_level) {
   RT_ASSERT(raise_level <= c.L, "The raise level must be less than or equal to q_cnt");
   // ModRaise: limb 0 (coefficient domain) spread to raise_level limbs, centred (Transform_values_from_level0 :1527-1551)
   Ct nc;
-  ev::init(nc, raise_level, 0, raised.c._scaling_factor, raised.c._sf_degree, slots);
+  ev::init(nc, raise_level, 0, raised.c._scaling_factor, raised.c._sf_degree, slots, false);
   HIPCHK(acehip_mod_raise(c.hip, q_limbs(&nc.c._c0_poly), q_limbs(&nc.c._c1_poly), q_limbs(&raised.c._c0_poly),
                           q_limbs(&raised.c._c1_poly), raise_level, nullptr));
   nc.c._c0_poly._is_ntt = nc.c._c1_poly._is_ntt = true;

@@ -52,7 +52,7 @@ void embedding(std::vector<cplx>& vals) {
 }
 
 // Init_plaintext plaintext.h:114-129
-void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree) {
+void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree, bool zero) {
   Context& c = ctx();
   p->_scaling_factor = sf;
   p->_sf_degree = sf_degree;
@@ -60,7 +60,7 @@ void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u3
   POLYNOMIAL* poly = &p->_poly;
   if (poly->_data == nullptr || (poly->_num_primes + poly->_num_primes_p) == 0) {
     if (poly->_data) poly_free(poly);
-    poly_alloc(poly, c.N, nq, np);
+    poly_alloc(poly, c.N, nq, np, zero);
   } else {
     RT_ASSERT(poly->_num_primes == nq && poly->_num_primes_p == np, "unmatched size");
   }
@@ -125,7 +125,7 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
   RT_ASSERT(len <= slots, "slot size is too small");
   RT_ASSERT(slots <= N / 2, " slot size > N/2 ");
   RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
-  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree);
+  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
   POLYNOMIAL* poly = &res->_poly;
   HIPCHK(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level,
                        p_cnt, nullptr));

@@ -27,7 +27,8 @@ struct Ct {
 };
 
 namespace ev {
-void init(Ct& r, u32 nq, u32 np, double sf, u32 sf_degree, u32 slots);   // fresh zeroed polys
+// fresh polys, zeroed unless the caller overwrites every limb right away (zero = false)
+void init(Ct& r, u32 nq, u32 np, double sf, u32 sf_degree, u32 slots, bool zero = true);
 void copy(Ct& r, const Ct& a);
 void from_ciph(Ct& r, CIPHER a);        // deep copy of a caller-owned ciphertext
 void to_ciph(CIPHER r, Ct& a);          // move a into caller-owned r (frees r's old polys)

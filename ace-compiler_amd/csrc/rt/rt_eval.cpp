@@ -15,10 +15,10 @@ static void set_meta(Ct& r, double sf, u32 deg, u32 slots) {
   r.c._slots = slots;
 }
 
-void init(Ct& r, u32 nq, u32 np, double sf, u32 sf_degree, u32 slots) {
+void init(Ct& r, u32 nq, u32 np, double sf, u32 sf_degree, u32 slots, bool zero) {
   r.reset();
-  poly_alloc(&r.c._c0_poly, ctx().N, nq, np);
-  poly_alloc(&r.c._c1_poly, ctx().N, nq, np);
+  poly_alloc(&r.c._c0_poly, ctx().N, nq, np, zero);
+  poly_alloc(&r.c._c1_poly, ctx().N, nq, np, zero);
   r.c._c0_poly._is_ntt = r.c._c1_poly._is_ntt = true;
   set_meta(r, sf, sf_degree, slots);
 }
@@ -26,13 +26,13 @@ void init(Ct& r, u32 nq, u32 np, double sf, u32 sf_degree, u32 slots) {
 void copy(Ct& r, const Ct& a) {
   if (&r == &a) return;
   Ct& aa = const_cast<Ct&>(a);
-  init(r, a.level(), a.np(), a.c._scaling_factor, a.c._sf_degree, a.c._slots);
+  init(r, a.level(), a.np(), a.c._scaling_factor, a.c._sf_degree, a.c._slots, false);
   poly_copy(&r.c._c0_poly, &aa.c._c0_poly);
   poly_copy(&r.c._c1_poly, &aa.c._c1_poly);
 }
 
 void from_ciph(Ct& r, CIPHER a) {
-  init(r, (u32)a->_c0_poly._num_primes, (u32)a->_c0_poly._num_primes_p, a->_scaling_factor, a->_sf_degree, a->_slots);
+  init(r, (u32)a->_c0_poly._num_primes, (u32)a->_c0_poly._num_primes_p, a->_scaling_factor, a->_sf_degree, a->_slots, false);
   poly_copy(&r.c._c0_poly, &a->_c0_poly);
   poly_copy(&r.c._c1_poly, &a->_c1_poly);
 }
@@ -165,7 +165,7 @@ void rescale(Ct& r, Ct& a) {
   RT_ASSERT(l > 1, "rescale: multiply level is not big enought for more operation, try to use larger depth");
   RT_ASSERT(a.np() == 0, "rescale: extended operand");
   Ct out;
-  init(out, l - 1, 0, a.c._scaling_factor / c.sf, a.c._sf_degree - 1, a.c._slots);
+  init(out, l - 1, 0, a.c._scaling_factor / c.sf, a.c._sf_degree - 1, a.c._slots, false);
   HIPCHK(acehip_rescale2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&a.c._c0_poly),
                          q_limbs(&a.c._c1_poly), l, nullptr));
   r.take(out);

@@ -94,7 +94,8 @@ void pool_release_all();
 size_t pool_bytes_in_use();
 
 // ---- polynomial helpers on POLYNOMIAL structs (device data) ----
-void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np);           // Alloc_poly_data polynomial.h:54
+// Alloc_poly_data polynomial.h:54; zero = false only where the caller overwrites every limb right away
+void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np, bool zero = true);
 void poly_free(POLYNOMIAL* p);                                         // Free_poly_data   :71
 void poly_init_like(POLYNOMIAL* res, POLYNOMIAL* like);                // Init_poly        :331
 void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src);                      // Copy_polynomial
@@ -140,7 +141,7 @@ void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree);
 void decode(std::vector<cplx>& out, PLAINTEXT* plain);
 void encrypt(CIPHERTEXT* res, PLAINTEXT* plain);                       // ckks_encryptor.c:20-95
 void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph);                        // ckks_decryptor.c:19-65
-void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree);
+void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree, bool zero = true);
 
 void bootstrap_setup_if_needed();
 void bootstrap_release();

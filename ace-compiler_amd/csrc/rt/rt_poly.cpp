@@ -181,13 +181,13 @@ double wall_s() {
 }
 
 // ---- POLYNOMIAL helpers ----
-void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np) {
+void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np, bool zero) {
   p->_ring_degree = N;
   p->_num_primes = nq;
   p->_num_primes_p = np;
   p->_num_alloc_primes = nq + np;
   p->_is_ntt = false;
-  p->_data = (int64_t*)dalloc((size_t)(nq + np) * N, true);
+  p->_data = (int64_t*)dalloc((size_t)(nq + np) * N, zero);
 }
 void poly_free(POLYNOMIAL* p) {
   if (p->_data) {
