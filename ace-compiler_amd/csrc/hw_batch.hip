@@ -15,7 +15,9 @@ namespace acehip {
 // limb is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
 // (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run always stores, so
 // every later reader -- in this segment, another launch or the host -- finds the final value in memory).
-__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs args) {
+// CAP: capacity of the argument table (a launch with few ops ships a small kernel-argument block)
+template <int CAP>
+__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs 
 }
 
 // independent gathers r[j] = a[perm[j]] (the host guarantees no result aliases any source of the launch)
-__global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgs args) {
+template <int CAP>
+__global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgsT<CAP> args) {
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= N) return;
   const HwBatchOp op = args.op[blockIdx.y];
@@ -81,16 +84,29 @@ __global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgs
   *reinterpret_cast<ulong2*>(op.res + i) = v;
 }
 
+template <int CAP>
+static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
+  HwBatchArgsT<CAP> r;
+  for (u32 i = 0; i < n_ops; ++i) r.op[i] = a.op[i];
+  for (u32 i = 0; i <= n_seg; ++i) r.seg_start[i] = a.seg_start[i];
+  return r;
+}
+
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
   if (n_seg == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_seg), block(256);
-  hipLaunchKernelGGL(hw_batch_ew_kernel, grid, block, 0, s, c, args);
+  const u32 n_ops = args.seg_start[n_seg];
+  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));
+  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));
+  else hipLaunchKernelGGL(hw_batch_ew_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args);
 }
 
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
   if (n_ops == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_ops), block(256);
-  hipLaunchKernelGGL(hw_batch_rotate_kernel, grid, block, 0, s, c.N, args);
+  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_rotate_kernel<16>, grid, block, 0, s, c.N, shrink<16>(args, n_ops, 0));
+  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_rotate_kernel<48>, grid, block, 0, s, c.N, shrink<48>(args, n_ops, 0));
+  else hipLaunchKernelGGL(hw_batch_rotate_kernel<HW_BATCH_MAX>, grid, block, 0, s, c.N, args);
 }
 
 }  // namespace acehip

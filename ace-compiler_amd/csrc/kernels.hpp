@@ -134,10 +134,12 @@ struct HwBatchOp {
   const u64* b;   // second operand; the u32 automorphism table for HW_OP_ROTATE
   u32 kind, gi;
 };
-struct HwBatchArgs {
-  HwBatchOp op[HW_BATCH_MAX];
-  uint16_t seg_start[HW_BATCH_MAX + 1];  // chain segments of the elementwise kernel: ops [seg_start[y], seg_start[y+1])
+template <int CAP>
+struct HwBatchArgsT {
+  HwBatchOp op[CAP];
+  uint16_t seg_start[CAP + 1];  // chain segments of the elementwise kernel: ops [seg_start[y], seg_start[y+1])
 };
+using HwBatchArgs = HwBatchArgsT<HW_BATCH_MAX>;
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s);
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s);
 // embed.hip: rounded, scaled inverse canonical embedding (device FP64, bit-identical to the reference host code)
