@@ -99,6 +99,56 @@ def cpu_baseline(have_model):
     return res
 
 
+def load_model_runtime(device):
+    """dlopen the generated ResNet-20 (+ the rt_ant drop-in it is linked against) and return (lib, step):
+    step() pushes one synthetic image through Prepare_input / Run_main_graph / Handle_output."""
+    import numpy as np
+
+    os.environ["ACEHIP_DEVICE"] = str(device)
+    os.environ.setdefault("ACEHIP_RT_DATA_SYNTH", "1")
+    # libmodel defines Main_graph + the Get_* callbacks and is linked against libFHErt_ant.so, so one
+    # dlopen resolves both directions of the generated-code <-> runtime boundary
+    fhe = C.CDLL(MODEL_LIB, mode=C.RTLD_GLOBAL)
+    fhe.Alloc_tensor.restype = C.c_void_p
+    fhe.Alloc_tensor.argtypes = [C.c_size_t] * 4 + [C.c_void_p]
+    fhe.Prepare_input.argtypes = [C.c_void_p, C.c_char_p]
+    fhe.Free_tensor.argtypes = [C.c_void_p]
+    fhe.Handle_output.restype = C.POINTER(C.c_double)
+    fhe.Handle_output.argtypes = [C.c_char_p]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    img_rng = np.random.default_rng(1)
+
+    def step():
+        img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
+        t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
+        fhe.Prepare_input(t, b"input")
+        fhe.Free_tensor(t)
+        fhe.Run_main_graph()
+        out = fhe.Handle_output(b"output")
+        vals = [out[i] for i in range(10)]
+        libc.free(out)
+        return vals
+
+    return fhe, step
+
+
+def stream_worker(rfd, wfd, device):
+    """one extra image stream on the same GPU (its own process, context and keys -- the reference runs one
+    OpenMP thread per image, resnet_cifar.main.inc:77-116): 'S' = run one image, anything else = quit"""
+    os.dup2(2, 1)
+    fhe, step = load_model_runtime(device)
+    fhe.Prepare_context()
+    os.write(wfd, b"R")
+    while True:
+        cmd = os.read(rfd, 1)
+        if cmd != b"S":
+            break
+        step()
+        os.write(wfd, b"D")
+    fhe.Finalize_context()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +159,14 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="concurrent image streams per GPU for the ResNet headline (one process each); 1 = a single stream")
+    ap.add_argument("--stream-worker", default=None, help=argparse.SUPPRESS)  # "rfd,wfd,device": internal
     args = ap.parse_args()
+    if args.stream_worker:
+        rfd, wfd, device = (int(x) for x in args.stream_worker.split(","))
+        stream_worker(rfd, wfd, device)
+        return
 
     # the runtime library prints the reference's stdout contract ([RT_STAT] ..., ckks_param: ...) from C;
     # keep fd 1 clean for the ONE JSON line: route everything else to stderr
@@ -118,6 +175,21 @@ def main():
 
     import ace_compiler_amd as A
     from ace_compiler_amd.dist import Ranks
+
+    bmod0 = sys.modules["ace_compiler_amd.build"]
+    want_model = (args.workload != "keyswitch" and not args.roofline_only and os.path.exists(MODEL_LIB) and
+                  os.path.exists(bmod0.RT_LIB))
+    workers = []  # (Popen, fd to write commands, fd to read replies); started before this process touches the GPU
+    if want_model:
+        for _ in range(max(args.streams, 1) - 1):
+            c2w_r, c2w_w = os.pipe()
+            w2c_r, w2c_w = os.pipe()
+            pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stream-worker",
+                                   "%d,%d,%s" % (c2w_r, w2c_w, os.environ.get("LOCAL_RANK", "0"))],
+                                  pass_fds=(c2w_r, w2c_w), stdout=2)
+            os.close(c2w_r)
+            os.close(w2c_w)
+            workers.append((pr, c2w_w, w2c_r))
 
     ranks = Ranks()  # one process per GPU; RCCL ("nccl") carries only the barrier and the max over ranks
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
@@ -163,38 +235,26 @@ def main():
         rt.check(lib.acehip_key_switch(h, o0.ptr, o1.ptr, a.ptr, key.ptr, L, None))
 
     logits = None
+    n_streams = 1 + len(workers)
     if use_model:
-        os.environ["ACEHIP_DEVICE"] = str(local_rank)
-        os.environ.setdefault("ACEHIP_RT_DATA_SYNTH", "1")
-        # libmodel defines Main_graph + the Get_* callbacks and is linked against libFHErt_ant.so, so one
-        # dlopen resolves both directions of the generated-code <-> runtime boundary
-        fhe = C.CDLL(MODEL_LIB, mode=C.RTLD_GLOBAL)
-        fhe.Alloc_tensor.restype = C.c_void_p
-        fhe.Alloc_tensor.argtypes = [C.c_size_t] * 4 + [C.c_void_p]
-        fhe.Prepare_input.argtypes = [C.c_void_p, C.c_char_p]
-        fhe.Free_tensor.argtypes = [C.c_void_p]
-        fhe.Handle_output.restype = C.POINTER(C.c_double)
-        fhe.Handle_output.argtypes = [C.c_char_p]
-        libc = C.CDLL(None)
-        libc.free.argtypes = [C.c_void_p]
+        fhe, one_image = load_model_runtime(local_rank)
         fhe.Prepare_context()
-        img_rng = np.random.default_rng(1)
+        for _, _, rf in workers:
+            assert os.read(rf, 1) == b"R", "an image-stream worker failed to start"
 
-        def step():
-            img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
-            t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
-            fhe.Prepare_input(t, b"input")
-            fhe.Free_tensor(t)
-            fhe.Run_main_graph()
-            out = fhe.Handle_output(b"output")
-            vals = [out[i] for i in range(10)]
-            libc.free(out)
+        def step():  # one image on every stream of this GPU, concurrently
+            for _, wf, _ in workers:
+                os.write(wf, b"S")
+            vals = one_image()
+            for _, _, rf in workers:
+                assert os.read(rf, 1) == b"D", "an image-stream worker died"
             return vals
 
         unit, metric = "images/s", "encrypted images/sec (ResNet-20 CIFAR-10, N=2^16)"
         workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
                     "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
-                    "N(0,0.05); one image per step per GPU")
+                    "N(0,0.05); %d concurrent image streams per GPU (one process, context and key set each -- the reference's "
+                    "own parallel axis is one OpenMP thread per image), one image per stream per step" % n_streams)
     elif args.roofline_only:
         def step():
             return None
@@ -222,9 +282,16 @@ def main():
     stats = read_stats(reset=False)
     barrier()
     elapsed = ranks.max_over_ranks(elapsed_local)
-    value = world * args.steps / elapsed
+    value = world * n_streams * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
+    for pr, wf, rf in workers:  # the extra streams leave the GPU before the micro workloads are timed
+        os.write(wf, b"Q")
+    for pr, wf, rf in workers:
+        pr.wait()
+        os.close(wf)
+        os.close(rf)
+    step = one_image if use_model else step
     if use_model:
         fhe.Finalize_context()
         if world == 1:
@@ -242,7 +309,7 @@ def main():
             fhe.Finalize_context()
             os.environ["ACEHIP_PT_CACHE"] = "0"
             cache_run = {"images_per_s": round(1.0 / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
-                         "note": "ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB); "
+                         "note": "single stream, ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB); "
                                  "reported beside the headline, which encodes all 6044 plaintexts for every image "
                                  "like the reference run does"}
 
@@ -290,7 +357,8 @@ def main():
             "metric": metric, "value": round(value, 6), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload, "N": 65536, "parallelism": "replicas x%d (one image stream per GPU)" % world},
+            "config": {"workload": workload, "N": 65536, "streams_per_gpu": n_streams, "images_per_step": world * n_streams,
+                       "parallelism": "replicas: %d GPU(s) x %d image stream(s) per GPU" % (world, n_streams)},
             "roofline": {"bound": "hbm",
                          "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -307,11 +375,13 @@ def main():
         # whole-workload view: algorithmic bytes of every entry-point call of the timed region on this rank
         alg = sum(v[2] for v in stats.values())
         out["workload_roofline"] = {
-            "algorithmic_bytes_per_step": int(alg / args.steps), "achieved_GBs": round(alg / elapsed_local / 1e9, 2),
-            "frac_of_hbm_peak": round(alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_image": int(alg / args.steps),
+            "achieved_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
+            "frac_of_hbm_peak": round(n_streams * alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
             "calls_per_step": {k: round(v[0] / args.steps, 1) for k, v in stats.items() if v[0]},
             "GB_per_step": {k: round(v[2] / args.steps / 1e9, 2) for k, v in stats.items() if v[2]},
-            "note": "sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) / wall time"}
+            "note": "sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) of one "
+                    "stream, times the streams of the GPU, / wall time"}
         if cache_run is not None:
             out["with_plaintext_cache"] = cache_run
         if logits is not None:
