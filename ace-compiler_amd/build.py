@@ -34,8 +34,10 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    # -fgpu-default-stream=per-thread: the NULL stream of every entry point is the calling thread's own stream, so
+    # host threads that each own a context (one image stream each) run concurrently on the GPU
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-fgpu-default-stream=per-thread", "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

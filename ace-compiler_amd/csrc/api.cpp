@@ -345,7 +345,7 @@ int acehip_event_destroy(void* e) {
 enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_COUNT };
 static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
                                                 "mod_down", "rescale", "key_switch", "encode"};
-static acehip_stat g_stat[ST_COUNT];
+static thread_local acehip_stat g_stat[ST_COUNT];  // per host thread (= per image stream)
 static inline void stat(int k, u64 units, u64 bytes) {
   g_stat[k].calls++;
   g_stat[k].units += units;

@@ -58,7 +58,7 @@ struct Precom {
   std::vector<std::vector<PLAINTEXT*>> u0hatt_fft, u0_fft;
   bool keys = false;
 };
-std::map<u32, Precom*> g_precom;
+thread_local std::map<u32, Precom*> g_precom;
 
 // Reduce_rotation :220-233
 u32 reduce_rotation(int32_t index, u32 slots) {

@@ -78,7 +78,8 @@ struct StageRing {
   char* dev = nullptr;
   void* ev[SLOTS] = {};
   int next = 0;
-} g_ring;
+};
+thread_local StageRing g_ring;
 }  // namespace
 
 const void* stage_to_device(const void* src, size_t bytes) {

@@ -187,7 +187,7 @@ void mul_integer(Ct& r, Ct& a, u64 k) {
 }
 
 // NTT of +-x^index over all q-limbs, cached per power (Mul_by_monomial :237-264)
-static std::map<u32, u64*> g_monomials;
+static thread_local std::map<u32, u64*> g_monomials;
 void mul_monomial(Ct& r, Ct& a, u32 power) {
   Context& c = ctx();
   RT_ASSERT(a.np() == 0, "Mul_by_monomial: extended operand");

@@ -84,7 +84,7 @@ struct Context {
   size_t n_bootstrap = 0;
 };
 
-extern Context* g_ctx;
+extern thread_local Context* g_ctx;
 Context& ctx();
 
 // ---- device memory pool (stream-ordered reuse; generated code does thousands of Alloc/Free) ----

@@ -79,7 +79,8 @@ struct PtMgr {
   char* dbuf = nullptr;   // the same bytes resident in HBM: Pt_from_msg encodes straight from here
   std::map<uint32_t, std::pair<float*, size_t>> synth_dev;  // synthetic mode: device copy per entry
   bool open = false;
-} g_pt;
+};
+thread_local PtMgr g_pt;
 
 }  // namespace
 
@@ -186,8 +187,8 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
 // ACEHIP_RT_DATA_FILE overrides the path the compiler baked into Get_rt_data_info() (the checked-in ResNet
 // sources name /app/release/...); ACEHIP_RT_DATA_SYNTH=1 replaces the file by deterministic synthetic
 // weights N(0, 0.05) (there is no weight file in the reference tree: SURVEY 8d, C4).
-static bool g_pt_synth = false;
-static double g_pt_synth_sigma = 0.05;  // ACEHIP_RT_DATA_SYNTH_SIGMA overrides
+static thread_local bool g_pt_synth = false;
+static thread_local double g_pt_synth_sigma = 0.05;  // ACEHIP_RT_DATA_SYNTH_SIGMA overrides
 static float* synth_entry(uint32_t index, size_t len) {
   static thread_local std::vector<float> buf;
   buf.resize(len);
@@ -298,8 +299,8 @@ struct PtKey {
     return std::tie(index, level, scale, len) < std::tie(o.index, o.level, o.scale, o.len);
   }
 };
-static std::map<PtKey, rt::u64*> g_pt_cache;
-static int g_pt_cache_on = -1;
+static thread_local std::map<PtKey, rt::u64*> g_pt_cache;
+static thread_local int g_pt_cache_on = -1;
 static void pt_cache_clear() {
   for (auto& kv : g_pt_cache) acehip_free(kv.second);
   g_pt_cache.clear();

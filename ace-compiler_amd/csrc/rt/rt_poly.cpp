@@ -8,7 +8,11 @@
 
 namespace rt {
 
-Context* g_ctx = nullptr;
+// All runtime state is per host thread: a thread that calls Prepare_context owns a context, a memory pool, an
+// operation queue and (through libacehip's per-thread default stream) a HIP stream of its own, so several
+// threads can push images through the same GPU concurrently -- the reference runs one OpenMP thread per image
+// (resnet_cifar.main.inc:77-116) on a shared context; here the keys are per thread.
+thread_local Context* g_ctx = nullptr;
 Context& ctx() {
   RT_ASSERT(g_ctx != nullptr, "rt_ant context is not prepared (call Prepare_context first)");
   return *g_ctx;
@@ -17,21 +21,22 @@ Context& ctx() {
 // ---- pool: exact-size free lists.  All launches go to the default stream in program order, so a
 // buffer released by Free_* can be handed out again immediately: later kernels are ordered after
 // earlier ones.  Nothing is returned to the driver before Finalize_context (hipFree synchronises).
-static std::mutex pool_mu;
-static std::map<size_t, std::vector<u64*>> pool_free;
-static std::map<u64*, size_t> pool_live;
-static size_t pool_live_bytes = 0;
+static thread_local std::mutex pool_mu;
+static thread_local std::map<size_t, std::vector<u64*>> pool_free;
+static thread_local std::map<u64*, size_t> pool_live;
+static thread_local size_t pool_live_bytes = 0;
 
 // ---- deferred per-limb ops ----
 // Generated code calls Hw_modadd / Hw_modmul / Hw_rotate once per RNS limb and component inside host loops
 // (resnet20_cifar10_pre.onnx.inc:1492-1503).  They are queued here and handed to acehip_hw_batch when any other
 // device work is issued (HIPCHK), so a whole loop nest becomes a few launches; zero fills and limb copies
-// that sit between such loops ride in the same queue.  Single-threaded like the reference runtime.
+// that sit between such loops ride in the same queue (one queue per host thread).
 namespace {
-std::vector<acehip_hw_op> g_hwq;
+thread_local std::vector<acehip_hw_op> g_hwq;
 struct HwqStats {
   size_t flushes = 0, ops = 0, by_kind[9] = {}, hist[8] = {};  // hist: <=1, <=4, <=16, <=64, <=256, <=1024, <=4096, more
-} g_hwq_stats;
+};
+thread_local HwqStats g_hwq_stats;
 }
 void hw_stats_print() {
   const HwqStats& s = g_hwq_stats;
@@ -52,14 +57,16 @@ struct PendingPair {
   u64* out = nullptr;
   const u64* in = nullptr;
   u32 level = 0;
-} g_pend;
+};
+thread_local PendingPair g_pend;
 struct ModupCache {
   const u64* src = nullptr;  // q-limbs of the polynomial the digits were raised from
   u32 level = 0, next_part = 0;
   u64* ext = nullptr;        // [nd][level+K][N]
   size_t ext_words = 0;
   bool valid = false;
-} g_muc;
+};
+thread_local ModupCache g_muc;
 void pending_flush() {
   if (!g_pend.kind) return;
   const PendingPair p = g_pend;
