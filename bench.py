@@ -133,22 +133,6 @@ def load_model_runtime(device):
     return fhe, step
 
 
-def stream_worker(rfd, wfd, device):
-    """one extra image stream on the same GPU (its own process, context and keys -- the reference runs one
-    OpenMP thread per image, resnet_cifar.main.inc:77-116): 'S' = run one image, anything else = quit"""
-    os.dup2(2, 1)
-    fhe, step = load_model_runtime(device)
-    fhe.Prepare_context()
-    os.write(wfd, b"R")
-    while True:
-        cmd = os.read(rfd, 1)
-        if cmd != b"S":
-            break
-        step()
-        os.write(wfd, b"D")
-    fhe.Finalize_context()
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,14 +143,15 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="concurrent image streams per GPU for the ResNet headline (one process each); 1 = a single stream")
-    ap.add_argument("--stream-worker", default=None, help=argparse.SUPPRESS)  # "rfd,wfd,device": internal
+    ap.add_argument("--streams", type=int, default=4,
+                    help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
+                         "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     args = ap.parse_args()
-    if args.stream_worker:
-        rfd, wfd, device = (int(x) for x in args.stream_worker.split(","))
-        stream_worker(rfd, wfd, device)
-        return
+
+    # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues two image
+    # streams serialise behind each other (measured: 4 image streams + this thread's own = 0.99 images/s with 4 queues,
+    # 1.24 with 8).  Must be in the environment before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     # the runtime library prints the reference's stdout contract ([RT_STAT] ..., ckks_param: ...) from C;
     # keep fd 1 clean for the ONE JSON line: route everything else to stderr
@@ -175,21 +160,6 @@ def main():
 
     import ace_compiler_amd as A
     from ace_compiler_amd.dist import Ranks
-
-    bmod0 = sys.modules["ace_compiler_amd.build"]
-    want_model = (args.workload != "keyswitch" and not args.roofline_only and os.path.exists(MODEL_LIB) and
-                  os.path.exists(bmod0.RT_LIB))
-    workers = []  # (Popen, fd to write commands, fd to read replies); started before this process touches the GPU
-    if want_model:
-        for _ in range(max(args.streams, 1) - 1):
-            c2w_r, c2w_w = os.pipe()
-            w2c_r, w2c_w = os.pipe()
-            pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stream-worker",
-                                   "%d,%d,%s" % (c2w_r, w2c_w, os.environ.get("LOCAL_RANK", "0"))],
-                                  pass_fds=(c2w_r, w2c_w), stdout=2)
-            os.close(c2w_r)
-            os.close(w2c_w)
-            workers.append((pr, c2w_w, w2c_r))
 
     ranks = Ranks()  # one process per GPU; RCCL ("nccl") carries only the barrier and the max over ranks
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
@@ -235,26 +205,64 @@ def main():
         rt.check(lib.acehip_key_switch(h, o0.ptr, o1.ptr, a.ptr, key.ptr, L, None))
 
     logits = None
-    n_streams = 1 + len(workers)
+    n_streams = max(args.streams, 1) if use_model else 1
     if use_model:
-        fhe, one_image = load_model_runtime(local_rank)
-        fhe.Prepare_context()
-        for _, _, rf in workers:
-            assert os.read(rf, 1) == b"R", "an image-stream worker failed to start"
+        import threading
 
-        def step():  # one image on every stream of this GPU, concurrently
-            for _, wf, _ in workers:
-                os.write(wf, b"S")
-            vals = one_image()
-            for _, _, rf in workers:
-                assert os.read(rf, 1) == b"D", "an image-stream worker died"
-            return vals
+        # Image streams: the reference runs one OpenMP thread per image on one context (resnet_cifar.main.inc:77-116);
+        # here every host thread owns a context (all runtime state is thread-local) and launches on its own HIP
+        # stream, so the small dependent kernels of several images overlap on the GPU.
+        fhe, _ = load_model_runtime(local_rank)
+        gate = threading.Barrier(n_streams + 1)
+        cmd = {"op": None}
+        stream_logits = [None] * n_streams
+        stream_stats = [None] * n_streams
+        stream_err = []
+
+        def stream_main(i):
+            try:
+                _, one_image = load_model_runtime(local_rank)  # per-thread image generator on the shared library
+                fhe.Prepare_context()                          # thread-local context, keys generated on the device
+                while True:
+                    gate.wait()
+                    op = cmd["op"]
+                    if op == "step":
+                        for _ in range(cmd["n"]):               # images back to back: streams are not kept in lock step
+                            stream_logits[i] = one_image()
+                    elif op == "reset":
+                        read_stats(reset=True)                 # statistics are per thread as well
+                    elif op == "stats":
+                        stream_stats[i] = read_stats(reset=False)
+                    gate.wait()
+                    if op == "quit":
+                        break
+                fhe.Finalize_context()
+            except BaseException as e:  # noqa: BLE001 -- report and release the barrier
+                stream_err.append(repr(e))
+                gate.abort()
+
+        threads = [threading.Thread(target=stream_main, args=(i,), daemon=True) for i in range(n_streams)]
+        for t in threads:
+            t.start()
+
+        def run_all(op, n=1):
+            cmd["op"], cmd["n"] = op, n
+            try:
+                gate.wait()
+                gate.wait()
+            except threading.BrokenBarrierError:
+                raise SystemExit("bench: an image stream failed: %s" % stream_err)
+
+        def step(n=1):  # n images on every stream of this GPU, concurrently
+            run_all("step", n)
+            return stream_logits[0]
 
         unit, metric = "images/s", "encrypted images/sec (ResNet-20 CIFAR-10, N=2^16)"
         workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
                     "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
-                    "N(0,0.05); %d concurrent image streams per GPU (one process, context and key set each -- the reference's "
-                    "own parallel axis is one OpenMP thread per image), one image per stream per step" % n_streams)
+                    "N(0,0.05); %d concurrent image streams per GPU (host threads with one context, key set and HIP stream each "
+                    "-- the reference's own parallel axis is one OpenMP thread per image), one image per stream per step"
+                    % n_streams)
     elif args.roofline_only:
         def step():
             return None
@@ -270,30 +278,40 @@ def main():
         workload = ("C3 (BASELINE configs[2]) FALLBACK: build/models/libmodel_resnet20.so not present, so the headline ResNet-20 "
                     "workload cannot run; full key-switch N=2^16 L=25 dnum=4 K=7 on resident inputs")
 
-    for _ in range(args.warmup):
-        logits = step()
+    if use_model:
+        if args.warmup:
+            logits = step(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            logits = step()
     barrier()
-    read_stats(reset=True)
+    if use_model:
+        run_all("reset")
+    else:
+        read_stats(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits = step()
+    if use_model:
+        logits = step(args.steps)  # every stream runs its K images back to back; the region ends when all are done
+    else:
+        for _ in range(args.steps):
+            logits = step()
     rt.sync()
     elapsed_local = time.perf_counter() - t0
-    stats = read_stats(reset=False)
+    if use_model:
+        run_all("stats")
+        stats = stream_stats[0]
+    else:
+        stats = read_stats(reset=False)
     barrier()
     elapsed = ranks.max_over_ranks(elapsed_local)
     value = world * n_streams * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
-    for pr, wf, rf in workers:  # the extra streams leave the GPU before the micro workloads are timed
-        os.write(wf, b"Q")
-    for pr, wf, rf in workers:
-        pr.wait()
-        os.close(wf)
-        os.close(rf)
-    step = one_image if use_model else step
-    if use_model:
-        fhe.Finalize_context()
+    if use_model:  # the image streams leave the GPU before the micro workloads are timed
+        run_all("quit")
+        for t in threads:
+            t.join()
+        _, step = load_model_runtime(local_rank)  # single stream on this thread for the secondary run below
         if world == 1:
             # secondary, NOT the headline: the same workload with the encoded weight plaintexts kept in HBM
             # (ACEHIP_PT_CACHE=1, 12.3 GB; the reference's pre-encoded DE_PLAINTEXT mode)

@@ -8,6 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per image stream (see bench.py)
 json_fd = os.dup(1)
 os.dup2(2, 1)
 import bench  # noqa: E402
