@@ -150,3 +150,42 @@ def test_encode_overflow_is_reported():
     finally:
         rt.close()
         o.close()
+
+
+def test_two_host_threads_own_independent_contexts(stub):
+    """All runtime state is per host thread (context, pool, queue, HIP stream): two threads that prepare a context each and
+    encode concurrently must both reproduce the reference plaintexts (the bench runs 4 such image streams per GPU)."""
+    import threading
+
+    path = [p for p in FILES if "n1024" in p][0]
+    g = json.load(open(path))
+    N, level = g["N"], g["level"]
+    stub.Stub_set_params(N, g["L"] - 1, g["q0_bits"], g["sf_bits"], g["dnum_req"], 192)
+    errors = []
+    gate = threading.Barrier(2)
+
+    def run(tid):
+        try:
+            stub.Prepare_context()
+            gate.wait()
+            for _ in range(20):
+                for case in g["cases"]:
+                    msg = O.encode_message(case["len"], g["seed"])
+                    pt = C.create_string_buffer(stub.Stub_sizeof_plaintext())
+                    stub.Encode_plain_from_float(pt, msg.ctypes.data, case["len"], case["sf_degree"], level)
+                    got = _download(stub, pt, N)
+                    if O.sum64(got) != case["poly"]["sum64"] or O.xorw(got) != case["poly"]["xorw"]:
+                        errors.append((tid, case["len"], case["sf_degree"]))
+                    stub.Free_plain(pt)
+            gate.wait()
+            stub.Finalize_context()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+            gate.abort()
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
