@@ -553,11 +553,40 @@ u32 hw_node(HwScratch& h, u64 ptr, u64 span, u64 mask) {
   return node;
 }
 
+static u64* hw_scratch(acehip_ctx* c, size_t limbs);
+inline bool limbs_overlap(const void* x, const void* y, u64 span) {
+  const u64 a = (u64)x, b = (u64)y;
+  return (a < b ? b - a : a - b) < span;
+}
+
+// One op per launch, in the caller's order (lists with partially overlapping limbs -- nothing Coeffs() can produce).
+// An operand that overlaps the result without being the same limb is read from a private copy taken before the op:
+// the op sees the operand as it was, which is what the reference's ascending-index loop (poly_arith.c:14-39) sees
+// whenever the operand lies above the result; an operand overlapping from below would be a loop-carried dependence
+// there, which this interface does not reproduce (documented in include/acehip.h).
 void hw_issue_one(acehip_ctx* c, const acehip_hw_op& o, hipStream_t st) {
+  const u64 span = (u64)c->hp.N * 8;
   HwBatchArgs args;
-  args.op[0] = HwBatchOp{o.res, o.a, (const u64*)o.b, o.op, o.prime_gi};
   args.seg_start[0] = 0;
   args.seg_start[1] = 1;
+  const u64* a = o.a;
+  const u64* b = (const u64*)o.b;
+  const bool has_a = o.op != ACEHIP_HW_ZERO;
+  const bool has_b = o.op == ACEHIP_HW_ADD || o.op == ACEHIP_HW_MUL || o.op == ACEHIP_HW_SUB || o.op == ACEHIP_HW_MULADD;
+  u64* scratch = nullptr;
+  for (int which = 0; which < 2; ++which) {
+    const u64*& src = which == 0 ? a : b;
+    if (!(which == 0 ? has_a : has_b) || o.op == ACEHIP_HW_ROTATE) continue;
+    if (src == o.res || !limbs_overlap(src, o.res, span)) continue;
+    if (!scratch) scratch = hw_scratch(c, 2);
+    if (!scratch) continue;  // no memory: run as is
+    u64* priv = scratch + (size_t)which * c->hp.N;
+    args.op[0] = HwBatchOp{priv, src, nullptr, HW_OP_COPY, 0};
+    launch_hw_batch_ew(c->dc, args, 1, st);
+    src = priv;
+  }
+  args.op[0] = HwBatchOp{o.res, a, o.op == ACEHIP_HW_MULC || o.op == ACEHIP_HW_ADDC || o.op == ACEHIP_HW_ROTATE ? (const u64*)o.b : b,
+                         o.op, o.prime_gi};
   if (o.op == ACEHIP_HW_ROTATE) launch_hw_batch_rotate(c->dc, args, 1, st);
   else launch_hw_batch_ew(c->dc, args, 1, st);
 }
@@ -731,11 +760,6 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
   }
   args.seg_start[++n_seg] = (uint16_t)n_ops;
   launch_hw_batch_ew(c->dc, args, n_seg, st);
-}
-
-inline bool limbs_overlap(const void* x, const void* y, u64 span) {
-  const u64 a = (u64)x, b = (u64)y;
-  return (a < b ? b - a : a - b) < span;
 }
 
 // rotation run: gathers are independent unless a result aliases a source or result of the same launch

@@ -58,7 +58,7 @@ struct Precom {
   std::vector<std::vector<PLAINTEXT*>> u0hatt_fft, u0_fft;
   bool keys = false;
 };
-thread_local std::map<u32, Precom*> g_precom;
+std::map<u32, Precom*> g_precom;  // shared by all threads (guarded by shared_mu), built by whichever thread needs it first
 
 // Reduce_rotation :220-233
 u32 reduce_rotation(int32_t index, u32 slots) {
@@ -331,11 +331,12 @@ Precom* bootstrap_setup(u32 num_slots) {
   Context& c = ctx();
   const size_t m = 2ull * c.N;
   const u32 slots = num_slots == 0 ? (u32)(m / 4) : num_slots;
+  std::lock_guard<std::recursive_mutex> lk(shared_mu());
   auto it = g_precom.find(slots);
   if (it != g_precom.end()) return it->second;
+  SharedAllocScope shared_plaintexts;  // the encoded diagonals outlive this thread's pool
   Precom* pre = new Precom();
   pre->slots = slots;
-  g_precom[slots] = pre;
   u32 budget[2] = {3, 3};
   const double log_slots = log2((double)slots);
   for (auto& bgt : budget) {
@@ -369,6 +370,8 @@ Precom* bootstrap_setup(u32 num_slots) {
   RT_ASSERT(!(enc_budget == 1 && dec_budget == 1), "linear-transform bootstrapping (level budget 1/1) is not implemented");
   pre->u0hatt_fft = fft_precomp(pre, ksi, rot_group, scale_enc, level_0 - enc_budget, true);
   pre->u0_fft = fft_precomp(pre, ksi, rot_group, scale_dec, level_0 - bts_depth, false);
+  sync();  // encoded on this thread's stream: complete before other threads can find it
+  g_precom[slots] = pre;
   return pre;
 }
 
@@ -404,6 +407,7 @@ void find_rot_index(std::set<int32_t>& out, Precom* pre, u32 slots, u32 m, bool 
 
 // Bootstrap_keygen :1194-1226
 void bootstrap_keygen(Precom* pre) {
+  std::lock_guard<std::recursive_mutex> lk(shared_mu());
   if (pre->keys) return;
   Context& c = ctx();
   const u32 m = 2 * c.N;

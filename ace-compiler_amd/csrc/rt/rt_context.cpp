@@ -60,7 +60,7 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) 
   const u32 T = c.L + c.K;
   const size_t N = c.N, poly_words = (size_t)T * N;
   auto* sk = new SwitchKeyStore();
-  sk->data = dalloc((size_t)c.dnum * 2 * poly_words, false);
+  sk->data = shared_alloc((size_t)c.dnum * 2 * poly_words, false);  // outlives the generating thread
   sk->parts.resize(c.dnum);
   POLYNOMIAL e{};
   poly_alloc(&e, c.N, c.L, c.K);
@@ -99,15 +99,17 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) 
 
 void free_switch_key(SwitchKeyStore* k) {
   if (!k) return;
-  dfree(k->data);
+  dfree(k->data);  // shared allocation: dfree recognises it
   delete k;
 }
 
 // Generate_rot_key (fast variant) :238-266: key from sigma_{k^-1}(s) ... applied before the automorphism
 SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   Context& c = ctx();
-  auto it = c.auto_keys.find(auto_idx);
-  if (it != c.auto_keys.end()) return it->second;
+  std::lock_guard<std::recursive_mutex> lk(shared_mu());  // keys are generated once, by whichever thread asks first
+  Context& prim = *g_primary;
+  auto it = prim.auto_keys.find(auto_idx);
+  if (it != prim.auto_keys.end()) return it->second;
   const u32 T = c.L + c.K;
   // k^-1 mod 2N (k odd): k^(N-1)
   u64 inv = 1, base = auto_idx, e = c.N - 1, m = 2ull * c.N;
@@ -121,17 +123,20 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   q_rotate(old_key, c.sk_ntt, perm, c.L, 0, T);
   SwitchKeyStore* k = make_switch_key(c.sk_ntt, old_key);
   dfree(old_key);
-  c.auto_keys[auto_idx] = k;
+  sync();  // complete in memory before another thread's stream may read it
+  prim.auto_keys[auto_idx] = k;
   return k;
 }
 
 u32 ensure_rot_key(int32_t rotation) {
   Context& c = ctx();
-  auto it = c.rot2auto.find(rotation);
-  if (it != c.rot2auto.end()) return it->second;
+  std::lock_guard<std::recursive_mutex> lk(shared_mu());
+  Context& prim = *g_primary;
+  auto it = prim.rot2auto.find(rotation);
+  if (it != prim.rot2auto.end()) return it->second;
   const u32 k = acehip_auto_index(c.hip, rotation);
-  c.rot2auto[rotation] = k;
   ensure_auto_key(k);
+  prim.rot2auto[rotation] = k;
   return k;
 }
 
@@ -180,6 +185,11 @@ extern "C" {
 
 void Prepare_context() {
   if (g_ctx != nullptr) return;
+  std::lock_guard<std::recursive_mutex> prep_lock(shared_mu());
+  if (g_primary != nullptr) {  // another thread prepared already: this one becomes a view of that context
+    (void)ctx();
+    return;
+  }
   CKKS_PARAMS* prm = Get_context_params();
   RT_ASSERT(prm != nullptr, "Get_context_params() returned NULL");
   RT_ASSERT(acehip_device_count() > 0, "no MI355X visible: the rt_ant HIP provider has no CPU fallback");
@@ -222,6 +232,7 @@ void Prepare_context() {
   for (size_t i = 1; i < c->N / 2; ++i) c->rot_group[i] = (u32)((5ull * c->rot_group[i - 1]) % m);
   c->profile = getenv("ACEHIP_PROFILE") != nullptr;
   g_ctx = c;
+  g_primary = c;
   // first stdout line parsed by scripts/perf.py:266-276 (context.c:49-57)
   printf("ckks_param: _provider = %d, _poly_degree = %d, _sec_level = %ld, mul_depth = %ld, _first_mod_size = %ld, "
          "_scaling_mod_size = %ld, _num_q_parts = %ld, _num_p = %ld, _num_rot_idx = %ld,_hamming_wieght = %ld\n",
@@ -239,6 +250,11 @@ void Prepare_context() {
 
 void Finalize_context() {
   if (g_ctx == nullptr) return;
+  if (g_ctx->secondary) {  // a worker thread leaves; the keys stay with the primary context
+    thread_release();
+    return;
+  }
+  std::lock_guard<std::recursive_mutex> fin_lock(shared_mu());
   Context& c = *g_ctx;
   sync();
   HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
@@ -268,6 +284,8 @@ void Finalize_context() {
   }
   for (auto& kv : c.auto_keys) free_switch_key(kv.second);
   c.auto_keys.clear();
+  dfree(c.relin.data);
+  c.relin.data = nullptr;
   bootstrap_release();
   ev::clear_monomial_cache();
   stage_release();
@@ -275,7 +293,11 @@ void Finalize_context() {
   acehip_ctx_destroy(c.hip);
   delete g_ctx;
   g_ctx = nullptr;
+  g_primary = nullptr;
 }
+// Extension: a worker thread that used the API (it attached to the prepared context on first use) gives back
+// its scratch context, pool and queue before it ends; Finalize_context from such a thread does the same.
+void Acehip_rt_thread_release(void) { thread_release(); }
 
 // Extension for callers that touch Coeffs() memory themselves (acehip_* / HIP calls on the raw device
 // pointers): hands over everything the shim still holds back and waits for the device.

@@ -79,12 +79,23 @@ struct Context {
   std::vector<u32> rot_group;     // 5^i mod 2N
   // statistics
   size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
+  bool secondary = false;         // a thread's view of the primary context (shares its keys, owns its acehip_ctx)
   bool profile = false;                          // ACEHIP_PROFILE=1: host-side timers below are printed
   double t_encode = 0, t_main = 0, t_issue = 0, t_bootstrap = 0;
   size_t n_bootstrap = 0;
 };
 
-extern thread_local Context* g_ctx;
+extern thread_local Context* g_ctx;  // this thread's context (its own acehip_ctx, counters, copies of the parameters)
+extern Context* g_primary;           // the context Prepare_context built: owner of the keys every thread uses
+// guards what threads grow lazily and share: rotation keys, bootstrap precomputation, weight/plaintext caches
+std::recursive_mutex& shared_mu();
+// device memory that outlives the allocating thread (keys, bootstrap plaintexts): not from the thread's pool
+u64* shared_alloc(size_t words, bool zero);
+struct SharedAllocScope {  // every dalloc of this thread inside the scope is a shared_alloc
+  SharedAllocScope();
+  ~SharedAllocScope();
+};
+void thread_release();               // give back this thread's context / pool / queue (secondary threads)
 Context& ctx();
 
 // ---- device memory pool (stream-ordered reuse; generated code does thousands of Alloc/Free) ----

@@ -80,7 +80,7 @@ struct PtMgr {
   std::map<uint32_t, std::pair<float*, size_t>> synth_dev;  // synthetic mode: device copy per entry
   bool open = false;
 };
-thread_local PtMgr g_pt;
+PtMgr g_pt;  // one weight file per process: read and uploaded once, shared by every thread (shared_mu guards the lazily filled maps)
 
 }  // namespace
 
@@ -187,8 +187,8 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
 // ACEHIP_RT_DATA_FILE overrides the path the compiler baked into Get_rt_data_info() (the checked-in ResNet
 // sources name /app/release/...); ACEHIP_RT_DATA_SYNTH=1 replaces the file by deterministic synthetic
 // weights N(0, 0.05) (there is no weight file in the reference tree: SURVEY 8d, C4).
-static thread_local bool g_pt_synth = false;
-static thread_local double g_pt_synth_sigma = 0.05;  // ACEHIP_RT_DATA_SYNTH_SIGMA overrides
+static bool g_pt_synth = false;
+static double g_pt_synth_sigma = 0.05;  // ACEHIP_RT_DATA_SYNTH_SIGMA overrides
 static float* synth_entry(uint32_t index, size_t len) {
   static thread_local std::vector<float> buf;
   buf.resize(len);
@@ -279,6 +279,7 @@ static float* pt_entry(uint32_t index, size_t len) {
 static const float* pt_entry_dev(uint32_t index, size_t len) {
   float* host = pt_entry(index, len);
   if (!g_pt_synth) return (const float*)(g_pt.dbuf + ((char*)host - g_pt.buf.data()));
+  std::lock_guard<std::recursive_mutex> lk(rt::shared_mu());
   auto it = g_pt.synth_dev.find(index);
   if (it != g_pt.synth_dev.end() && it->second.second >= len) return it->second.first;
   if (it != g_pt.synth_dev.end()) acehip_free(it->second.first);
@@ -299,8 +300,8 @@ struct PtKey {
     return std::tie(index, level, scale, len) < std::tie(o.index, o.level, o.scale, o.len);
   }
 };
-static thread_local std::map<PtKey, rt::u64*> g_pt_cache;
-static thread_local int g_pt_cache_on = -1;
+static std::map<PtKey, rt::u64*> g_pt_cache;  // shared by all threads (shared_mu)
+static int g_pt_cache_on = -1;
 static void pt_cache_clear() {
   for (auto& kv : g_pt_cache) acehip_free(kv.second);
   g_pt_cache.clear();
@@ -314,6 +315,7 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
   if (g_pt_cache_on < 0) g_pt_cache_on = getenv("ACEHIP_PT_CACHE") && atoi(getenv("ACEHIP_PT_CACHE")) != 0;
   if (g_pt_cache_on) {
     rt::Context& c = rt::ctx();
+    std::unique_lock<std::recursive_mutex> lk(rt::shared_mu());
     const uint32_t lv = level ? level : c.L;
     const size_t words = (size_t)lv * c.N;
     auto it = g_pt_cache.find(PtKey{index, lv, scale, len});
@@ -322,8 +324,10 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
       rt::u64* keep = (rt::u64*)acehip_malloc(words * 8);
       RT_ASSERT(keep, "plaintext cache: %s", acehip_last_error());
       HIPCHK(acehip_memcpy_d2d(keep, rt::q_limbs(&plain->_poly), words * 8, nullptr));
+      rt::sync();  // complete before another thread's stream may copy from it
       g_pt_cache[PtKey{index, lv, scale, len}] = keep;
     } else {
+      lk.unlock();
       rt::init_plaintext(plain, c.N / 2, lv, 0, pow(c.sf, (double)scale), scale);
       rt::copy_limbs(rt::q_limbs(&plain->_poly), it->second, words);
       plain->_poly._is_ntt = true;

@@ -13,9 +13,65 @@ namespace rt {
 // threads can push images through the same GPU concurrently -- the reference runs one OpenMP thread per image
 // (resnet_cifar.main.inc:77-116) on a shared context; here the keys are per thread.
 thread_local Context* g_ctx = nullptr;
+Context* g_primary = nullptr;
+std::recursive_mutex& shared_mu() {
+  static std::recursive_mutex mu;
+  return mu;
+}
+// A thread that uses the API without having prepared a context itself (the OpenMP workers of the reference's
+// main(), dataset/resnet_cifar.main.inc:77-116) attaches to the primary one: same parameters and keys (shared,
+// read-only device memory), its own acehip_ctx (scratch, tables), pool, queue and HIP stream.
+static void attach_thread() {
+  std::lock_guard<std::recursive_mutex> lk(shared_mu());
+  RT_ASSERT(g_primary != nullptr, "rt_ant context is not prepared (call Prepare_context first)");
+  Context* p = g_primary;
+  auto* c = new Context(*p);
+  c->secondary = true;
+  c->auto_keys.clear();  // the shared maps live in the primary context only
+  c->rot2auto.clear();
+  int dev = 0;
+  if (const char* e = getenv("ACEHIP_DEVICE")) dev = atoi(e);
+  c->hip = acehip_ctx_create(p->prm->_poly_degree, (uint32_t)p->prm->_mul_depth + 1, (uint32_t)p->prm->_first_mod_size,
+                             (uint32_t)p->prm->_scaling_mod_size, (uint32_t)p->prm->_num_q_parts, dev);
+  RT_ASSERT(c->hip != nullptr, "acehip_ctx_create failed: %s", acehip_last_error());
+  c->rng.seed(p->rng() ^ (u64)(uintptr_t)c);  // encryption noise of this thread
+  c->weight_plain_cnt = c->weight_plain_bytes = 0;
+  c->t_encode = c->t_main = c->t_issue = c->t_bootstrap = 0;
+  c->n_bootstrap = 0;
+  g_ctx = c;
+}
 Context& ctx() {
-  RT_ASSERT(g_ctx != nullptr, "rt_ant context is not prepared (call Prepare_context first)");
+  if (g_ctx == nullptr) attach_thread();
   return *g_ctx;
+}
+
+// shared device memory: plain hipMalloc, remembered so that any thread can free it
+static std::mutex g_shared_alloc_mu;
+static std::map<u64*, size_t> g_shared_allocs;
+static thread_local int g_shared_scope = 0;
+SharedAllocScope::SharedAllocScope() { ++g_shared_scope; }
+SharedAllocScope::~SharedAllocScope() { --g_shared_scope; }
+u64* shared_alloc(size_t words, bool zero) {
+  if (words == 0) words = 1;
+  u64* p = (u64*)acehip_malloc(words * sizeof(u64));
+  RT_ASSERT(p != nullptr, "device allocation of %zu bytes failed: %s", words * sizeof(u64), acehip_last_error());
+  {
+    std::lock_guard<std::mutex> lk(g_shared_alloc_mu);
+    g_shared_allocs[p] = words;
+  }
+  if (zero) HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
+  return p;
+}
+static bool shared_free(u64* p) {
+  {
+    std::lock_guard<std::mutex> lk(g_shared_alloc_mu);
+    auto it = g_shared_allocs.find(p);
+    if (it == g_shared_allocs.end()) return false;
+    g_shared_allocs.erase(it);
+  }
+  hw_flush();  // nothing queued may still name it
+  acehip_free(p);
+  return true;
 }
 
 // ---- pool: exact-size free lists.  All launches go to the default stream in program order, so a
@@ -134,6 +190,7 @@ void copy_limbs(u64* dst, const u64* src, size_t words) {
 }
 
 u64* dalloc(size_t words, bool zero) {
+  if (g_shared_scope > 0) return shared_alloc(words, zero);
   if (words == 0) words = 1;
   u64* p = nullptr;
   {
@@ -161,11 +218,24 @@ void dfree(u64* p) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(pool_mu);
   auto it = pool_live.find(p);
+  if (it == pool_live.end() && shared_free(p)) return;
   RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
   if (g_muc.valid && g_muc.src >= p && g_muc.src < p + it->second) g_muc.valid = false;
   pool_live_bytes -= it->second * sizeof(u64);
   pool_free[it->second].push_back(p);
   pool_live.erase(it);
+}
+
+// a secondary thread gives back what it owns (the primary thread does this in Finalize_context)
+void thread_release() {
+  if (g_ctx == nullptr || !g_ctx->secondary) return;
+  sync();
+  ev::clear_monomial_cache();
+  stage_release();
+  pool_release_all();
+  acehip_ctx_destroy(g_ctx->hip);
+  delete g_ctx;
+  g_ctx = nullptr;
 }
 
 void pool_release_all() {

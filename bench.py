@@ -210,9 +210,10 @@ def main():
         import threading
 
         # Image streams: the reference runs one OpenMP thread per image on one context (resnet_cifar.main.inc:77-116);
-        # here every host thread owns a context (all runtime state is thread-local) and launches on its own HIP
-        # stream, so the small dependent kernels of several images overlap on the GPU.
+        # same structure here: the context (keys) is prepared once, every image thread attaches to it with its own
+        # scratch, pool, queue and HIP stream, so the small dependent kernels of several images overlap on the GPU.
         fhe, _ = load_model_runtime(local_rank)
+        fhe.Prepare_context()  # this thread owns the context: keys are generated once (on the device) and shared
         gate = threading.Barrier(n_streams + 1)
         cmd = {"op": None}
         stream_logits = [None] * n_streams
@@ -222,7 +223,7 @@ def main():
         def stream_main(i):
             try:
                 _, one_image = load_model_runtime(local_rank)  # per-thread image generator on the shared library
-                fhe.Prepare_context()                          # thread-local context, keys generated on the device
+                fhe.Prepare_context()                          # attaches: shared keys, own scratch / pool / queue / stream
                 while True:
                     gate.wait()
                     op = cmd["op"]
@@ -311,6 +312,7 @@ def main():
         run_all("quit")
         for t in threads:
             t.join()
+        fhe.Finalize_context()
         _, step = load_model_runtime(local_rank)  # single stream on this thread for the secondary run below
         if world == 1:
             # secondary, NOT the headline: the same workload with the encoded weight plaintexts kept in HBM

@@ -121,7 +121,8 @@ int acehip_hw_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, cons
 
 /* A list of such per-limb calls handed over at once.  Result: exactly what issuing ops[0..n) one by one would
  * give (limbs are N words; two limb pointers are either equal or disjoint in every case the reference code
- * produces -- partially overlapping limbs are still handled, op by op).  The library groups the ops into
+ * produces -- partially overlapping limbs are still handled, op by op, with every op reading its operands as
+ * they were before the op started).  The library groups the ops into
  * dependency chains and runs them in a few launches instead of n: generated code calls Hw_* once per RNS limb
  * and component, ~600k times per ResNet-20 image.
  *   ADD/SUB/MUL: res = a (+|-|*) b mod prime(prime_gi);  MULADD: res += a*b (Multiply_add polynomial.c:148);

@@ -11,6 +11,9 @@ void       Set_output_data(const char* name, size_t idx, CIPHER data);
  * lazily in batches.  Code that touches that memory itself (HIP / acehip_* calls on the raw pointers) calls
  * this first: it submits everything still queued and waits for the device. */
 void       Acehip_rt_sync(void);
+/* Extension: a thread other than the one that called Prepare_context attaches to that context on its first API
+ * call (shared keys; own scratch, pool, queue, HIP stream); before it ends it may give those back. */
+void       Acehip_rt_thread_release(void);
 #ifdef __cplusplus
 }
 #endif

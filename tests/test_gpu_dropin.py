@@ -96,3 +96,24 @@ def test_bootstrap_at_generated_model_parameters(tmp_path, cfg):
                            "-Wl,-rpath," + bmod.LIBDIR, "-o", exe])
     r = subprocess.run([exe] + cfg.split(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_style_openmp_main_shares_one_context():
+    """The reference's model main prepares the context once and runs Main_graph from an OpenMP loop, one image per thread
+    (rtlib/ant/dataset/resnet_cifar.main.inc:77-116).  tools/model_main_omp.c has that structure around the UNCHANGED
+    generated ResNet-20: worker threads attach to the prepared context (shared keys; own scratch, pool, queue and HIP stream).
+    Every thread processes the same image, so every line of logits must be the same."""
+    import re
+
+    exe = os.path.join(EX_DIR, "modelomp_resnet20_cifar10_pre")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/examples/modelomp_* not built (needs /root/reference: make -C oracle models)")
+    env = dict(os.environ, OMP_NUM_THREADS="3", GPU_MAX_HW_QUEUES="8", ACEHIP_RT_DATA_SYNTH="1")
+    r = subprocess.run([exe, "6"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = re.findall(r"\[MODEL\] image \d+: logits:((?: -?\d+\.\d+)+)", r.stdout)
+    assert len(rows) == 6
+    vals = [[float(x) for x in row.split()] for row in rows]
+    for v in vals[1:]:
+        assert max(abs(a - b) for a, b in zip(v, vals[0])) <= 2e-4, vals
+    assert "rot_key_cnt = 227," in r.stdout  # the keys exist once, not once per thread

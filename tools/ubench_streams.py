@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of W concurrent image streams in ONE process: W host threads, each with its own rt_ant context
-(keys, pool, queue) and its own HIP stream (per-thread default stream).  usage: ubench_streams.py W [images]"""
+"""Throughput of W concurrent image streams in ONE process: W host threads attached to one rt_ant context
+(shared keys; own scratch context, pool, queue and HIP stream each).  usage: ubench_streams.py W [images]"""
 import os
 import sys
 import threading
@@ -16,6 +16,7 @@ import bench  # noqa: E402
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 IMAGES = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 fhe, _ = bench.load_model_runtime(0)
+fhe.Prepare_context()  # keys once; the image threads attach to this context
 barrier = threading.Barrier(W + 1)
 logits = [None] * W
 
@@ -40,5 +41,6 @@ barrier.wait()
 dt = time.perf_counter() - t0
 for t in threads:
     t.join()
+fhe.Finalize_context()
 os.write(json_fd, ("%d streams: %d images in %.3f s = %.3f images/s (%.3f s per image per stream); logits[0..2] %s\n" % (
     W, W * IMAGES, dt, W * IMAGES / dt, dt / IMAGES, [[round(v, 4) for v in l[:3]] for l in logits])).encode())
