@@ -60,6 +60,7 @@ SYMBOLS = [
     ("acehip_hw_modmul", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_rotate", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_batch", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    ("acehip_hw_batch_plan", C.c_long, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _u64]),
     ("acehip_stats", C.c_int, [_vp, C.c_int, C.c_int]),
     ("acehip_stat_name", C.c_char_p, [C.c_int]),
     ("acehip_decomp_modup", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),

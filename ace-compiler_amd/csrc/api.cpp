@@ -554,6 +554,43 @@ u32 hw_node(HwScratch& h, u64 ptr, u64 span, u64 mask) {
 }
 
 static u64* hw_scratch(acehip_ctx* c, size_t limbs);
+// acehip_hw_batch_plan: the launches are recorded instead of issued (host-side test of the analysis, no GPU needed)
+struct HwPlanSink {
+  acehip_hw_op* ops;
+  uint32_t* launch_id;
+  uint32_t* seg_id;
+  size_t cap, n;
+  uint32_t launches;
+  u64 scratch_base;
+};
+static thread_local HwPlanSink* g_plan = nullptr;
+static void plan_append(const HwBatchOp& o, u32 seg) {
+  HwPlanSink& p = *g_plan;
+  if (p.n < p.cap) {
+    p.ops[p.n] = acehip_hw_op{o.kind, o.gi, o.res, o.a, (const void*)o.b};
+    p.launch_id[p.n] = p.launches;
+    p.seg_id[p.n] = seg;
+  }
+  ++p.n;
+}
+static void emit_ew(acehip_ctx* c, const HwBatchArgs& args, u32 n_seg, hipStream_t st) {
+  if (!g_plan) {
+    launch_hw_batch_ew(c->dc, args, n_seg, st);
+    return;
+  }
+  for (u32 sgm = 0; sgm < n_seg; ++sgm)
+    for (u32 k = args.seg_start[sgm]; k < args.seg_start[sgm + 1]; ++k) plan_append(args.op[k], sgm);
+  ++g_plan->launches;
+}
+static void emit_rotate(acehip_ctx* c, const HwBatchArgs& args, u32 n_ops, hipStream_t st) {
+  if (!g_plan) {
+    launch_hw_batch_rotate(c->dc, args, n_ops, st);
+    return;
+  }
+  if (n_ops == 0) return;
+  for (u32 k = 0; k < n_ops; ++k) plan_append(args.op[k], k);  // every gather is its own segment
+  ++g_plan->launches;
+}
 inline bool limbs_overlap(const void* x, const void* y, u64 span) {
   const u64 a = (u64)x, b = (u64)y;
   return (a < b ? b - a : a - b) < span;
@@ -582,17 +619,18 @@ void hw_issue_one(acehip_ctx* c, const acehip_hw_op& o, hipStream_t st) {
     if (!scratch) continue;  // no memory: run as is
     u64* priv = scratch + (size_t)which * c->hp.N;
     args.op[0] = HwBatchOp{priv, src, nullptr, HW_OP_COPY, 0};
-    launch_hw_batch_ew(c->dc, args, 1, st);
+    emit_ew(c, args, 1, st);
     src = priv;
   }
   args.op[0] = HwBatchOp{o.res, a, o.op == ACEHIP_HW_MULC || o.op == ACEHIP_HW_ADDC || o.op == ACEHIP_HW_ROTATE ? (const u64*)o.b : b,
                          o.op, o.prime_gi};
-  if (o.op == ACEHIP_HW_ROTATE) launch_hw_batch_rotate(c->dc, args, 1, st);
-  else launch_hw_batch_ew(c->dc, args, 1, st);
+  if (o.op == ACEHIP_HW_ROTATE) emit_rotate(c, args, 1, st);
+  else emit_ew(c, args, 1, st);
 }
 
 // scratch limbs for renamed intermediate versions (see hw_run_ew); grown on demand, owned by the context
 static u64* hw_scratch(acehip_ctx* c, size_t limbs) {
+  if (g_plan) return (u64*)g_plan->scratch_base;  // recording: addresses only
   if (limbs <= c->hw_scratch_limbs) return c->hw_scratch;
   size_t want = std::max<size_t>(256, c->hw_scratch_limbs);
   while (want < limbs) want *= 2;
@@ -746,7 +784,7 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     while (t >= h.cnt[chain]) ++chain;
     if (n_ops == HW_BATCH_MAX) {  // a chain cut here continues in the next launch, which is ordered after this one
       args.seg_start[++n_seg] = (uint16_t)n_ops;
-      launch_hw_batch_ew(c->dc, args, n_seg, st);
+      emit_ew(c, args, n_seg, st);
       n_ops = 0;
       n_seg = 0;
       prev_chain = UINT32_MAX;
@@ -759,7 +797,7 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
                                  hw_has_b(o.op) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b, o.op, o.prime_gi};
   }
   args.seg_start[++n_seg] = (uint16_t)n_ops;
-  launch_hw_batch_ew(c->dc, args, n_seg, st);
+  emit_ew(c, args, n_seg, st);
 }
 
 // rotation run: gathers are independent unless a result aliases a source or result of the same launch
@@ -774,18 +812,17 @@ void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t
       cut = limbs_overlap(ops[k].res, ops[j].res, span) || limbs_overlap(ops[k].res, ops[j].a, span) ||
             limbs_overlap(ops[k].a, ops[j].res, span);
     if (cut) {
-      launch_hw_batch_rotate(c->dc, args, n_ops, st);
+      emit_rotate(c, args, n_ops, st);
       n_ops = 0;
       first = k;
     }
     args.op[n_ops++] = HwBatchOp{ops[k].res, ops[k].a, (const u64*)ops[k].b, ops[k].op, ops[k].prime_gi};
   }
-  launch_hw_batch_rotate(c->dc, args, n_ops, st);
+  emit_rotate(c, args, n_ops, st);
 }
 }  // namespace
 
-int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_stream s) {
-  if (int e = check_dev(c)) return e;
+static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st) {
   if (n == 0) return ACEHIP_OK;
   if (!ops) return fail(ACEHIP_EINVAL, "acehip_hw_batch: null op list");
   const u32 T = c->hp.L + c->hp.K;
@@ -806,8 +843,6 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
     if (o.op == ACEHIP_HW_ROTATE && limbs_overlap(o.res, o.a, span))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: in-place rotation is not supported");
   }
-  (void)hipSetDevice(c->device);
-  hipStream_t st = (hipStream_t)s;
   size_t i = 0;
   while (i < n) {
     size_t j = i;
@@ -817,12 +852,33 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
     else hw_run_ew(c, ops + i, j - i, st);
     i = j;
   }
-  stat(ST_EW, n - n_rot, (alg_words - 2 * n_rot) * span);
-  if (n_rot) {
-    stat(ST_ROTATE, n_rot, 2 * n_rot * span);
-    g_stat[ST_ROTATE].calls--;  // one entry point call, counted under elementwise
+  if (!g_plan) {
+    stat(ST_EW, n - n_rot, (alg_words - 2 * n_rot) * span);
+    if (n_rot) {
+      stat(ST_ROTATE, n_rot, 2 * n_rot * span);
+      g_stat[ST_ROTATE].calls--;  // one entry point call, counted under elementwise
+    }
   }
+  return ACEHIP_OK;
+}
+
+int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  (void)hipSetDevice(c->device);
+  if (int e = hw_batch_run(c, ops, n, (hipStream_t)s)) return e;
   return post_launch();
+}
+
+long acehip_hw_batch_plan(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_hw_op* out_ops, uint32_t* out_launch,
+                          uint32_t* out_segment, size_t cap, uint64_t scratch_base) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if ((cap && (!out_ops || !out_launch || !out_segment)) || !scratch_base) return fail(ACEHIP_EINVAL, "acehip_hw_batch_plan: bad output arguments");
+  HwPlanSink sink{out_ops, out_launch, out_segment, cap, 0, 0, scratch_base};
+  g_plan = &sink;
+  const int e = hw_batch_run(c, ops, n, nullptr);
+  g_plan = nullptr;
+  if (e) return e;
+  return (long)sink.n;
 }
 
 int acehip_decomp_modup(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, uint32_t digit, acehip_stream s) {

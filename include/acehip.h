@@ -141,6 +141,13 @@ typedef struct acehip_hw_op {
   const void*     b;         /* second operand (uint64 limb); uint32 automorphism table (ROTATE); residue (MULC/ADDC) */
 } acehip_hw_op;
 int acehip_hw_batch(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, acehip_stream stream);
+/* The same analysis without a GPU (works on a host-only context): what acehip_hw_batch WOULD launch, as a flat list of
+ * ops (dead zero fills / copies removed, intermediate versions renamed to scratch limbs starting at `scratch_base`, an
+ * arbitrary non-null address) with the launch and the chain segment each belongs to.  Ops of one segment run in list
+ * order, segments of a launch in any order, launches in order.  Returns the number of planned ops (may exceed `cap`,
+ * in which case only the first `cap` were written) or a negative error.  tests/test_hw_batch_plan.py replays plans. */
+long acehip_hw_batch_plan(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, acehip_hw_op* out_ops, uint32_t* out_launch,
+                          uint32_t* out_segment, size_t cap, uint64_t scratch_base);
 
 /* ---- RNS basis operations (NTT-domain in, NTT-domain out) ----
  * Decomp_modup (src/poly/poly_eval.c:28 -> Decompose_modup polynomial.c:1241-1335): digit `digit` of

@@ -1,0 +1,168 @@
+"""Host logic of acehip_hw_batch without a GPU: acehip_hw_batch_plan (include/acehip.h) returns what would be launched --
+dead zero fills / copies dropped, intermediate versions renamed to scratch limbs, ops grouped into chain segments per
+launch.  The plan is REPLAYED here on a numpy memory image: launches in order, the segments of a launch in a random order
+(they run concurrently on the GPU), ops of a segment in order.  Whatever the order, the final contents of the caller's
+memory must equal those of executing the original list one op at a time (the reference's call sequence,
+poly_arith.c:14-56).  Exact modular arithmetic via Python integers on a tiny ring (N = 8)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import ace_compiler_amd as A
+from ace_compiler_amd import binding as B
+
+N, L, Q0, SF, DNUM = 8, 4, 60, 56, 2
+BASE = 0x10000000          # fake device address of the arena (never dereferenced: plan only)
+SCRATCH = 0x7F0000000000   # fake scratch arena
+SPAN = N * 8
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = A.AceHip(N, L, Q0, SF, DNUM, host_only=True)
+    yield r
+    r.close()
+
+
+def _exec(mem, primes, perms, op, gi, res, a, b):
+    """one op on the address -> numpy row dictionary `mem` (object arrays of Python ints: exact)"""
+    q = primes[gi] if op not in (B.HW_ROTATE, B.HW_COPY, B.HW_ZERO) else None
+    if op == B.HW_ZERO:
+        out = [0] * N
+    elif op == B.HW_COPY:
+        out = list(mem[a])
+    elif op == B.HW_ROTATE:
+        out = [mem[a][j] for j in perms[b]]
+    elif op == B.HW_ADD:
+        out = [(x + y) % q for x, y in zip(mem[a], mem[b])]
+    elif op == B.HW_SUB:
+        out = [(x - y) % q for x, y in zip(mem[a], mem[b])]
+    elif op == B.HW_MUL:
+        out = [(x * y) % q for x, y in zip(mem[a], mem[b])]
+    elif op == B.HW_MULADD:
+        out = [(r + x * y) % q for r, x, y in zip(mem[res], mem[a], mem[b])]
+    elif op == B.HW_MULC:
+        out = [(x * b) % q for x in mem[a]]
+    else:  # ADDC
+        out = [(x + b) % q for x in mem[a]]
+    mem[res] = out
+
+
+def _plan(rt, prog):
+    arr = (B.HwOp * len(prog))(*[B.HwOp(o, g, r, a or None, b or None) for o, g, r, a, b in prog])
+    cap = 4 * len(prog) + 16
+    out = (B.HwOp * cap)()
+    launch = (C.c_uint32 * cap)()
+    seg = (C.c_uint32 * cap)()
+    n = rt.lib.acehip_hw_batch_plan(rt.h, arr, len(prog), out, launch, seg, cap, SCRATCH)
+    assert 0 <= n <= cap, (n, rt.err())
+    return [(out[i].op, out[i].prime_gi, out[i].res, out[i].a, out[i].b, launch[i], seg[i]) for i in range(n)]
+
+
+def _replay(plan, mem, primes, perms, rng):
+    by_launch = {}
+    for op, gi, res, a, b, la, sg in plan:
+        by_launch.setdefault(la, {}).setdefault(sg, []).append((op, gi, res, a, b))
+    for la in sorted(by_launch):
+        segs = list(by_launch[la].values())
+        rng.shuffle(segs)                       # concurrent chains: any order must do
+        for ops in segs:
+            for op, gi, res, a, b in ops:
+                for p in (res, a if op != B.HW_ZERO else None, b if op in (B.HW_ADD, B.HW_SUB, B.HW_MUL, B.HW_MULADD) else None):
+                    if p is not None and p not in mem:
+                        assert p >= SCRATCH, "plan names an address outside the caller's limbs and the scratch arena"
+                        mem[p] = ["uninitialised"] * N   # reading it before a write would poison the result
+                _exec(mem, primes, perms, op, gi, res, a, b)
+
+
+def _random_program(rt, rng, n_limbs, n_ops, with_rot):
+    T = rt.L + rt.K
+    prog = []
+    perm_keys = [1, 2]
+    while len(prog) < n_ops:
+        if with_rot and rng.random() < 0.15:
+            k = rng.choice(perm_keys)
+            for _ in range(rng.randint(1, 6)):
+                g = rng.randrange(T)
+                r, a = rng.sample(range(g, n_limbs, T), 2)
+                prog.append((B.HW_ROTATE, g, BASE + r * SPAN, BASE + a * SPAN, k))
+        else:
+            for _ in range(rng.randint(1, 30)):
+                g = rng.randrange(T)
+                r, a, b = (BASE + rng.choice(range(g, n_limbs, T)) * SPAN for _ in range(3))
+                op = rng.choice([B.HW_ADD, B.HW_ADD, B.HW_MUL, B.HW_MUL, B.HW_COPY, B.HW_ZERO, B.HW_ZERO, B.HW_SUB,
+                                 B.HW_MULADD, B.HW_MULADD, B.HW_MULC, B.HW_ADDC])
+                if op in (B.HW_MULC, B.HW_ADDC):
+                    b = rng.randrange(rt.primes[g])
+                prog.append((op, g, r, a, b))
+    return prog[:n_ops]
+
+
+def _check(rt, prog, n_limbs, seed):
+    rng = random.Random(seed)
+    T = rt.L + rt.K
+    perms = {1: [rng.randrange(N) for _ in range(N)], 2: list(reversed(range(N)))}  # any index table will do
+    mem0 = {BASE + i * SPAN: [rng.randrange(rt.primes[i % T]) for _ in range(N)] for i in range(n_limbs)}
+    want = {k: list(v) for k, v in mem0.items()}
+    for op, gi, res, a, b in prog:
+        _exec(want, rt.primes, perms, op, gi, res, a, b)
+    plan = _plan(rt, prog)
+    for trial in range(3):                      # three different interleavings of the concurrent segments
+        got = {k: list(v) for k, v in mem0.items()}
+        _replay(plan, got, rt.primes, perms, random.Random(seed * 7 + trial))
+        for addr in mem0:
+            assert got[addr] == want[addr], (hex(addr), trial)
+    return plan
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_programs_replay_to_the_sequential_result(rt, seed):
+    rng = random.Random(100 + seed)
+    T = rt.L + rt.K
+    prog = _random_program(rt, rng, n_limbs=3 * T, n_ops=rng.choice([40, 150, 400]), with_rot=seed % 2 == 0)
+    _check(rt, prog, 3 * T, seed)
+
+
+def test_generated_key_inner_product_is_split_into_independent_chains(rt):
+    """resnet20_cifar10_pre.onnx.inc:7011-7036: every product goes through ONE scratch limb; after renaming there must be
+    (at least) one chain per limb and component instead of a single serial chain, and the dead zero fills must be gone"""
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    tmp = at(9, 0)
+    prog = [(B.HW_ZERO, 0, at(4, g), 0, 0) for g in range(T)] + [(B.HW_ZERO, 0, at(5, g), 0, 0) for g in range(T)]
+    for g in range(T):
+        prog += [(B.HW_MUL, g, tmp, at(2, g), at(0, g)), (B.HW_ADD, g, at(4, g), at(4, g), tmp),
+                 (B.HW_MUL, g, tmp, at(3, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
+    plan = _check(rt, prog, 10 * T, 5)
+    assert len({(la, sg) for *_, la, sg in plan}) >= 2 * T - 1      # independent chains
+    assert sum(1 for p in plan if p[2] >= SCRATCH) == 2 * T - 2     # every product but the first and the last goes to a private limb
+    # the zero fills are needed here (the accumulators are read), none may be dropped
+    assert sum(1 for p in plan if p[0] == B.HW_ZERO) == 2 * T
+
+
+def test_dead_zero_fills_and_copies_are_dropped(rt):
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    prog = []
+    for g in range(T):   # Alloc_poly zero fill, then the Hw_* loop overwrites the limb: the fill is dead
+        prog += [(B.HW_ZERO, 0, at(2, g), 0, 0), (B.HW_COPY, 0, at(3, g), at(0, g), 0), (B.HW_MUL, g, at(2, g), at(0, g), at(1, g)),
+                 (B.HW_ADD, g, at(3, g), at(0, g), at(1, g))]
+    plan = _check(rt, prog, 4 * T, 6)
+    assert not any(p[0] in (B.HW_ZERO, B.HW_COPY) for p in plan)
+    assert len(plan) == 2 * T
+
+
+def test_partially_overlapping_limbs_run_one_by_one(rt):
+    prog = [(B.HW_ADD, 0, BASE, BASE, BASE + SPAN // 2), (B.HW_MUL, 0, BASE + 2 * SPAN, BASE + SPAN // 2, BASE)]
+    plan = _plan(rt, prog)
+    # no reordering: one launch per op (plus the private copies of operands that overlap a result)
+    assert [p[5] for p in plan] == sorted(p[5] for p in plan) and len({p[5] for p in plan}) == len(plan)
+
+
+def test_argument_errors(rt):
+    bad = (B.HwOp * 1)(B.HwOp(B.HW_ADD, 99, BASE, BASE, BASE))
+    out, la, sg = (B.HwOp * 4)(), (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+    assert rt.lib.acehip_hw_batch_plan(rt.h, bad, 1, out, la, sg, 4, SCRATCH) < 0
+    assert rt.lib.acehip_hw_batch_plan(rt.h, bad, 1, out, la, sg, 4, 0) < 0
