@@ -116,7 +116,6 @@ std::vector<u64> const_residues(double value, u32 level, u32 sf_degree) {
 }
 
 void add_const(Ct& r, Ct& a, double v) {
-  Context& c = ctx();
   if (&r != &a) copy(r, a);
   const u32 l = r.level();
   std::vector<u64> k = const_residues(v, l, r.c._sf_degree);
@@ -280,7 +279,6 @@ CIPHER Mul_plain(CIPHER res, CIPHER a, PLAIN p) {
 // Mul_ciphertext3 :130-165
 CIPHER3 Mul_ciph3(CIPHER3 res, CIPHER a, CIPHER b) {
   Init_ciph3_up_scale(res, a, b);
-  Context& c = ctx();
   const u32 l = (u32)res->_c0_poly._num_primes;
   q_ew(ACEHIP_HW_MUL, q_limbs(&res->_c0_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c0_poly), l, 0, l);
   q_ew(ACEHIP_HW_MUL, q_limbs(&res->_c1_poly), q_limbs(&a->_c0_poly), q_limbs(&b->_c1_poly), l, 0, l);

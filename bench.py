@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N, L, Q0, SF, DNUM = 65536, 25, 60, 56, 4   # C2/C3 parameter set
+# the reference's published ResNet-20/CIFAR-10 run, 1453.96 s per image on one Xeon 8369B core
+# (scripts/ace_pre.log:28) -- the same metric on the reference's own hardware
+BASELINE_IMAGES_PER_S = 1.0 / 1453.96
 N_CT = 16                                    # ciphertext pairs in the resident NTT batch
 MODEL_LIB = os.path.join(ROOT, "build", "models", "libmodel_resnet20.so")
 
@@ -376,7 +379,7 @@ def main():
         out = {
             "metric": metric, "value": round(value, 6), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "vs_baseline": (round(value / BASELINE_IMAGES_PER_S, 1) if use_model else None), "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "N": 65536, "streams_per_gpu": n_streams, "images_per_step": world * n_streams,
                        "parallelism": "replicas: %d GPU(s) x %d image stream(s) per GPU" % (world, n_streams)},
             "roofline": {"bound": "hbm",
