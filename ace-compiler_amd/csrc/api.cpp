@@ -505,6 +505,7 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
   std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b, cur, last_pure;
   std::vector<u64> node_ptr;  // address of every node (limb)
   std::vector<char> written, dead, state;
+  std::vector<u32> kind, readers;  // effective op kind after fusion; reads of every node
 };
 thread_local HwScratch g_hw;
 
@@ -746,14 +747,43 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     }
   }
   const u32 n_nodes = (u32)h.parent.size();
+  h.kind.resize(m);
+  for (size_t k = 0; k < m; ++k) h.kind[k] = ops[k].op;
+  // fuse  t = a*b ; acc = acc + t  into  acc += a*b  when t is a private scratch version nobody else reads: the product
+  // never goes to memory and runs of such pairs on one accumulator keep it in registers (hw_batch_ew_kernel)
+  if (n_nodes > n_base) {
+    h.readers.assign(n_nodes, 0);
+    for (size_t k = 0; k < m; ++k) {
+      if (h.dead[k]) continue;
+      if (hw_has_a(ops[k].op)) h.readers[h.n_a[k]]++;
+      if (hw_has_b(ops[k].op)) h.readers[h.n_b[k]]++;
+      if (ops[k].op == ACEHIP_HW_MULADD) h.readers[h.n_res[k]]++;
+    }
+    size_t prev = SIZE_MAX;  // previous live op
+    for (size_t k = 0; k < m; ++k) {
+      if (h.dead[k]) continue;
+      const size_t p = prev;
+      prev = k;
+      if (p == SIZE_MAX || ops[k].op != ACEHIP_HW_ADD || ops[p].op != ACEHIP_HW_MUL) continue;
+      const u32 t = h.n_res[p], acc = h.n_res[k];
+      if (t < n_base || h.readers[t] != 1 || ops[p].prime_gi != ops[k].prime_gi) continue;
+      const bool acc_a = h.n_a[k] == acc && h.n_b[k] == t, acc_b = h.n_b[k] == acc && h.n_a[k] == t;
+      if (!(acc_a || acc_b) || acc == t) continue;
+      h.kind[k] = ACEHIP_HW_MULADD;
+      h.n_a[k] = h.n_a[p];
+      h.n_b[k] = h.n_b[p];
+      h.dead[p] = 1;
+      --live;
+    }
+  }
   h.written.assign(n_nodes, 0);
   for (size_t k = 0; k < m; ++k)
     if (!h.dead[k]) h.written[h.n_res[k]] = 1;
   for (size_t k = 0; k < m; ++k) {
     if (h.dead[k]) continue;
     const u32 r = uf_find(h.parent, h.n_res[k]);
-    if (hw_has_a(ops[k].op) && h.written[h.n_a[k]]) h.parent[uf_find(h.parent, h.n_a[k])] = r;
-    if (hw_has_b(ops[k].op) && h.written[h.n_b[k]]) h.parent[uf_find(h.parent, h.n_b[k])] = uf_find(h.parent, r);
+    if (hw_has_a(h.kind[k]) && h.written[h.n_a[k]]) h.parent[uf_find(h.parent, h.n_a[k])] = r;
+    if (hw_has_b(h.kind[k]) && h.written[h.n_b[k]]) h.parent[uf_find(h.parent, h.n_b[k])] = uf_find(h.parent, r);
   }
   // chains numbered by first appearance; ops of a chain keep their program order
   h.comp_of_node.assign(n_nodes, UINT32_MAX);
@@ -793,8 +823,9 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     prev_chain = chain;
     const u32 k = h.ord[t];
     const acehip_hw_op& o = ops[k];
-    args.op[n_ops++] = HwBatchOp{(u64*)h.node_ptr[h.n_res[k]], hw_has_a(o.op) ? (const u64*)h.node_ptr[h.n_a[k]] : nullptr,
-                                 hw_has_b(o.op) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b, o.op, o.prime_gi};
+    const u32 kind = h.kind[k];
+    args.op[n_ops++] = HwBatchOp{(u64*)h.node_ptr[h.n_res[k]], hw_has_a(kind) ? (const u64*)h.node_ptr[h.n_a[k]] : nullptr,
+                                 hw_has_b(kind) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b, kind, o.prime_gi};
   }
   args.seg_start[++n_seg] = (uint16_t)n_ops;
   emit_ew(c, args, n_seg, st);

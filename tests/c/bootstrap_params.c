@@ -26,7 +26,7 @@ bool Main_graph() {
     Encode_plain_from_float(&pt, one, Slots, Sc_degree(&cur), Level(&cur));
     Mul_plain(&mp, &cur, &pt);
     Rescale_ciph(&rs, &mp);
-    Free_plain(&pt);
+    Free_poly_data(&pt._poly);
     Free_ciph_poly(&mp, 1);
     Free_ciph_poly(&cur, 1);
     cur = rs;

@@ -137,7 +137,11 @@ def test_generated_key_inner_product_is_split_into_independent_chains(rt):
                  (B.HW_MUL, g, tmp, at(3, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
     plan = _check(rt, prog, 10 * T, 5)
     assert len({(la, sg) for *_, la, sg in plan}) >= 2 * T - 1      # independent chains
-    assert sum(1 for p in plan if p[2] >= SCRATCH) == 2 * T - 2     # every product but the first and the last goes to a private limb
+    # every product but the first and the last would go to a private limb and is consumed by exactly one add:
+    # those pairs become one multiply-add each and the product never reaches memory
+    assert sum(1 for p in plan if p[2] >= SCRATCH) == 0
+    assert sum(1 for p in plan if p[0] == B.HW_MULADD) == 2 * T - 2
+    assert sum(1 for p in plan if p[0] == B.HW_MUL) == 2 and sum(1 for p in plan if p[0] == B.HW_ADD) == 2
     # the zero fills are needed here (the accumulators are read), none may be dropped
     assert sum(1 for p in plan if p[0] == B.HW_ZERO) == 2 * T
 
