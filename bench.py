@@ -237,6 +237,10 @@ def main():
                         read_stats(reset=True)                 # statistics are per thread as well
                     elif op == "stats":
                         stream_stats[i] = read_stats(reset=False)
+                    elif op == "release":
+                        fhe.Finalize_context()                 # a worker's Finalize only gives back its own state
+                    elif op == "attach":
+                        fhe.Prepare_context()
                     gate.wait()
                     if op == "quit":
                         break
@@ -311,30 +315,29 @@ def main():
     value = world * n_streams * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
-    if use_model:  # the image streams leave the GPU before the micro workloads are timed
-        run_all("quit")
+    if use_model:
+        if world == 1:
+            # secondary, NOT the headline: the same streams with the encoded weight plaintexts kept in HBM
+            # (ACEHIP_PT_CACHE=1, 12.3 GB shared by the streams; the reference's pre-encoded DE_PLAINTEXT mode)
+            run_all("release")
+            fhe.Finalize_context()
+            os.environ["ACEHIP_PT_CACHE"] = "1"
+            fhe.Prepare_context()
+            run_all("attach")
+            step(1)  # fills the cache
+            tc = time.perf_counter()
+            step(2)
+            dt = (time.perf_counter() - tc) / 2
+            os.environ["ACEHIP_PT_CACHE"] = "0"
+            cache_run = {"images_per_s": round(n_streams / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
+                         "streams_per_gpu": n_streams,
+                         "note": "ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB, shared by the "
+                                 "image streams); reported beside the headline, which encodes all 6044 plaintexts for every "
+                                 "image like the reference run does"}
+        run_all("quit")  # the image streams leave the GPU before the micro workloads are timed
         for t in threads:
             t.join()
         fhe.Finalize_context()
-        _, step = load_model_runtime(local_rank)  # single stream on this thread for the secondary run below
-        if world == 1:
-            # secondary, NOT the headline: the same workload with the encoded weight plaintexts kept in HBM
-            # (ACEHIP_PT_CACHE=1, 12.3 GB; the reference's pre-encoded DE_PLAINTEXT mode)
-            os.environ["ACEHIP_PT_CACHE"] = "1"
-            fhe.Prepare_context()
-            step()  # fills the cache
-            rt.sync()
-            tc = time.perf_counter()
-            for _ in range(2):
-                step()
-            rt.sync()
-            dt = (time.perf_counter() - tc) / 2
-            fhe.Finalize_context()
-            os.environ["ACEHIP_PT_CACHE"] = "0"
-            cache_run = {"images_per_s": round(1.0 / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
-                         "note": "single stream, ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB); "
-                                 "reported beside the headline, which encodes all 6044 plaintexts for every image "
-                                 "like the reference run does"}
 
     # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
     n_polys = 2 * N_CT
