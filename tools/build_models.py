@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Compile the reference's checked-in ACE-generated model sources (rtlib/ant/dataset/*.onnx.inc), unchanged
-and from where they lie under /root/reference, into build/models/libmodel_<name>.so against OUR headers.
+and from where they lie under /root/reference, into oracle/_ref/models/libmodel_<name>.so against OUR headers
+(everything compiled from reference sources lives under oracle/_ref/, which is git-ignored).
 These libraries are the benchmark workload (BASELINE.json configs[3]/[4]); they only exist where
-/root/reference exists (dev container) and travel to the GPU box with the snapshot (build/ is git-ignored).
+/root/reference exists (dev container) and travel to the GPU box with the snapshot.
 """
 import os
 import subprocess
@@ -10,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/fhe-cmplr/rtlib/ant/dataset"
-OUT = os.path.join(ROOT, "build", "models")
+OUT = os.path.join(ROOT, "oracle", "_ref", "models")
 MODELS = {"resnet20": "resnet20_cifar10_pre.onnx.inc", "resnet110": "resnet110_cifar10_train.onnx.inc"}
 
 
@@ -27,7 +28,7 @@ def build(verbose=False):
             continue
         cmd = ["gcc", "-O1", "-w", "-fPIC", "-shared", os.path.join(ROOT, "tools", "model_lib.c"),
                "-DMODEL_INC=\"%s\"" % src, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "include", "rt_ant"),
-               "-L", os.path.join(ROOT, "ace-compiler_amd", "lib"), "-lFHErt_ant", "-Wl,-rpath,$ORIGIN/../../ace-compiler_amd/lib",
+               "-L", os.path.join(ROOT, "ace-compiler_amd", "lib"), "-lFHErt_ant", "-Wl,-rpath,$ORIGIN/../../../ace-compiler_amd/lib",
                "-o", out]
         if verbose:
             print(" ".join(cmd))
