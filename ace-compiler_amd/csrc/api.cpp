@@ -53,6 +53,9 @@ T* upload(const std::vector<T>& v) {
 struct KsPlan {
   ConvDesc* d_descs = nullptr;  // [nd] ModUp problems, then [1] ModDown problem
   u32 nd = 0, max_nc = 0;
+  // N = 2^16: the pre-factors of both base conversions ride in the last stage of the inverse NTT (NttFuse::inv_scale)
+  u64* inv_up = nullptr;    // [level][4]
+  u64* inv_down = nullptr;  // [K][4]
 };
 
 struct acehip_ctx {
@@ -942,6 +945,7 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
     NttFuse fi;
     fi.src0 = in0 + QL;
     fi.src1 = in1 ? in1 + QL : nullptr;
+    fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
     launch_ntt_fused(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
   } else {
     HIP_TRY(hipMemcpyAsync(pc, in0 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
@@ -1081,14 +1085,28 @@ static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   const HostParams& hp = c->hp;
   KsPlan plan;
   plan.nd = hp.num_decomp(level);
+  const bool fold = c->dc.logN == 16;
+  std::vector<u64> inv_up(4 * (size_t)level, 0), inv_down(4 * (size_t)hp.K, 0);
   std::vector<ConvDesc> descs;
   for (u32 d = 0; d < plan.nd; ++d) {
     const DevModUp* t = get_modup(c, level, d);
     if (!t) return nullptr;
     ConvDesc cd{};
     cd.hat = t->hat_mod;
-    cd.scale = t->hat_inv;
-    cd.scale_prec = t->hat_inv_prec;
+    cd.scale = fold ? nullptr : t->hat_inv;
+    cd.scale_prec = fold ? nullptr : t->hat_inv_prec;
+    if (fold) {
+      HostParams::ModUp hm = hp.modup(level, d);
+      for (u32 i = 0; i < hm.n2; ++i) {
+        const PrimeConsts& P = hp.primes[hm.start + i];
+        const u64 tn = mul_mod(P.n_inv, hm.hat_inv[i], P.q), tw = mul_mod(P.inv_w1_ninv, hm.hat_inv[i], P.q);
+        u64* o = &inv_up[4 * (size_t)(hm.start + i)];
+        o[0] = tn;
+        o[1] = shoup_prec(tn, P.q);
+        o[2] = tw;
+        o[3] = shoup_prec(tw, P.q);
+      }
+    }
     cd.src_gi = t->src_gi;
     cd.out_gi = t->out_gi;
     cd.out_pos = t->out_pos;
@@ -1101,8 +1119,17 @@ static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   }
   ConvDesc md{};  // ModDown: K p-limbs at positions level.. -> level q-limbs (polynomial.c:755-807)
   md.hat = c->phat_modq_t;
-  md.scale = c->phat_inv;
-  md.scale_prec = c->phat_inv_prec;
+  md.scale = fold ? nullptr : c->phat_inv;
+  md.scale_prec = fold ? nullptr : c->phat_inv_prec;
+  if (fold)
+    for (u32 j = 0; j < hp.K; ++j) {
+      const PrimeConsts& P = hp.primes[hp.L + j];
+      const u64 tn = mul_mod(P.n_inv, hp.phat_inv_modp[j], P.q), tw = mul_mod(P.inv_w1_ninv, hp.phat_inv_modp[j], P.q);
+      inv_down[4 * j + 0] = tn;
+      inv_down[4 * j + 1] = shoup_prec(tn, P.q);
+      inv_down[4 * j + 2] = tw;
+      inv_down[4 * j + 3] = shoup_prec(tw, P.q);
+    }
   md.src_gi = c->p_gi;
   md.out_gi = c->q_gi;
   md.out_pos = c->q_pos;
@@ -1114,6 +1141,11 @@ static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   std::lock_guard<std::mutex> lk(c->mu);
   plan.d_descs = c->up(descs);
   if (!plan.d_descs) return nullptr;
+  if (fold) {
+    plan.inv_up = c->up(inv_up);
+    plan.inv_down = c->up(inv_down);
+    if (!plan.inv_up || !plan.inv_down) return nullptr;
+  }
   return &(c->ks_plans[level] = plan);
 }
 
@@ -1138,6 +1170,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   if (fused) {
     NttFuse fi;
     fi.src0 = in;
+    fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
     launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
   } else {
     HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
@@ -1151,7 +1184,13 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
   launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
   // 5. ModDown of both accumulators together (polynomial.c:928-967)
-  launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
+  if (fused) {
+    NttFuse fa;
+    fa.inv_scale = plan->inv_down - 4 * (size_t)level;  // the p-limbs sit at positions level .. level+K-1
+    launch_ntt_fused(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E, 0, fa);
+  } else {
+    launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
+  }
   launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s);
   if (fused) {  // the ModDown tail rides in the last NTT pass
     NttFuse fo;
@@ -1331,6 +1370,7 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
   if (c->dc.logN == 16) {
     NttFuse fi;
     fi.src0 = in;
+    fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
     launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
   } else {
     HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));

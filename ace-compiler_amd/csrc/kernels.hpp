@@ -61,6 +61,9 @@ struct NttFuse {
   // inverse, last pass: store the centred representative (x > q/2 ? x - q : x, as int64) instead of x, i.e. the
   // `msg` of a following forward transform over other primes (Rescale, ModRaise)
   bool center_out = false;
+  // inverse, last pass: per limb position {N^-1*c, its Shoup companion, w1^-1*N^-1*c, companion} replacing the prime's
+  // own last-stage constants: the base-conversion pre-factor c = (Q_d/q_i)^-1 (or (P/p_j)^-1) costs nothing this way
+  const u64* inv_scale = nullptr;
   // forward, last pass: v = NTT value; 1: out = x*w + v (Rescale tail polynomial.c:1145-1158),
   // 2: out = (x - v)*w (ModDown tail :956-965); x_z, out_z are polynomials of q-limbs, w/wp per limb
   int epi = 0;

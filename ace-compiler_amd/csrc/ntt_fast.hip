@@ -162,7 +162,12 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
     radix16_inv_321(x, t1, t2, t3, q, q2);
-    const Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+    Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+    if (f.inv_scale) {
+      const u64* sc = f.inv_scale + 4 * (size_t)pos;
+      tn = Tw{sc[0], sc[1]};
+      tw = Tw{sc[2], sc[3]};
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const u64 s = x[k] + x[k + 8];            // [0,4q)
