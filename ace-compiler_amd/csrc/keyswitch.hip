@@ -7,7 +7,7 @@
 namespace acehip {
 
 constexpr int kMaxIn = 16;   // alpha, K <= 12 for the reference parameter sets
-constexpr int kGroup = 4;    // output limbs per workgroup row (sources stay in registers)
+constexpr int kGroup = 8;    // output limbs per workgroup row (sources stay in registers)
 
 // out[pos_j][n] = ( sum_i y_i[n] * hat[i][j] ) mod t_j,  y_i = in[src_pos0+i][n] (* scale_i mod q_i)
 __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
