@@ -10,62 +10,108 @@
 
 namespace acehip {
 
-// Every lane owns coefficients (i, i+1) of all limbs of its segment: read-after-write between ops of a chain goes
+// Every lane owns ACEHIP_HW_LANES (2 or 4) consecutive coefficients of all limbs of its segment: read-after-write between ops of a chain goes
 // through the lane itself.  The previous result stays in registers: an operand that is the previous op's result
 // limb is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
 // (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run always stores, so
 // every later reader -- in this segment, another launch or the host -- finds the final value in memory).
-// CAP: capacity of the argument table (a launch with few ops ships a small kernel-argument block)
+// Measured on ResNet-20 (1 stream s/image | 4 streams images/s): 2 lanes 1.466 | 1.324, 4 lanes 1.460 | 1.316, with the
+// per-prime constants staged in LDS (ACEHIP_HW_STAGE=1) 1.42 | 1.29-1.31: the defaults are the best throughput.
+#ifndef ACEHIP_HW_LANES
+#define ACEHIP_HW_LANES 2
+#endif
+constexpr u32 kHwLanes = ACEHIP_HW_LANES;   // coefficients per lane (one or two 16-byte accesses)
+#ifndef ACEHIP_HW_STAGE
+#define ACEHIP_HW_STAGE 0
+#endif
+constexpr u32 kMaxPrimes = ACEHIP_HW_STAGE ? 96 : 1;   // per-prime constants staged in LDS (0: read them from memory)
+
+struct V4 {
+  ulong2 lo, hi;
+};
+__device__ __forceinline__ V4 ld4(const u64* p) {
+  if (kHwLanes == 2) return V4{*reinterpret_cast<const ulong2*>(p), ulong2{0, 0}};
+  return V4{*reinterpret_cast<const ulong2*>(p), *reinterpret_cast<const ulong2*>(p + 2)};
+}
+__device__ __forceinline__ void st4(u64* p, const V4& v) {
+  *reinterpret_cast<ulong2*>(p) = v.lo;
+  if (kHwLanes == 4) *reinterpret_cast<ulong2*>(p + 2) = v.hi;
+}
+template <typename F>
+__device__ __forceinline__ V4 map2(const V4& a, const V4& b, F f) {
+  V4 r;
+  r.lo.x = f(a.lo.x, b.lo.x);
+  r.lo.y = f(a.lo.y, b.lo.y);
+  if (kHwLanes == 4) {
+    r.hi.x = f(a.hi.x, b.hi.x);
+    r.hi.y = f(a.hi.y, b.hi.y);
+  } else {
+    r.hi = ulong2{0, 0};
+  }
+  return r;
+}
+
 template <int CAP>
 __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
-  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  __shared__ u64 s_q[kMaxPrimes], s_mu[kMaxPrimes];
+  __shared__ u32 s_nb[kMaxPrimes];
+  if (ACEHIP_HW_STAGE) {
+    const u32 n_primes = c.L + c.K;
+    if (threadIdx.x < n_primes && threadIdx.x < kMaxPrimes) {
+      const DevPrime& P = c.primes[threadIdx.x];
+      s_q[threadIdx.x] = P.q;
+      s_mu[threadIdx.x] = P.barrett_mu;
+      s_nb[threadIdx.x] = P.nbits;
+    }
+    __syncthreads();
+  }
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * kHwLanes;
   if (i >= c.N) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
   const u64* prev_res = nullptr;
-  ulong2 vprev{0, 0};
+  V4 vprev{{0, 0}, {0, 0}};
   for (u32 k = beg; k < end; ++k) {
     const HwBatchOp op = args.op[k];
     const bool keep_in_regs = k + 1 < end && args.op[k + 1].res == op.res;
-    ulong2 vr;
+    V4 vr;
     if (op.kind == HW_OP_ZERO) {
-      vr.x = 0;
-      vr.y = 0;
+      vr = V4{{0, 0}, {0, 0}};
     } else {
-      const ulong2 va = op.a == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.a + i);
+      const V4 va = op.a == prev_res ? vprev : ld4(op.a + i);
       if (op.kind == HW_OP_COPY) {
         vr = va;
       } else {
-        const DevPrime P = c.primes[op.gi];
-        ulong2 vb;
+        const bool staged = ACEHIP_HW_STAGE && op.gi < kMaxPrimes;  // larger prime sets read the rest from memory
+        const u64 q = staged ? s_q[op.gi] : c.primes[op.gi].q, mu = staged ? s_mu[op.gi] : c.primes[op.gi].barrett_mu;
+        const u32 nb = staged ? s_nb[op.gi] : c.primes[op.gi].nbits;
+        V4 vb;
         if (op.kind == HW_OP_MULC || op.kind == HW_OP_ADDC) {  // the second operand is an immediate
-          vb.x = vb.y = (u64)(uintptr_t)op.b;
+          const u64 imm = (u64)(uintptr_t)op.b;
+          vb = V4{{imm, imm}, {imm, imm}};
         } else {
-          vb = op.b == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.b + i);
+          vb = op.b == prev_res ? vprev : ld4(op.b + i);
         }
         switch (op.kind) {
           case HW_OP_ADD:
           case HW_OP_ADDC:
-            vr.x = add_mod(va.x, vb.x, P.q);
-            vr.y = add_mod(va.y, vb.y, P.q);
+            vr = map2(va, vb, [q](u64 x, u64 y) { return add_mod(x, y, q); });
             break;
           case HW_OP_SUB:
-            vr.x = sub_mod(va.x, vb.x, P.q);
-            vr.y = sub_mod(va.y, vb.y, P.q);
+            vr = map2(va, vb, [q](u64 x, u64 y) { return sub_mod(x, y, q); });
             break;
           case HW_OP_MULADD: {
-            const ulong2 acc = op.res == prev_res ? vprev : *reinterpret_cast<const ulong2*>(op.res + i);
-            vr.x = add_mod(acc.x, mul_mod(va.x, vb.x, P), P.q);
-            vr.y = add_mod(acc.y, mul_mod(va.y, vb.y, P), P.q);
+            const V4 acc = op.res == prev_res ? vprev : ld4(op.res + i);
+            const V4 pr = map2(va, vb, [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
+            vr = map2(acc, pr, [q](u64 x, u64 y) { return add_mod(x, y, q); });
             break;
           }
           default:  // HW_OP_MUL, HW_OP_MULC
-            vr.x = mul_mod(va.x, vb.x, P);
-            vr.y = mul_mod(va.y, vb.y, P);
+            vr = map2(va, vb, [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
             break;
         }
       }
     }
-    if (!keep_in_regs) *reinterpret_cast<ulong2*>(op.res + i) = vr;
+    if (!keep_in_regs) st4(op.res + i, vr);
     prev_res = op.res;
     vprev = vr;
   }
@@ -94,7 +140,7 @@ static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
 
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
   if (n_seg == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_seg), block(256);
+  dim3 grid((c.N / kHwLanes + 255) / 256, n_seg), block(256);
   const u32 n_ops = args.seg_start[n_seg];
   if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));
   else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));
