@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
       for (int k = 0; k < 16; ++k) {
         const int64_t v = f.msg[blockIdx.z * f.msg_stride + ((size_t)(16 * k + hg) << log_s) + col];
         const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
-        u64 r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
+        u64 r = mag;
+        if (__any(mag >= q))  // encoded weights are far below the primes: the wide reduction is the rare path, skip it per wave
+          r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
         if (v < 0 && r != 0) r = q - r;
         x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
       }
