@@ -1242,6 +1242,17 @@ static int ensure_embed_tables(acehip_ctx* c) {
   }
   std::vector<u32> rot(N / 2 ? N / 2 : 1, 1);
   for (size_t i = 1; i < N / 2; ++i) rot[i] = (u32)((5ull * rot[i - 1]) % m);
+  // per-stage layout of the twiddles Embedding_inv uses: stage logm, butterfly i < 2^(logm-1)
+  std::vector<double> tws(2 * (N / 2 ? N / 2 : 1), 0.0);
+  for (u32 logm = 1; (1ull << logm) <= N / 2; ++logm) {
+    const size_t idx_mod = 1ull << (logm + 2), gap = m / idx_mod, half = 1ull << (logm - 1);
+    for (size_t i = 0; i < half; ++i) {
+      const size_t k = (idx_mod - (rot[i] % idx_mod)) * gap;
+      tws[2 * (half - 1 + i)] = rou[2 * k];
+      tws[2 * (half - 1 + i) + 1] = rou[2 * k + 1];
+    }
+  }
+  rou.swap(tws);  // the device gets the per-stage table (the flat one is only needed to build it)
   u32* d_rot = c->up(rot);
   double* d_rou = c->up(rou);
   void *work = nullptr, *msg = nullptr, *err = nullptr;

@@ -30,13 +30,11 @@ __device__ __forceinline__ cd load_value(const void* __restrict__ vals, int kind
   return cd{p[0], p[1]};
 }
 
-// twiddle of butterfly i at stage logm: rou[(idx_mod - rot_group[i] % idx_mod) * gap], idx_mod = 2^(logm+2)
-__device__ __forceinline__ cd stage_twiddle(const cd* __restrict__ rou, const u32* __restrict__ rot_group, u32 log2m, u32 logm,
-                                            u32 i) {
-  const u32 idx_mod = 1u << (logm + 2);
-  const u32 gap_shift = log2m - (logm + 2);
-  const u32 k = (idx_mod - (rot_group[i] & (idx_mod - 1))) << gap_shift;
-  return rou[k];
+// twiddle of butterfly i at stage logm: rou[(idx_mod - rot_group[i] % idx_mod) * gap], idx_mod = 2^(logm+2), as the
+// reference looks it up (ntt.c:728-736); the host lays the values out per stage, tws[2^(logm-1) - 1 + i], so that
+// the lanes of a wave read consecutive entries instead of chasing two tables
+__device__ __forceinline__ cd stage_twiddle(const cd* __restrict__ tws, const u32* __restrict__, u32, u32 logm, u32 i) {
+  return tws[(1u << (logm - 1)) - 1 + i];
 }
 
 constexpr u32 EMB_LOW = 8;    // stages 8..1 run on 256 contiguous values per workgroup
