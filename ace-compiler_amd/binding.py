@@ -69,6 +69,7 @@ SYMBOLS = [
     ("acehip_mod_down2", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_rescale2", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_mod_raise", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_base_conv", C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp, _u32, _vp]),
     ("acehip_key_switch", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_switch_bytes", _u64, [_vp, _u32]),
     ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),

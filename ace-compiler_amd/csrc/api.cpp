@@ -1017,6 +1017,77 @@ int acehip_mod_raise(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64
   return post_launch();
 }
 
+// Base conversion onto a SUBSET of the target limbs (limb-sharded execution, SURVEY 8e: every GPU converts only the
+// limbs it owns once the source limbs have been gathered).  which = digit index (ModUp of that digit at `level`,
+// sources = the digit's limbs in the coefficient domain, NOT yet scaled) or ACEHIP_CONV_MODDOWN (sources = the K
+// p-limbs in the coefficient domain).  d_in: the n_in source limbs, contiguous; h_out_pos: target limb positions (in the
+// polynomial extended at `level`); d_out: n_out limbs, output k is the limb at h_out_pos[k], coefficient domain.
+int acehip_base_conv(acehip_ctx* c, uint64_t* d_out, const uint64_t* d_in, uint32_t level, int which, const uint32_t* h_out_pos,
+                     uint32_t n_out, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  const HostParams& hp = c->hp;
+  if (level == 0 || level > hp.L || !d_out || !d_in || !h_out_pos || n_out == 0 || n_out > hp.L + hp.K)
+    return fail(ACEHIP_EINVAL, "acehip_base_conv: bad arguments");
+  std::vector<u32> gi(n_out), col(n_out), pos(n_out);
+  ConvDesc cd{};
+  if (which == ACEHIP_CONV_MODDOWN) {
+    for (u32 k = 0; k < n_out; ++k) {
+      if (h_out_pos[k] >= level) return fail(ACEHIP_EINVAL, "acehip_base_conv: ModDown targets are q-limbs below the level");
+      gi[k] = col[k] = h_out_pos[k];
+      pos[k] = k;
+    }
+    cd.hat = c->phat_modq_t;
+    cd.scale = c->phat_inv;
+    cd.scale_prec = c->phat_inv_prec;
+    cd.src_gi = c->p_gi;
+    cd.n_in = hp.K;
+    cd.hat_ld = hp.L;
+  } else {
+    if (which < 0 || (u32)which >= hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_base_conv: bad digit");
+    const DevModUp* t = get_modup(c, level, (u32)which);
+    if (!t) return fail(ACEHIP_EHIP, "ModUp table upload failed");
+    HostParams::ModUp hm = hp.modup(level, (u32)which);
+    for (u32 k = 0; k < n_out; ++k) {
+      const u32 p = h_out_pos[k];
+      const u32 want = p < level ? p : hp.L + (p - level);  // global prime index of the target
+      u32 j = 0;
+      while (j < hm.nc && hm.compl_idx[j] != want) ++j;
+      if (p >= level + hp.K || j == hm.nc) return fail(ACEHIP_EINVAL, "acehip_base_conv: target is not a complement limb of the digit");
+      gi[k] = want;
+      col[k] = j;
+      pos[k] = k;
+    }
+    cd.hat = t->hat_mod;
+    cd.scale = t->hat_inv;
+    cd.scale_prec = t->hat_inv_prec;
+    cd.src_gi = t->src_gi;
+    cd.n_in = t->n2;
+    cd.hat_ld = t->nc;
+  }
+  // the three index lists and the descriptor travel in one small upload; freed after the launch has been ordered
+  std::vector<u32> blob;
+  blob.insert(blob.end(), gi.begin(), gi.end());
+  blob.insert(blob.end(), col.begin(), col.end());
+  blob.insert(blob.end(), pos.begin(), pos.end());
+  u32* d_blob = nullptr;
+  ConvDesc* d_desc = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_blob, blob.size() * sizeof(u32)));
+  HIP_TRY(hipMalloc((void**)&d_desc, sizeof(ConvDesc)));
+  HIP_TRY(hipMemcpy(d_blob, blob.data(), blob.size() * sizeof(u32), hipMemcpyHostToDevice));
+  cd.out_gi = d_blob;
+  cd.col = d_blob + n_out;
+  cd.out_pos = d_blob + 2 * n_out;
+  cd.src_pos0 = 0;
+  cd.n_out = n_out;
+  HIP_TRY(hipMemcpy(d_desc, &cd, sizeof(ConvDesc), hipMemcpyHostToDevice));
+  hipStream_t s = (hipStream_t)s_;
+  launch_base_conv_batch(c->dc, d_out, 0, d_in, 0, d_desc, 0, 1, n_out, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(d_blob);
+  (void)hipFree(d_desc);
+  return post_launch();
+}
+
 // one or two polynomials (c0, c1 of a ciphertext) through Rescale_poly in the same launches
 static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s) {
   const HostParams& hp = c->hp;

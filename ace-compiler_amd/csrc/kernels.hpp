@@ -41,6 +41,7 @@ struct ConvDesc {
   const u32* src_gi;      // [n_in] prime of each source limb
   const u32* out_gi;      // [n_out] prime of each output limb
   const u32* out_pos;     // [n_out] limb position of each output
+  const u32* col;         // [n_out] column of `hat` for each output (nullptr: column j for output j)
   u32 src_pos0;           // first source limb position in the input polynomial
   u32 n_in, n_out, hat_ld;
 };

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
     U128 acc{0, 0};
 #pragma unroll
     for (int i = 0; i < kMaxIn; ++i)
-      if ((u32)i < d.n_in) mac128(acc, y[i], d.hat[(size_t)i * d.hat_ld + j]);
+      if ((u32)i < d.n_in) mac128(acc, y[i], d.hat[(size_t)i * d.hat_ld + (d.col ? d.col[j] : j)]);
     dst[(size_t)d.out_pos[j] * c.N] = reduce128(acc, P.q, P.prec128_lo, P.prec128_hi);
   }
 }

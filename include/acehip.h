@@ -158,6 +158,15 @@ int acehip_decomp_modup(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, 
 int acehip_mod_down(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_rescale(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 
+/* Base conversion onto a chosen subset of target limbs: the building block of limb-sharded execution, where
+ * every GPU converts only the limbs it owns after the source limbs have been all-gathered.  `which` = digit index
+ * (Decompose_modup polynomial.c:1297-1320, sources = the digit's limbs in the coefficient domain, unscaled) or
+ * ACEHIP_CONV_MODDOWN (Fast_base_conv :755-807, sources = the K p-limbs in the coefficient domain).  d_in: the source
+ * limbs, contiguous; h_out_pos (host): target limb positions in the polynomial extended at `level`; d_out: n_out limbs
+ * (output k = position h_out_pos[k]), coefficient domain.  Synchronises the stream (setup-style call). */
+#define ACEHIP_CONV_MODDOWN (-1)
+int acehip_base_conv(acehip_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, uint32_t level, int which, const uint32_t* h_out_pos,
+                     uint32_t n_out, acehip_stream stream);
 /* ModRaise of bootstrapping (Transform_values_from_level0 ckks_bootstrap_context.c:1527-1551): limb 0 of d_in0
  * (and d_in1, may both be NULL with d_out1) in the NTT domain is taken to the coefficient domain, lifted to its
  * centred representative and spread to `level_out` limbs (NTT domain) at d_out0 / d_out1. */
