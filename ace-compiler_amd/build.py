@@ -38,6 +38,7 @@ def build(force=False, verbose=False):
     # host threads that each own a context (one image stream each) run concurrently on the GPU
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-fgpu-default-stream=per-thread", "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += os.environ.get("ACEHIP_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

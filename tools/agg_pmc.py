@@ -17,4 +17,4 @@ with open(path) as f:
         cnt[name] += 1
 json.dump({"counter": counter, "kernels": {k: {"dispatches": cnt[k], "sum": tot[k]} for k in sorted(tot, key=lambda k: -tot[k])},
            "total": sum(tot.values())}, open(out, "w"), indent=1)
-print(counter, "total", sum(tot.values()) / 1e9, "GB (raw counter units = bytes)")
+print(counter, "total", sum(tot.values()), "(raw counter units: FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 double FETCH_SIZE for wide streaming reads)")
