@@ -80,3 +80,37 @@ def test_torch_communicator_single_rank_nccl(tmp_path):
     script.write_text(NCCL_WORKER % (ROOT, ROOT))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "nccl shard ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_base_conv_subset_against_full_conversions():
+    """acehip_base_conv on chosen targets = the matching limbs of the full Decomp_modup / Mod_down (before their NTT/tail):
+    checked through the identities ext[d][p] = NTT(conv) and (x - NTT(conv)) * P^-1, i.e. against the oracle's results."""
+    import ace_compiler_amd as A
+
+    N, L, q0, sf, dnum, level = 4096, 6, 60, 50, 3, 5
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum, device=0)
+    try:
+        K = o.K
+        a = o.uniform(level, level, 311)
+        coef = o.ntt_inv(a, list(range(level)))
+        d_coef = rt.to_device(coef)
+        for d in range(o.num_decomp(level)):
+            start, n2 = o.alpha * d, min(o.alpha, level - o.alpha * d)
+            full = o.decomp_modup(a, level, d)
+            targets = [p for p in range(level + K) if not (start <= p < start + n2)][::2]   # every other complement limb
+            pos = np.asarray(targets, dtype=np.uint32)
+            out = rt.buf(len(targets) * N)
+            rt.check(rt.lib.acehip_base_conv(rt.h, out.ptr, d_coef.at(start * N), level, d, pos.ctypes.data, len(targets), None))
+            got = out.download((len(targets), N))
+            gis = [o.gidx(p, level) for p in targets]
+            assert np.array_equal(o.ntt_fwd(got, gis), full[targets]), d
+            out.free()
+            # a limb of the digit itself is not a conversion target
+            bad = np.asarray([start], dtype=np.uint32)
+            assert rt.lib.acehip_base_conv(rt.h, d_coef.ptr, d_coef.ptr, level, d, bad.ctypes.data, 1, None) == -1
+        assert rt.lib.acehip_base_conv(rt.h, d_coef.ptr, d_coef.ptr, level, 9, pos.ctypes.data, 1, None) == -1
+        d_coef.free()
+    finally:
+        rt.close()
+        o.close()
