@@ -345,9 +345,9 @@ int acehip_event_destroy(void* e) {
 
 // ---- argument checks shared by the launch entry points ----
 // ---- call statistics: algorithmic bytes of SURVEY 8(d) per entry point (tables and scratch excluded) ----
-enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_COUNT };
+enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_COUNT };
 static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
-                                                "mod_down", "rescale", "key_switch", "encode"};
+                                                "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed"};
 static thread_local acehip_stat g_stat[ST_COUNT];  // per host thread (= per image stream)
 static inline void stat(int k, u64 units, u64 bytes) {
   g_stat[k].calls++;
@@ -711,6 +711,11 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     h.state[nr] = pure;
     if (hw_has_a(op)) h.state[h.n_a[k]] = 0;
     if (hw_has_b(op)) h.state[h.n_b[k]] = 0;
+  }
+  if (!g_plan) {  // zero fills that survive (their overwrite, if any, is not in this list): units = limbs, a subset of "elementwise"
+    u64 z = 0;
+    for (size_t k = 0; k < m; ++k) z += !h.dead[k] && ops[k].op == ACEHIP_HW_ZERO;
+    if (z) stat(ST_ZERO_RUN, z, z * span);
   }
   if (live == 0) return;
   // forwards: give intermediate versions private scratch limbs

@@ -399,7 +399,7 @@ def main():
                            "frac_of_hbm_peak": round(ks_bytes / (ks_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         # whole-workload view: algorithmic bytes of every entry-point call of the timed region on this rank
-        alg = sum(v[2] for v in stats.values())
+        alg = sum(v[2] for k, v in stats.items() if k != "zero_fill_executed")  # that family is a subset of "elementwise"
         out["workload_roofline"] = {
             "algorithmic_bytes_per_image": int(alg / args.steps),
             "achieved_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
