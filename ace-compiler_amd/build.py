@@ -53,7 +53,7 @@ if __name__ == "__main__":
 RT_DIR = os.path.join(CSRC, "rt")
 RT_LIB = os.path.join(LIBDIR, "libFHErt_ant.so")
 RT_COMMON_LIB = os.path.join(LIBDIR, "libFHErt_common.so")
-RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp", "rt_bootstrap.cpp"]
+RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp", "rt_bootstrap.cpp", "rt_serial.cpp"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 

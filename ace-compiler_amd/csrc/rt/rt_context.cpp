@@ -110,6 +110,7 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   Context& prim = *g_primary;
   auto it = prim.auto_keys.find(auto_idx);
   if (it != prim.auto_keys.end()) return it->second;
+  RT_ASSERT(!(prim.keys_loaded && prim.keys_strict), "automorphism key %u is not in the loaded key file (ACEHIP_KEYS_STRICT)", auto_idx);
   const u32 T = c.L + c.K;
   // k^-1 mod 2N (k odd): k^(N-1)
   u64 inv = 1, base = auto_idx, e = c.N - 1, m = 2ull * c.N;
@@ -238,7 +239,17 @@ void Prepare_context() {
          "_scaling_mod_size = %ld, _num_q_parts = %ld, _num_p = %ld, _num_rot_idx = %ld,_hamming_wieght = %ld\n",
          prm->_provider, prm->_poly_degree, (long)prm->_sec_level, (long)prm->_mul_depth, (long)prm->_first_mod_size,
          (long)prm->_scaling_mod_size, (long)c->dnum, (long)c->K, (long)prm->_num_rot_idx, (long)prm->_hamming_weight);
-  generate_keys();
+  // key set: generated, or taken from / written to a key container (rt_serial.cpp)
+  const char* kfile = getenv("ACEHIP_KEYS_FILE");
+  c->keys_strict = getenv("ACEHIP_KEYS_STRICT") != nullptr && atoi(getenv("ACEHIP_KEYS_STRICT")) != 0;
+  bool have_keys = false;
+  if (kfile != nullptr && *kfile) {
+    const int rc = load_keys(kfile);
+    RT_ASSERT(rc == 0 || rc == -1, "ACEHIP_KEYS_FILE=%s: %s", kfile, rc == -3 ? "written for other CKKS parameters" : "truncated or not a key file");
+    have_keys = rc == 0;
+    if (!have_keys) c->keys_save_path = kfile;  // does not exist yet: written by Finalize_context
+  }
+  if (!have_keys) generate_keys();
   bootstrap_setup_if_needed();
   RT_DATA_INFO* di = Get_rt_data_info();
   if (di != nullptr) {
@@ -258,6 +269,7 @@ void Finalize_context() {
   Context& c = *g_ctx;
   sync();
   HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
+  if (!c.keys_save_path.empty()) RT_ASSERT(save_keys(c.keys_save_path.c_str()) == 0, "cannot write key file %s", c.keys_save_path.c_str());
   if (Get_rt_data_info() != nullptr) Pt_mgr_fini();
   const size_t key_words = (size_t)c.dnum * 2 * (c.L + c.K) * c.N;
   const size_t rot_cnt = c.auto_keys.size();
@@ -286,6 +298,10 @@ void Finalize_context() {
   c.auto_keys.clear();
   dfree(c.relin.data);
   c.relin.data = nullptr;
+  dfree(c.sk_ntt);
+  dfree(c.pk0);
+  dfree(c.pk1);
+  c.sk_ntt = c.pk0 = c.pk1 = nullptr;
   bootstrap_release();
   ev::clear_monomial_cache();
   stage_release();

@@ -79,6 +79,8 @@ struct Context {
   std::vector<u32> rot_group;     // 5^i mod 2N
   // statistics
   size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
+  bool keys_loaded = false, keys_strict = false;  // key set came from a container / a key missing from it is an error
+  std::string keys_save_path;                    // Finalize_context writes the key set here (ACEHIP_KEYS_FILE, rt_serial.cpp)
   bool secondary = false;         // a thread's view of the primary context (shares its keys, owns its acehip_ctx)
   bool profile = false;                          // ACEHIP_PROFILE=1: host-side timers below are printed
   double t_encode = 0, t_main = 0, t_issue = 0, t_bootstrap = 0;
@@ -141,6 +143,8 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt /*[L+K][N]*/, const u64* 
 u32 ensure_rot_key(int32_t rotation);   // Insert_rot_map :290; returns automorphism index
 SwitchKeyStore* ensure_auto_key(u32 auto_idx);
 void free_switch_key(SwitchKeyStore* k);
+int save_keys(const char* path);   // rt_serial.cpp: "ACEHKEY1" container
+int load_keys(const char* path);
 
 // ---- encode / decode (ckks_encoder.c) ----
 void embedding(std::vector<cplx>& vals);                               // ntt.c:678-711

@@ -14,6 +14,22 @@ void       Acehip_rt_sync(void);
 /* Extension: a thread other than the one that called Prepare_context attaches to that context on its first API
  * call (shared keys; own scratch, pool, queue, HIP stream); before it ends it may give those back. */
 void       Acehip_rt_thread_release(void);
+/* Extension: on-disk containers (the reference has none).  All return 0 or a negative code
+ * (-1 cannot open, -2 truncated / wrong magic, -3 written for other CKKS parameters).
+ *   "ACEHCT01" ciphertext / plaintext: u32 n_polys, N, level, num_p, is_ntt, slots, sf_degree, 0; f64 scaling_factor;
+ *              per polynomial `level` q-limbs then `num_p` p-limbs of N u64 residues
+ *   "ACEHKEY1" key set (secret, public, relinearisation and every automorphism key + the rotation map); layout in
+ *              csrc/rt/rt_serial.cpp.  ACEHIP_KEYS_FILE=<path> makes Prepare_context load it when it exists and
+ *              Finalize_context write it when it does not; ACEHIP_KEYS_STRICT=1 turns a key missing from a loaded set
+ *              into an error instead of generating a fresh one. */
+int        Acehip_rt_save_ciph(const char* path, CIPHER ciph);
+int        Acehip_rt_save_ciph3(const char* path, CIPHER3 ciph);
+int        Acehip_rt_save_plain(const char* path, PLAIN plain);
+int        Acehip_rt_load_ciph(CIPHER ciph, const char* path);   /* frees what ciph held, allocates from the pool */
+int        Acehip_rt_load_ciph3(CIPHER3 ciph, const char* path);
+int        Acehip_rt_load_plain(PLAIN plain, const char* path);
+int        Acehip_rt_save_keys(const char* path);
+int        Acehip_rt_load_keys(const char* path);                 /* replaces the keys of the prepared context */
 #ifdef __cplusplus
 }
 #endif
