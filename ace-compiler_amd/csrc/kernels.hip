@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
                                                        u32 s0, u32 r, u32 log_c, u32 skip_alpha) {
   extern __shared__ u64 tile[];
   u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blockIdx.y, blockIdx.z)) return;
   const u32 gi = limb_prime(pos, level, c.L);
   const DevPrime P = c.primes[gi];
   const u64 q = P.q;

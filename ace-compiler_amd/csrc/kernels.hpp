@@ -17,14 +17,40 @@ struct DevCtx {
 // prime (global index) of the limb at position pos of a polynomial extended at `level`
 __host__ __device__ inline u32 limb_prime(u32 pos, u32 level, u32 L) { return pos < level ? pos : L + (pos - level); }
 
-// limb position handled by this workgroup (blockIdx.y) of polynomial blockIdx.z.  With skip_alpha != 0
+// Workgroup -> (tile, limb row y, polynomial z) of an NTT pass launch (1-D grid of tiles*n_limbs*n_polys blocks).
+// XCD-aware: blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so the n_polys workgroups that
+// work on the same (tile, limb) -- and therefore read the same twiddles -- get block ids that are congruent mod 8 and
+// consecutive in time: the twiddle tile is fetched into that XCD's L2 once instead of once per polynomial (measured on the
+// 32-polynomial roofline batch: contiguous-pass reads 1.57 GB -> 0.57 GB per launch).  An L2 does not keep anything
+// across a kernel boundary, so there is nothing to gain from pinning a limb's two passes to one XCD (tried: same
+// FETCH_SIZE, worse balance).  Placement only affects speed; any mapping is correct.
+#ifdef __HIPCC__
+struct NttBlk {
+  u32 tile, y, z;
+};
+__device__ __forceinline__ NttBlk ntt_block(u32 log_tiles, u32 n_limbs, u32 n_polys) {
+  const u32 b = blockIdx.x, G = n_limbs << log_tiles;  // tiles per limb: a power of two
+  u32 g, z;
+  if ((G & 7u) == 0) {
+    const u32 r = b >> 3;
+    g = (r / n_polys) * 8 + (b & 7u);
+    z = r % n_polys;
+  } else {
+    g = b % G;
+    z = b / G;
+  }
+  // wave-uniform values: keep them (and the prime / base pointers derived from them) on the scalar unit
+  g = __builtin_amdgcn_readfirstlane(g);
+  z = __builtin_amdgcn_readfirstlane(z);
+  return NttBlk{g & ((1u << log_tiles) - 1), g >> log_tiles, z};
+}
+// limb position handled by limb row y of polynomial z.  With skip_alpha != 0
 // the launch covers the key-switch digits: polynomial z skips its own digit limbs
 // [alpha*z, alpha*z + n2) (they are not produced by ModUp), pos0 must be 0.
-#ifdef __HIPCC__
-__device__ __forceinline__ bool ntt_limb_pos(u32& pos, u32 pos0, u32 level, u32 K, u32 skip_alpha) {
-  pos = pos0 + blockIdx.y;
+__device__ __forceinline__ bool ntt_limb_pos(u32& pos, u32 pos0, u32 level, u32 K, u32 skip_alpha, u32 y, u32 z) {
+  pos = pos0 + y;
   if (skip_alpha) {
-    const u32 start = skip_alpha * blockIdx.z;
+    const u32 start = skip_alpha * z;
     const u32 n2 = min(skip_alpha, level - start);
     if (pos >= start) pos += n2;
     return pos < level + K;

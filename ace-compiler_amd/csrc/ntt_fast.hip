@@ -5,13 +5,19 @@
 // per workgroup.  N = 2^16 is exactly two passes:
 //   STRIDED pass: stages [0,8)          rows = index bits [logN-8, logN), 16 adjacent columns/tile
 //   CONTIG  pass: stages [logN-8,logN)  16 consecutive 256-coefficient blocks per tile
-// Butterflies are Harvey-style lazy (values in [0,4q) forward, [0,2q) inverse; q < 2^61) with Shoup
-// twiddle multiplication; the last pass writes canonical residues in [0,q), so results are
-// bit-identical to the reference (ntt.c:190-353), which keeps every intermediate canonical.
-// Twiddles come from the interleaved {w, floor(w*2^64/q)} tables (16-byte loads).
-//
-// Integer-multiply throughput (v_mad_u64_u32 at half rate, v_mul_lo/hi_u32 at quarter rate:
-// tools/ubench_int.hip) is the VALU ceiling of these kernels; see DESIGN.md.
+// The kernels are bound by 32-bit integer multiplies (tools/ubench_int.hip), so the butterflies are built to need as
+// few of them, and as little else, as possible:
+//   * twiddle products use a "sloppy" Shoup reduction (shoup4): the quotient estimate takes three of the four partial
+//     products of a * floor(w*2^64/q), is at most 3 below the true quotient, and the result lies in [0,4q) -- 9
+//     multiply instructions instead of 10 and none of the register shuffling of a full 64x64 high product;
+//   * forward transforms of primes with 65q < 2^64 (every q-limb of the 50..57-bit scaling primes) never reduce the
+//     butterfly sums: values grow by 4q per stage, stay below 65q over the 16 stages (33q between the passes) and
+//     are reduced once, at the very end (quotient from floor(2^64/q));  larger primes (q0, the P primes, < 2^61) keep
+//     values in [0,8q) with one conditional subtraction of 4q per butterfly;
+//   * inverse transforms keep values in [0,4q) (one conditional subtraction per butterfly).
+// The last pass writes canonical residues in [0,q), so results are bit-identical to the reference (ntt.c:190-353),
+// which keeps every intermediate canonical.  Twiddles come from the interleaved {w, floor(w*2^64/q)} tables (16-byte
+// loads); workgroups that share twiddles are placed on one XCD (kernels.hpp ntt_block).
 #include "device_arith.hpp"
 #include "kernels.hpp"
 
@@ -26,58 +32,86 @@ __device__ __forceinline__ Tw ldtw(const ulong2* __restrict__ t, u32 idx) {
   return Tw{v.x, v.y};
 }
 
-// a*w mod q in [0,2q) for any 64-bit a
+// a*w mod q in [0,2q) for any 64-bit a (exact Shoup quotient: at most 1 below the true quotient)
 __device__ __forceinline__ u64 shoup_lazy(u64 a, Tw t, u64 q) { return a * t.w - mulhi64(a, t.p) * q; }
 
-// forward (Cooley-Tukey) lazy butterfly: X,Y in [0,4q) -> [0,4q)
-__device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, u64 q, u64 q2) {
-  const u64 x = X >= q2 ? X - q2 : X;
-  const u64 m = shoup_lazy(Y, t, q);
-  X = x + m;
-  Y = x + q2 - m;
+// a*w mod q in [0,4q) for any 64-bit a: quotient estimate h = a1*p1 + hi32(a0*p1) + hi32(a1*p0), which is
+// floor(a*wp/2^64) less at most 2 (the dropped a0*p0 and the two truncated cross terms), itself at most 1 below
+// floor(a*w/q)
+__device__ __forceinline__ u64 shoup4(u64 a, Tw t, u64 q) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)t.p, p1 = (u32)(t.p >> 32);
+  const u64 h = (u64)a1 * p1 + __umulhi(a0, p1) + __umulhi(a1, p0);
+  return a * t.w - h * q;
 }
-// inverse (Gentleman-Sande) lazy butterfly: X,Y in [0,2q) -> [0,2q)
-__device__ __forceinline__ void bf_inv(u64& X, u64& Y, Tw t, u64 q, u64 q2) {
+
+// primes for which 16 forward stages without any reduction stay below 2^64: q + 16*4q = 65q
+constexpr u64 kSmallPrimeMax = ~0ull / 65;
+
+// forward (Cooley-Tukey) lazy butterfly.  SMALL: X,Y < B -> X,Y < B + 4q, no reduction.
+// !SMALL: X,Y in [0,8q) -> [0,8q) (q < 2^61)
+template <bool SMALL>
+__device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, u64 q, u64 q4) {
+  u64 x = X;
+  if (!SMALL) x = X >= q4 ? X - q4 : X;
+  const u64 m = shoup4(Y, t, q);
+  X = x + m;
+  Y = x + q4 - m;
+}
+// inverse (Gentleman-Sande) lazy butterfly: X,Y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void bf_inv(u64& X, u64& Y, Tw t, u64 q, u64 q4) {
   const u64 s = X + Y;
-  const u64 d = X + q2 - Y;
-  X = s >= q2 ? s - q2 : s;
-  Y = shoup_lazy(d, t, q);
+  const u64 d = X + q4 - Y;
+  X = s >= q4 ? s - q4 : s;
+  Y = shoup4(d, t, q);
+}
+// canonical residue of a forward result: v < 65q (SMALL; mu = floor(2^64/q)) or v < 8q
+template <bool SMALL>
+__device__ __forceinline__ u64 canon_fwd(u64 v, u64 q, u64 mu) {
+  if (SMALL) {
+    const u64 r = v - mulhi64(v, mu) * q;  // quotient at most 1 low: [0,2q)
+    return r >= q ? r - q : r;
+  }
+  const u64 q4 = 4 * q, q2 = 2 * q;
+  v = v >= q4 ? v - q4 : v;
+  v = v >= q2 ? v - q2 : v;
+  return v >= q ? v - q : v;
 }
 
 // 4 forward stages on 16 registers; stage u pairs (k, k + (8>>u)), twiddle T_u[k / (16>>u)]
+template <bool SMALL>
 __device__ __forceinline__ void radix16_fwd(u64 (&x)[16], const Tw& t0, const Tw (&t1)[2], const Tw (&t2)[4],
-                                            const Tw (&t3)[8], u64 q, u64 q2) {
+                                            const Tw (&t3)[8], u64 q, u64 q4) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bf_fwd(x[k], x[k + 8], t0, q, q2);
+  for (int k = 0; k < 8; ++k) bf_fwd<SMALL>(x[k], x[k + 8], t0, q, q4);
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bf_fwd(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q2);
+    for (int k = 0; k < 4; ++k) bf_fwd<SMALL>(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q4);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) bf_fwd(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q2);
+    for (int k = 0; k < 2; ++k) bf_fwd<SMALL>(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q4);
 #pragma unroll
-  for (int g = 0; g < 8; ++g) bf_fwd(x[2 * g], x[2 * g + 1], t3[g], q, q2);
+  for (int g = 0; g < 8; ++g) bf_fwd<SMALL>(x[2 * g], x[2 * g + 1], t3[g], q, q4);
 }
 
 // 4 inverse stages (u = 3..1); stage u = 0 is handled by the caller (it may carry the N^-1 fold)
 __device__ __forceinline__ void radix16_inv_321(u64 (&x)[16], const Tw (&t1)[2], const Tw (&t2)[4], const Tw (&t3)[8],
-                                                u64 q, u64 q2) {
+                                                u64 q, u64 q4) {
 #pragma unroll
-  for (int g = 0; g < 8; ++g) bf_inv(x[2 * g], x[2 * g + 1], t3[g], q, q2);
+  for (int g = 0; g < 8; ++g) bf_inv(x[2 * g], x[2 * g + 1], t3[g], q, q4);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) bf_inv(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q2);
+    for (int k = 0; k < 2; ++k) bf_inv(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q4);
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bf_inv(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q2);
+    for (int k = 0; k < 4; ++k) bf_inv(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q4);
 }
-__device__ __forceinline__ void radix16_inv_0(u64 (&x)[16], const Tw& t0, u64 q, u64 q2) {
+__device__ __forceinline__ void radix16_inv_0(u64 (&x)[16], const Tw& t0, u64 q, u64 q4) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bf_inv(x[k], x[k + 8], t0, q, q2);
+  for (int k = 0; k < 8; ++k) bf_inv(x[k], x[k + 8], t0, q, q4);
 }
 
 // twiddles of the 16-group with index `prefix` at stage `sbase`: T_u[i] = TW[2^(sbase+u) + (prefix<<u) + i]
@@ -92,6 +126,30 @@ __device__ __forceinline__ void load_tw(const ulong2* __restrict__ TW, u32 sbase
   for (int i = 0; i < 8; ++i) t3[i] = ldtw(TW, (8u << sbase) + (prefix << 3) + i);
 }
 
+// One limb seen through a buffer descriptor: addresses are descriptor (SGPRs) + one 32-bit per-lane byte offset + a scalar
+// byte offset, so the 16 strided accesses of a lane share ONE address VGPR instead of 16 64-bit pairs (the difference
+// between 4 and 2 waves per SIMD for the forward strided pass).  `base` must be wave-uniform.
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+struct LimbBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ LimbBuf limb_buf(const u64* base, u32 bytes) {
+  const u64 a = reinterpret_cast<u64>(base);
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)a), hi = __builtin_amdgcn_readfirstlane((u32)(a >> 32));
+  void* p = reinterpret_cast<void*>(((u64)hi << 32) | lo);
+  return LimbBuf{__builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000)};
+}
+__device__ __forceinline__ u64 bld(const LimbBuf& b, u32 voff, u32 soff) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
+  return ((u64)v.y << 32) | v.x;
+}
+__device__ __forceinline__ void bst(const LimbBuf& b, u32 voff, u32 soff, u64 v) {
+  u32x2_t w;
+  w.x = (u32)v;
+  w.y = (u32)(v >> 32);
+  __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff, soff, 0);
+}
+
 constexpr u32 kRowPitch = 17;        // strided tile: 256 rows x 16 cols, row pitch 17 words
 constexpr u32 kBlkPitch = 272;       // contig tile: 16 blocks x (256 + 16 pad) words
 __device__ __forceinline__ u32 cpad(u32 rho) { return rho + (rho >> 4); }
@@ -101,61 +159,89 @@ __device__ __forceinline__ u32 cpad(u32 rho) { return rho + (rho >> 4); }
 // columns col = chunk*16 + cc.  Round A lanes (g = tid>>4, cc = tid&15) hold rows 16k+g;
 // round B lanes (h = tid>>4, cc) hold rows 16h+g'.
 // ------------------------------------------------------------------------------------------------
-// FROM_MSG (forward only): the input of every limb is the signed message f.msg reduced mod the limb's prime
-template <bool INVERSE, bool FROM_MSG>
-__global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
-                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f) {
-  __shared__ u64 lds[256 * kRowPitch];
-  u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
-  const u32 gi = limb_prime(pos, level, c.L);
-  const DevPrime& P = c.primes[gi];
-  const u64 q = P.q, q2 = 2 * q;
-  u64* __restrict__ X = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N;
-  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
-  const u32 log_s = c.logN - 8;
-  const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
-  const u32 col = blockIdx.x * 16 + cc;
+struct StridedArgs {
+  LimbBuf buf;
+  const ulong2* __restrict__ TW;
+  u64* lds;
+  u32 cc, hg, col;
+  u64 q;
+  static constexpr u32 log_s = 8;
+};
+
+// forward: rows 16k+hg are read in place unless FROM_MSG filled x[]; the result (lazy: < 33q SMALL, < 8q otherwise) is
+// stored in place.  The two prime classes are separate code regions from the first load to the last store (one
+// scalar branch at the top): sharing the loads lets the compiler hoist both paths' twiddles above the branch, which
+// costs half of the occupancy.
+template <bool SMALL, bool FROM_MSG>
+__device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 z, u32 n_bytes) {
+  const u64 q = a.q, q4 = 4 * q;
   u64 x[16];
   Tw t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch (no hoisting / merging across paths)
+  if (FROM_MSG) {  // the signed message, reduced mod this limb's prime (and scaled): Encode_impl ckks_encoder.c:262-285
+    const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
+    const LimbBuf mbuf = limb_buf(reinterpret_cast<const u64*>(f.msg + z * f.msg_stride), n_bytes);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t v = (int64_t)bld(mbuf, (a.hg << 11) + a.col * 8, (u32)k << 15);
+      const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+      u64 r = mag;
+      if (__any(mag >= q))  // encoded weights are far below the primes: the wide reduction is the rare path, skip it per wave
+        r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
+      if (v < 0 && r != 0) r = q - r;
+      x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, (a.hg << 11) + a.col * 8, (u32)k << 15);  // row 16k+hg, row pitch 2 KiB
+  }
+  load_tw(a.TW, 0, 0, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a.lds[(16 * k + a.hg) * kRowPitch + a.cc] = x[k];
+  load_tw(a.TW, 4, a.hg, t0, t1, t2, t3);
+  __syncthreads();
+  // round B: stages 4..7
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = a.lds[(16 * a.hg + k) * kRowPitch + a.cc];
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) bst(a.buf, (a.hg << 15) + a.col * 8, (u32)k << 11, x[k]);  // row 16hg+k
+  asm volatile("" ::: "memory");  // and its stores above the join
+}
+
+// FROM_MSG (forward only): the input of every limb is the signed message f.msg reduced mod the limb's prime
+template <bool INVERSE, bool FROM_MSG>
+__global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
+                                                           u32 n_limbs, u32 n_polys) {
+  __shared__ u64 lds[256 * kRowPitch];
+  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
+  u32 pos;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+  pos = __builtin_amdgcn_readfirstlane(pos);  // wave-uniform: prime constants and base pointers live in SGPRs
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, q4 = 4 * q;
+  u64* __restrict__ X = poly + blk.z * poly_stride + (size_t)(pos - pos_off) * c.N;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
+  constexpr u32 log_s = 8;  // N = 2^16 only (launch_ntt_fused): constant row stride, addresses = one base + immediates
+  const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
+  const u32 col = blk.tile * 16 + cc;
 
   if (!INVERSE) {
-    // round A: stages 0..3 (uniform twiddles TW[1..15])
-    if (FROM_MSG) {
-      const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int64_t v = f.msg[blockIdx.z * f.msg_stride + ((size_t)(16 * k + hg) << log_s) + col];
-        const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
-        u64 r = mag;
-        if (__any(mag >= q))  // encoded weights are far below the primes: the wide reduction is the rare path, skip it per wave
-          r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
-        if (v < 0 && r != 0) r = q - r;
-        x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * k + hg) << log_s) + col];
-    }
-    load_tw(TW, 0, 0, t0, t1, t2, t3);
-    radix16_fwd(x, t0, t1, t2, t3, q, q2);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[(16 * k + hg) * kRowPitch + cc] = x[k];
-    load_tw(TW, 4, hg, t0, t1, t2, t3);
-    __syncthreads();
-    // round B: stages 4..7
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[(16 * hg + k) * kRowPitch + cc];
-    radix16_fwd(x, t0, t1, t2, t3, q, q2);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) X[((size_t)(16 * hg + k) << log_s) + col] = x[k];  // lazy [0,4q)
+    const StridedArgs a{limb_buf(X, c.N * 8), TW, lds, cc, hg, col, q};
+    if (q <= kSmallPrimeMax) strided_fwd_body<true, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
+    else                     strided_fwd_body<false, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
   } else {
-    // round B first: stages 7..4 on rows 16h+g'
+    u64 x[16];
+    Tw t0, t1[2], t2[4], t3[8];
+    // round B first: stages 7..4 on rows 16h+g'; input lazy [0,4q) from the contiguous pass
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * hg + k) << log_s) + col];
     load_tw(TW, 4, hg, t0, t1, t2, t3);
-    radix16_inv_321(x, t1, t2, t3, q, q2);
-    radix16_inv_0(x, t0, q, q2);
+    radix16_inv_321(x, t1, t2, t3, q, q4);
+    radix16_inv_0(x, t0, q, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
     load_tw(TW, 0, 0, t0, t1, t2, t3);
@@ -163,7 +249,7 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
     // round A: stages 3..1, then stage 0 with N^-1 folded in, canonical output
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
-    radix16_inv_321(x, t1, t2, t3, q, q2);
+    radix16_inv_321(x, t1, t2, t3, q, q4);
     Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
     if (f.inv_scale) {
       const u64* sc = f.inv_scale + 4 * (size_t)pos;
@@ -172,9 +258,9 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const u64 s = x[k] + x[k + 8];            // [0,4q)
-      const u64 d = x[k] + q2 - x[k + 8];       // (0,4q)
-      u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);
+      const u64 s = x[k] + x[k + 8];            // [0,8q)
+      const u64 d = x[k] + q4 - x[k + 8];       // (0,8q)
+      u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);  // exact quotient: [0,2q)
       x[k] = a >= q ? a - q : a;
       x[k + 8] = b >= q ? b - q : b;
     }
@@ -194,54 +280,64 @@ __global__ __launch_bounds__(256) void ntt8_strided_kernel(DevCtx c, u64* __rest
 // hold rho = 16k+g (each load instruction reads whole 128-byte lines); round B lanes (h = tid&15, b)
 // hold the 16 contiguous rho = 16h+g'.  The contiguous side goes through LDS so that global accesses
 // stay 16 bytes per lane, 1 KiB contiguous per wave instruction.
-// CANON_OUT (inverse only): write canonical values instead of lazy [0,2q) (needed when a generic
+// CANON_OUT (inverse only): write canonical values instead of lazy [0,4q) (needed when a generic
 // pass follows instead of the strided fast pass).
 // ------------------------------------------------------------------------------------------------
+// forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
+// rho = 16*lo4+k on return
+template <bool SMALL>
+__device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, u32 s8, u32 o,
+                                                u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
+  const u64 q4 = 4 * q;
+  Tw t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = X[b * 256 + 16 * k + lo4];
+  load_tw(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
+  load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  __syncthreads();
+  // round B: stages s8+4..s8+7 on rho = 16h + g'
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = canon_fwd<SMALL>(x[k], q, mu);
+}
+
 // FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
 // f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
 template <bool INVERSE, bool CANON_OUT, int FUSE>
-__global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
-                                                          u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f) {
+__global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+                                                          u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
+                                                          u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[16 * kBlkPitch];
+  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha)) return;
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+  pos = __builtin_amdgcn_readfirstlane(pos);  // wave-uniform: prime constants and base pointers live in SGPRs
   const u32 gi = limb_prime(pos, level, c.L);
   const DevPrime& P = c.primes[gi];
-  const u64 q = P.q, q2 = 2 * q;
-  u64* __restrict__ X = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N + (size_t)blockIdx.x * 4096;
+  const u64 q = P.q, q4 = 4 * q;
+  u64* __restrict__ X = poly + blk.z * poly_stride + (size_t)(pos - pos_off) * c.N + (size_t)blk.tile * 4096;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
   const u32 s8 = c.logN - 8;
   const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
-  const u32 o = blockIdx.x * 16 + b;
+  const u32 o = blk.tile * 16 + b;
   u64 x[16];
-  Tw t0, t1[2], t2[4], t3[8];
 
   if (!INVERSE) {
-    // round A: stages s8..s8+3 on rho = 16k + g
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = X[b * 256 + 16 * k + lo4];
-    load_tw(TW, s8, o, t0, t1, t2, t3);
-    radix16_fwd(x, t0, t1, t2, t3, q, q2);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
-    load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
-    __syncthreads();
-    // round B: stages s8+4..s8+7 on rho = 16h + g'
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-    radix16_fwd(x, t0, t1, t2, t3, q, q2);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {  // canonical output
-      u64 v = x[k] >= q2 ? x[k] - q2 : x[k];
-      x[k] = v >= q ? v - q : v;
-    }
+    if (q <= kSmallPrimeMax) contig_fwd_body<true>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    else                     contig_fwd_body<false>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
     __syncthreads();
-    const size_t tail_off = (size_t)pos * c.N + (size_t)blockIdx.x * 4096;  // q-limb `pos` of x_z / out_z
-    const u64* __restrict__ xin = FUSE ? (blockIdx.z ? f.x1 : f.x0) + tail_off : nullptr;
-    u64* __restrict__ dst = FUSE ? (blockIdx.z ? f.out1 : f.out0) + tail_off : X;
+    const size_t tail_off = (size_t)pos * c.N + (size_t)blk.tile * 4096;  // q-limb `pos` of x_z / out_z
+    const u64* __restrict__ xin = FUSE ? (blk.z ? f.x1 : f.x0) + tail_off : nullptr;
+    u64* __restrict__ dst = FUSE ? (blk.z ? f.out1 : f.out0) + tail_off : X;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte stores
@@ -261,8 +357,9 @@ __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restr
       *reinterpret_cast<ulong2*>(dst + e) = v;
     }
   } else {
+    Tw t0, t1[2], t2[4], t3[8];
     const u64* __restrict__ S =
-        FUSE ? (blockIdx.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)blockIdx.x * 4096 : X;
+        FUSE ? (blk.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)blk.tile * 4096 : X;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
@@ -275,8 +372,8 @@ __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restr
     // round B first: stages s8+7..s8+4 on the 16 contiguous rho = 16h + g'
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-    radix16_inv_321(x, t1, t2, t3, q, q2);
-    radix16_inv_0(x, t0, q, q2);
+    radix16_inv_321(x, t1, t2, t3, q, q4);
+    radix16_inv_0(x, t0, q, q4);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
@@ -285,12 +382,15 @@ __global__ __launch_bounds__(256) void ntt8_contig_kernel(DevCtx c, u64* __restr
     // round A: stages s8+3..s8 on rho = 16k + g
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * k + lo4];
-    radix16_inv_321(x, t1, t2, t3, q, q2);
-    radix16_inv_0(x, t0, q, q2);
+    radix16_inv_321(x, t1, t2, t3, q, q4);
+    radix16_inv_0(x, t0, q, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      u64 v = x[k];
-      if (CANON_OUT) v = v >= q ? v - q : v;
+      u64 v = x[k];  // [0,4q)
+      if (CANON_OUT) {
+        v = v >= 2 * q ? v - 2 * q : v;
+        v = v >= q ? v - q : v;
+      }
       X[b * 256 + 16 * k + lo4] = v;
     }
   }
@@ -306,8 +406,8 @@ void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limb
 void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                       u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
   if (n_limbs == 0) return;
-  dim3 block(256), grid(c.N >> 12, n_limbs, n_polys);
-#define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f
+  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
+#define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg) hipLaunchKernelGGL((ntt8_strided_kernel<false, true>), ACEHIP_NTT_ARGS);
     else       hipLaunchKernelGGL((ntt8_strided_kernel<false, false>), ACEHIP_NTT_ARGS);
@@ -324,10 +424,10 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
 
 void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
                         u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
-  dim3 block(256), grid(c.N >> 12, n_limbs, n_polys);
+  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);
   const NttFuse f{};
-  if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f);
-  else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f);
+  if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys);
+  else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys);
 }
 
 }  // namespace acehip

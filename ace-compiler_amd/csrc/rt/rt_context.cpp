@@ -283,7 +283,9 @@ void Finalize_context() {
     printf("[ACEHIP] host seconds: encode (launch side) %.3f, Main_graph issue %.3f (until the last call returns), Main_graph %.3f\n",
            c.t_encode, c.t_issue, c.t_main);
     printf("[ACEHIP] %zu Bootstrap calls: %.3f s (synchronised on both sides while profiling)\n", c.n_bootstrap, c.t_bootstrap);
+    printf("[ACEHIP] %zu encodes, %zu of them launched ahead of the per-limb queue\n", c.n_encode, c.n_encode_ahead);
     hw_stats_print();
+    hw_flush_sites_print();
     acehip_stat st[16];
     const int nf = acehip_stats(st, 16, 0);
     unsigned long long total = 0;

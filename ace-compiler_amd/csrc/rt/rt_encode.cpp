@@ -126,10 +126,29 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
   RT_ASSERT(len <= slots, "slot size is too small");
   RT_ASSERT(slots <= N / 2, " slot size > N/2 ");
   RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
-  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
   POLYNOMIAL* poly = &res->_poly;
-  HIPCHK(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level,
-                       p_cnt, nullptr));
+  // Generated conv loops encode one weight plaintext per tap into the SAME PLAINTEXT shell, between the per-limb
+  // multiply-accumulates of consecutive taps (resnet20_cifar10_pre.onnx.inc:1486-1503).  Flushing the per-limb queue
+  // for every encode would send each tap's accumulator through memory; instead the plaintext gets a fresh block (the
+  // old one stays intact for the queued ops that read it: renaming) and the encode, which writes nothing else, is
+  // launched ahead of the queue.  The taps of a whole output channel then form one accumulation chain per limb.
+  const bool ahead = !hw_queue_empty();
+  c.n_encode++;
+  c.n_encode_ahead += ahead;
+  if (ahead && poly->_data != nullptr) {
+    RT_ASSERT((poly->_num_primes + poly->_num_primes_p) == 0 || (poly->_num_primes == level && poly->_num_primes_p == p_cnt),
+              "unmatched size");  // init_plaintext's check
+    poly_free(poly);  // into the pool's limbo until the queue has been issued
+  }
+  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
+  if (ahead) {
+    hw_pending_flush();
+    HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
+                                 level, p_cnt, nullptr));
+  } else {
+    HIPCHK(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level,
+                         p_cnt, nullptr));
+  }
   poly->_is_ntt = true;
   if (c.profile) c.t_encode += wall_s() - t0;
 }

@@ -34,10 +34,21 @@
   } while (0)
 // Every device call of the shim goes through HIPCHK, which first hands over the per-limb Hw_* calls
 // that are still queued (rt_poly.cpp hw_queue): the device sees all work in program order.
-namespace rt { void hw_flush(); }
+namespace rt { void hw_flush(); void hw_flush_site(const char* file, int line); }
 #define HIPCHK(expr)                                                                       \
   do {                                                                                     \
-    rt::hw_flush();                                                                        \
+    rt::hw_flush_site(__FILE__, __LINE__);                                                                        \
+    int rc_ = (expr);                                                                      \
+    if (rc_ < 0) {                                                                         \
+      fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
+      abort();                                                                             \
+    }                                                                                      \
+  } while (0)
+
+// Device work that provably touches nothing the queue names (it only writes a block that was allocated, from memory
+// no queued op can reference, after the caller checked) may be launched AHEAD of the queue: no hw_flush.
+#define HIPCHK_NOFLUSH(expr)                                                               \
+  do {                                                                                     \
     int rc_ = (expr);                                                                      \
     if (rc_ < 0) {                                                                         \
       fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
@@ -85,6 +96,7 @@ struct Context {
   bool profile = false;                          // ACEHIP_PROFILE=1: host-side timers below are printed
   double t_encode = 0, t_main = 0, t_issue = 0, t_bootstrap = 0;
   size_t n_bootstrap = 0;
+  size_t n_encode = 0, n_encode_ahead = 0;       // encodes / encodes launched ahead of the per-limb queue
 };
 
 extern thread_local Context* g_ctx;  // this thread's context (its own acehip_ctx, counters, copies of the parameters)
@@ -123,6 +135,9 @@ void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals); // Transf
 void sync();
 // queue `n_limbs` consecutive limbs of a per-limb op (ACEHIP_HW_*) instead of launching it now
 void hw_stats_print();
+void hw_flush_sites_print();
+bool hw_queue_empty();   // nothing queued (a held-back Mod_down / Rescale does not count)
+void hw_pending_flush(); // issue a held-back Mod_down / Rescale now
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs = 1);
 // queued multi-limb forms, argument meaning as acehip_modadd & co: limbs [pos0, pos0+n) of polynomials extended
 // at `level` (limb p < level is prime p, the others are p primes); scalars[i] belongs to limb pos0+i

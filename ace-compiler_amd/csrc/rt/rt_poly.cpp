@@ -69,7 +69,7 @@ static bool shared_free(u64* p) {
     if (it == g_shared_allocs.end()) return false;
     g_shared_allocs.erase(it);
   }
-  hw_flush();  // nothing queued may still name it
+  hw_flush_site(__FILE__, __LINE__);  // nothing queued may still name it
   acehip_free(p);
   return true;
 }
@@ -81,6 +81,11 @@ static thread_local std::mutex pool_mu;
 static thread_local std::map<size_t, std::vector<u64*>> pool_free;
 static thread_local std::map<u64*, size_t> pool_live;
 static thread_local size_t pool_live_bytes = 0;
+// Blocks freed while per-limb ops are still queued may be named by those ops: they wait here until the queue has been
+// handed to the device (hw_flush), and only then become reusable.  A block taken from pool_free is therefore never
+// referenced by anything still queued -- which is what lets work that only writes a fresh block (Pt_from_msg's encode)
+// be launched ahead of the queue instead of cutting it (rt_encode.cpp encode_device).
+static thread_local std::vector<std::pair<u64*, size_t>> pool_limbo;
 
 // ---- deferred per-limb ops ----
 // Generated code calls Hw_modadd / Hw_modmul / Hw_rotate once per RNS limb and component inside host loops
@@ -132,10 +137,19 @@ void pending_flush() {
   RT_ASSERT(rc >= 0, "deferred %s failed: %s", p.kind == 1 ? "Mod_down" : "Rescale", acehip_last_error());
 }
 }  // namespace
+static void limbo_release() {
+  if (pool_limbo.empty()) return;
+  std::lock_guard<std::mutex> lk(pool_mu);
+  for (auto& b : pool_limbo) pool_free[b.second].push_back(b.first);
+  pool_limbo.clear();
+}
 void hw_flush() {
   pending_flush();   // it was issued after everything flushed earlier and before everything queued since
   g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
-  if (g_hwq.empty()) return;
+  if (g_hwq.empty()) {
+    limbo_release();
+    return;
+  }
   if (ctx().profile) {
     HwqStats& st = g_hwq_stats;
     st.flushes++;
@@ -151,7 +165,29 @@ void hw_flush() {
   const int rc = acehip_hw_batch(ctx().hip, g_hwq.data(), g_hwq.size(), nullptr);
   g_hwq.clear();
   RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());
+  limbo_release();
 }
+// ACEHIP_PROFILE: which call sites hand over how many queued limb-ops (finds what cuts accumulation chains short)
+namespace {
+thread_local std::map<std::pair<std::string, int>, std::pair<size_t, size_t>> g_flush_sites;
+}
+void hw_flush_site(const char* file, int line) {
+  if (g_ctx != nullptr && g_ctx->profile && !g_hwq.empty()) {
+    auto& e = g_flush_sites[{file, line}];
+    e.first++;
+    e.second += g_hwq.size();
+  }
+  hw_flush();
+}
+void hw_flush_sites_print() {
+  for (auto& kv : g_flush_sites) {
+    const char* f = strrchr(kv.first.first.c_str(), '/');
+    printf("[ACEHIP] flush site %s:%d: %zu flushes, %zu limb-ops\n", f ? f + 1 : kv.first.first.c_str(), kv.first.second, kv.second.first,
+           kv.second.second);
+  }
+}
+bool hw_queue_empty() { return g_hwq.empty(); }
+void hw_pending_flush() { pending_flush(); }
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs) {
   const size_t N = ctx().N;
   pending_flush();
@@ -159,7 +195,7 @@ void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_
   for (size_t l = 0; l < n_limbs; ++l)
     g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
                                  b ? (const void*)((const u64*)b + l * N) : nullptr});
-  if (g_hwq.size() >= 8192) hw_flush();
+  if (g_hwq.size() >= 8192) hw_flush_site(__FILE__, __LINE__);
 }
 static inline u32 limb_gi(u32 pos, u32 level) { return pos < level ? pos : ctx().L + (pos - level); }
 void q_ew(u32 op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n) {
@@ -222,7 +258,8 @@ void dfree(u64* p) {
   RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
   if (g_muc.valid && g_muc.src >= p && g_muc.src < p + it->second) g_muc.valid = false;
   pool_live_bytes -= it->second * sizeof(u64);
-  pool_free[it->second].push_back(p);
+  if (g_hwq.empty()) pool_free[it->second].push_back(p);
+  else pool_limbo.emplace_back(p, it->second);  // queued ops may still name it
   pool_live.erase(it);
 }
 
@@ -244,6 +281,8 @@ void pool_release_all() {
   for (auto& kv : pool_free)
     for (u64* p : kv.second) acehip_free(p);
   pool_free.clear();
+  for (auto& b : pool_limbo) acehip_free(b.first);
+  pool_limbo.clear();
   for (auto& kv : pool_live) acehip_free(kv.first);
   pool_live.clear();
   pool_live_bytes = 0;
@@ -480,7 +519,7 @@ POLY Mod_down(POLY res, POLY poly) {
     g_pend.kind = 0;
     HIPCHK(acehip_mod_down2(c.hip, p.out, out, p.in, in, level, nullptr));
   } else {
-    hw_flush();  // everything issued so far, including an unpaired predecessor
+    hw_flush_site(__FILE__, __LINE__);  // everything issued so far, including an unpaired predecessor
     g_pend.kind = 1;
     g_pend.out = out;
     g_pend.in = in;
@@ -507,7 +546,7 @@ POLY Rescale(POLY res, POLY poly) {
       g_pend.kind = 0;
       HIPCHK(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr));
     } else {
-      hw_flush();
+      hw_flush_site(__FILE__, __LINE__);
       g_pend.kind = 2;
       g_pend.out = out;
       g_pend.in = in;

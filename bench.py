@@ -20,9 +20,11 @@ Same JSON line:
   roofline      the dominant kernel family (forward NTT, its two 8-stage pass kernels), HIP events on the
                 launch stream over a 1024-limb batch (512 MiB > Infinity Cache): algorithmic 16*N B/limb
   key_switch    C3 key-switch, HIP-event timed
-  cpu_baseline  reference rtlib (oracle/_ref/ref_dump, kind "reference") or the oracle port on this
-                host, 1 thread, bounded sample (NTT + key-switch micro-ops), scaled to images/s with the
-                measured op mix of the full CPU run recorded in profiles/cpu_resnet20_devbox.json
+  cpu_baseline  reference rtlib (oracle/_ref/ref_dump, kind "reference") on this host before the GPU is touched:
+                one process per usable physical core of ONE socket, all at once (cores = how many; a cgroup CPU quota
+                below the socket size is reported and the full socket given as an ideal-scaling extrapolation), with
+                the 1-core figures beside it; bounded sample (NTT + key-switch micro-ops), scaled to images/s with
+                the measured op mix of the full CPU run recorded in profiles/cpu_resnet20_devbox.json
 """
 import argparse
 import ctypes as C
@@ -44,20 +46,95 @@ N_CT = 16                                    # ciphertext pairs in the resident 
 MODEL_LIB = os.path.join(ROOT, "oracle", "_ref", "models", "libmodel_resnet20.so")
 
 
+def cpu_topology():
+    """Physical cores of socket 0 usable by this process: one logical CPU per core (lscpu), intersected with the
+    affinity mask, capped by the cgroup CPU quota (a container may see 256 CPUs and be allowed 16 of them)."""
+    import math
+
+    allowed = sorted(os.sched_getaffinity(0))
+    per_core = {}
+    sockets = set()
+    try:
+        out = subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, check=True).stdout
+        for line in out.splitlines():
+            if line.startswith("#") or not line.strip():
+                continue
+            cpu, core, sock = (int(x) for x in line.split(",")[:3])
+            sockets.add(sock)
+            if sock == min(sockets | {sock}) and cpu in allowed:
+                per_core.setdefault((sock, core), cpu)
+    except Exception:  # noqa: BLE001 -- no lscpu: treat every allowed CPU as a core
+        per_core = {(0, c): c for c in allowed}
+        sockets = {0}
+    s0 = min(sockets) if sockets else 0
+    cpus = [cpu for (sock, _), cpu in sorted(per_core.items()) if sock == s0]
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:  # noqa: BLE001
+        pass
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:  # noqa: BLE001
+        pass
+    usable = len(cpus) if quota is None else max(1, min(len(cpus), int(math.floor(quota))))
+    return {"cpu_model": model, "sockets": len(sockets), "cores_per_socket": len(cpus), "cgroup_cpu_quota": quota,
+            "pin_cpus": cpus[:usable]}
+
+
+def _ref_bench(ref, cpus, ks_reps, ntt_reps):
+    """One `ref_dump bench` child per entry of cpus, started together, each pinned to its CPU; returns their JSON results."""
+    procs = []
+    for cpu in cpus:
+        procs.append(subprocess.Popen([ref, "bench", str(N), str(L), str(Q0), str(SF), str(DNUM), str(L), str(ks_reps), str(ntt_reps)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      preexec_fn=(lambda c=cpu: os.sched_setaffinity(0, {c}))))
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("ref_dump bench exited with %d" % p.returncode)
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    return res
+
+
 def cpu_baseline(have_model):
-    """Reference rtlib micro-ops timed on this host (1 thread, ~15 s)."""
+    """Reference rtlib (oracle/_ref/ref_dump, built from /root/reference by oracle/Makefile) timed on this host BEFORE the
+    GPU is touched: (1) one process on one core, (2) one process per usable physical core of one socket, all at once
+    (the reference's throughput policy is one image per OpenMP thread on the cores of a socket, scripts/accuracy.sh:15-20,37,
+    dataset/resnet_cifar.main.inc:77-116).  Bounded sample: NTTs of one limb and full C3 key-switches; scaled to images/s with
+    the measured (CPU ResNet-20 s/image)/(CPU key-switch s) of profiles/cpu_resnet20_devbox.json."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    topo = cpu_topology()
     res = None
     if os.path.exists(ref):
         try:
-            out = subprocess.run([ref, "bench", str(N), str(L), str(Q0), str(SF), str(DNUM), str(L), "8", "3000"],
-                                 capture_output=True, text=True, timeout=300, check=True).stdout
-            r = json.loads(out.strip().splitlines()[-1])
-            res = {"cores": 1, "kind": "reference", "ntt_fwd_ms": round(r["ntt_fwd_s"] * 1e3, 4),
-                   "ntt_inv_ms": round(r["ntt_inv_s"] * 1e3, 4), "key_switch_s": round(r["key_switch_s"], 4),
-                   "sample": "3000 Ftt_fwd + 3000 Ftt_inv of one limb (N=2^16) and 8 full key-switches (L=25, dnum=4) "
-                             "by the reference rtlib (gcc -O3), 1 thread"}
-        except Exception as e:
+            one = _ref_bench(ref, topo["pin_cpus"][:1], 8, 3000)[0]
+            many = _ref_bench(ref, topo["pin_cpus"], 8, 3000) if len(topo["pin_cpus"]) > 1 else [one]
+            c = len(many)
+            agg_ks = sum(1.0 / r["key_switch_s"] for r in many)
+            agg_ntt = sum(2 * 16 * N / (r["ntt_fwd_s"] + r["ntt_inv_s"]) for r in many) / 1e9
+            res = {"cores": c, "kind": "reference", "cpu_model": topo["cpu_model"], "sockets": topo["sockets"],
+                   "cores_per_socket": topo["cores_per_socket"], "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
+                   "key_switch_per_s": round(agg_ks, 4), "ntt_GBs": round(agg_ntt, 4),
+                   "key_switch_s_per_core_loaded": round(c / agg_ks, 4),
+                   "one_core": {"ntt_fwd_ms": round(one["ntt_fwd_s"] * 1e3, 4), "ntt_inv_ms": round(one["ntt_inv_s"] * 1e3, 4),
+                                "key_switch_s": round(one["key_switch_s"], 4), "key_switch_per_s": round(1.0 / one["key_switch_s"], 4),
+                                "ntt_GBs": round(2 * 16 * N / (one["ntt_fwd_s"] + one["ntt_inv_s"]) / 1e9, 4)},
+                   "sample": "reference rtlib (gcc -O3): per process 3000 Ftt_fwd + 3000 Ftt_inv of one limb (N=2^16) and 8 full "
+                             "key-switches (L=25, dnum=4); first 1 process alone, then %d processes at once, one pinned to each "
+                             "usable physical core of socket 0" % c}
+            if topo["cgroup_cpu_quota"] is not None and c < topo["cores_per_socket"]:
+                res["sample"] += (" (the container's cgroup allows %.0f CPUs of the socket's %d cores: the full socket cannot be "
+                                  "loaded here; socket_extrapolated assumes ideal scaling from the measured %d)"
+                                  % (topo["cgroup_cpu_quota"], topo["cores_per_socket"], c))
+        except Exception as e:  # noqa: BLE001
             sys.stderr.write("reference baseline failed (%s); timing the oracle port instead\n" % e)
     if res is None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,12 +155,12 @@ def cpu_baseline(have_model):
         for _ in range(4):
             o.key_switch(a, key, L)
         t4 = time.perf_counter()
-        res = {"cores": 1, "kind": "port", "ntt_fwd_ms": round((t1 - t0) / reps * 1e3, 4),
-               "ntt_inv_ms": round((t2 - t1) / reps * 1e3, 4), "key_switch_s": round((t4 - t3) / 4, 4),
+        ks_s = (t4 - t3) / 4
+        res = {"cores": 1, "kind": "port", "cpu_model": topo["cpu_model"], "sockets": topo["sockets"],
+               "cores_per_socket": topo["cores_per_socket"], "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
+               "key_switch_per_s": round(1.0 / ks_s, 4), "ntt_GBs": round(2 * 16 * N * reps / (t2 - t0) / 1e9, 4),
+               "key_switch_s_per_core_loaded": round(ks_s, 4),
                "sample": "3000 fwd + 3000 inv NTTs of one limb (N=2^16) and 4 key-switches by oracle/ckks_oracle.c, 1 thread"}
-    ntt_gbs = 2 * 16 * N / ((res["ntt_fwd_ms"] + res["ntt_inv_ms"]) * 1e-3) / 1e9
-    res["ntt_GBs"] = round(ntt_gbs, 4)
-    res["key_switch_per_s"] = round(1.0 / res["key_switch_s"], 4)
     if have_model:
         # scale to images/s: (full CPU ResNet-20 seconds / key-switch seconds) measured once on the dev box
         dev = os.path.join(ROOT, "profiles", "cpu_resnet20_devbox.json")
@@ -94,11 +171,16 @@ def cpu_baseline(have_model):
                 ratio, src = d["image_s"] / d["key_switch_s"], "profiles/cpu_resnet20_devbox.json"
         if ratio is None:  # published: 1453.96 s/image (ace_pre.log:28); key-switch 0.58 s on the survey box
             ratio, src = 1453.96 / 0.58, "BASELINE.md (published 1453.96 s/image; 0.58 s key-switch)"
-        res["value"] = round(1.0 / (ratio * res["key_switch_s"]), 8)
+        res["value"] = round(res["key_switch_per_s"] / ratio, 8)
         res["unit"] = "images/s"
+        if "one_core" in res:
+            res["one_core"]["images_per_s"] = round(res["one_core"]["key_switch_per_s"] / ratio, 8)
         res["sample"] += "; scaled to images/s by (CPU ResNet-20 s/image) / (CPU key-switch s) = %.1f from %s" % (ratio, src)
     else:
         res["value"], res["unit"] = res["key_switch_per_s"], "key-switches/s"
+    if res["cores"] < res["cores_per_socket"]:
+        res["socket_extrapolated"] = {"cores": res["cores_per_socket"], "value": round(res["value"] * res["cores_per_socket"] / res["cores"], 8),
+                                      "unit": res["unit"], "note": "ideal linear scaling of the measured aggregate; an upper bound for the CPU"}
     return res
 
 
@@ -160,6 +242,12 @@ def main():
     # keep fd 1 clean for the ONE JSON line: route everything else to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    cpu_res = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.roofline_only:
+        # timed first: the host cores are idle and no child process is started once the GPU is initialised
+        want_model = args.workload != "keyswitch" and os.path.exists(MODEL_LIB)
+        cpu_res = cpu_baseline(want_model)
 
     import ace_compiler_amd as A
     from ace_compiler_amd.dist import Ranks
@@ -415,9 +503,13 @@ def main():
         if args.roofline_only:
             out.pop("key_switch")
             out.pop("workload_roofline")
-        if world == 1 and not args.no_cpu_baseline and not args.roofline_only:
-            out["cpu_baseline"] = cpu_baseline(use_model)
+        if cpu_res is not None:
+            out["cpu_baseline"] = cpu_res
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            ref_v = cpu_res.get("socket_extrapolated", cpu_res)["value"]
+            if cpu_res["unit"] == unit and ref_v > 0:
+                out["cpu_baseline"]["gpu_over_cpu_measured"] = round(value / cpu_res["value"], 1)
+                out["cpu_baseline"]["gpu_over_one_socket"] = round(value / ref_v, 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ranks.close()
     rt.close()
