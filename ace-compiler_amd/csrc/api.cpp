@@ -1489,6 +1489,37 @@ int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, cons
   return post_launch();
 }
 
+// Rotate_iteration's inner loop (ckks_bootstrap_context.c:1326-1341): out_i = sum_j rot_j (*) pt_{i,j} in the PQ basis
+int acehip_bsgs_inner(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out1, const uint64_t* const* in0, const uint64_t* const* in1,
+                      const uint64_t* const* pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs, uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L || pt_q_limbs < level || pt_q_limbs > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: bad level");
+  if (g == 0 || b == 0 || g > BSGS_MAX_G || b > BSGS_MAX_B || g * b > BSGS_MAX_PT) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: g, b out of range");
+  BsgsArgs a{};
+  u32 n_pt = 0;
+  for (u32 j = 0; j < g; ++j) {
+    if (!in0[j] || !in1[j]) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: null input");
+    a.in0[j] = in0[j];
+    a.in1[j] = in1[j];
+  }
+  for (u32 i = 0; i < b; ++i) {
+    if (!out0[i] || !out1[i]) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: null output");
+    a.out0[i] = out0[i];
+    a.out1[i] = out1[i];
+    for (u32 j = 0; j < g; ++j) {
+      a.pt[i * g + j] = pt[i * g + j];
+      n_pt += pt[i * g + j] != nullptr;
+    }
+  }
+  a.g = g;
+  a.b = b;
+  a.pt_q_alloc = pt_q_limbs;
+  launch_bsgs_inner(c->dc, a, level, (hipStream_t)s);
+  const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
+  stat(ST_EW, n_pt, 8ull * E * (2ull * g + n_pt + 2ull * b));
+  return post_launch();
+}
+
 int acehip_stats(acehip_stat* out, int n, int reset) {
   for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = g_stat[i];
   if (reset) std::memset(g_stat, 0, sizeof(g_stat));

@@ -131,6 +131,17 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
 //   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s);
+// BSGS inner products (keyswitch.hip bsgs_inner_kernel): kernel-argument block, g <= 16, b <= 16, g*b <= 128
+constexpr u32 BSGS_MAX_G = 16, BSGS_MAX_B = 16, BSGS_MAX_PT = 128;
+struct BsgsArgs {
+  const u64* in0[BSGS_MAX_G];   // c0 of the g pre-rotated PQ-extended ciphertexts (level + K limbs each)
+  const u64* in1[BSGS_MAX_G];
+  u64* out0[BSGS_MAX_B];        // c0 / c1 of the b results
+  u64* out1[BSGS_MAX_B];
+  const u64* pt[BSGS_MAX_PT];   // [b][g] plaintext polynomials (q-limbs first, p-limbs at limb pt_q_alloc); nullptr = absent
+  u32 g, b, pt_q_alloc;
+};
+void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s);
 // ModDown tail for two polynomials: out_z = shoup(x_z - t_z, pinv), z in {0,1}
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
                           const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys = 2);

@@ -83,6 +83,65 @@ void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key,
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Baby-step giant-step inner products of a homomorphic linear transform (Rotate_iteration
+// ckks_bootstrap_context.c:1326-1341, the Mul_plaintext / Add loops over one giant step):
+//   out_i = sum_{j < g} rot_j (*) pt_{i,j}      for every i < b, both polynomials of the PQ-extended ciphertexts
+// One lane keeps its two coefficients of all g pre-rotated ciphertexts (c0 and c1) in registers and streams the b*g
+// plaintext diagonals past them once: per limb 2g + b*g + 2b limb transfers instead of the 3*b*g + 2b of one
+// multiply-accumulate chain per output (the rotated ciphertexts -- 2g*(l+K) limbs, hundreds of MiB -- are otherwise
+// re-read for every i).  Products are accumulated exactly in 128 bits and reduced once per output (g <= 16 products
+// below 2^122 each), so the result is the canonical residue of the exact sum whatever the order.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u32 level) {
+  const u32 pos = blockIdx.y;
+  const u32 gi = limb_prime(pos, level, c.L);
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, ml = P.prec128_lo, mh = P.prec128_hi;
+  const size_t ct_off = (size_t)pos * c.N;  // PQ-extended ciphertext: p-limbs follow the q-limbs
+  // plaintext: q-limb `pos`, or p-limb (pos - level) behind its own (possibly higher) number of q-limbs
+  const size_t pt_off = pos < level ? ct_off : (size_t)(a.pt_q_alloc + (pos - level)) * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  ulong2 r0[G], r1[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (j < (int)a.g) {
+      r0[j] = *reinterpret_cast<const ulong2*>(a.in0[j] + ct_off + i);
+      r1[j] = *reinterpret_cast<const ulong2*>(a.in1[j] + ct_off + i);
+    }
+  }
+  for (u32 bi = 0; bi < a.b; ++bi) {
+    U128 s0x{0, 0}, s0y{0, 0}, s1x{0, 0}, s1y{0, 0};
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const u64* pt = j < (int)a.g ? a.pt[bi * a.g + j] : nullptr;
+      if (pt != nullptr) {  // a missing diagonal (giant + j == num_rot) contributes nothing
+        const ulong2 p = *reinterpret_cast<const ulong2*>(pt + pt_off + i);
+        mac128(s0x, r0[j].x, p.x);
+        mac128(s0y, r0[j].y, p.y);
+        mac128(s1x, r1[j].x, p.x);
+        mac128(s1y, r1[j].y, p.y);
+      }
+    }
+    ulong2 o0, o1;
+    o0.x = reduce128(s0x, q, ml, mh);
+    o0.y = reduce128(s0y, q, ml, mh);
+    o1.x = reduce128(s1x, q, ml, mh);
+    o1.y = reduce128(s1y, q, ml, mh);
+    *reinterpret_cast<ulong2*>(a.out0[bi] + ct_off + i) = o0;
+    *reinterpret_cast<ulong2*>(a.out1[bi] + ct_off + i) = o1;
+  }
+}
+
+void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
+  else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
+  else               hipLaunchKernelGGL((bsgs_inner_kernel<16>), grid, block, 0, s, c, a, level);
+}
+
 __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __restrict__ out0, u64* __restrict__ out1,
                                                             const u64* __restrict__ x0, const u64* __restrict__ x1,
                                                             const u64* __restrict__ t0, const u64* __restrict__ t1,

@@ -511,12 +511,49 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
   poly_alloc(&first, c.N, l, c.K);
   poly_alloc(&temp_poly, c.N, l, c.K);
   first._is_ntt = temp_poly._is_ntt = true;
-  Ct outer, inner;
+  // inner_i = sum_j fast_rot[j] (*) diag[giant_step*i + j] for all baby steps in one pass over the diagonals
+  // (acehip_bsgs_inner); the per-output multiply-accumulate chains are the fallback for shapes the kernel does not take
+  std::vector<Ct> inners(baby_step);
+  bool fused = giant_step <= 16 && baby_step <= 16 && giant_step * baby_step <= 128;
+  u32 pt_q = 0;
+  if (fused) {
+    for (int i = 0; i < baby_step && fused; i++)
+      for (int j = 0; j < giant_step; j++) {
+        if (j > 0 && giant_step * i + j == num_rot) continue;  // the one diagonal a full grid would have too many
+        PLAINTEXT* p = conj_pre[step][giant_step * i + j];
+        const u32 nq = (u32)(p->_poly._num_alloc_primes - p->_poly._num_primes_p);
+        if (p->_poly._num_primes_p != c.K || p->_poly._num_primes < l || (pt_q && nq != pt_q)) fused = false;
+        pt_q = nq;
+      }
+  }
+  if (fused) {
+    std::vector<u64*> o0(baby_step), o1(baby_step);
+    std::vector<const u64*> i0(giant_step), i1(giant_step), pts((size_t)baby_step * giant_step, nullptr);
+    for (int j = 0; j < giant_step; j++) {
+      i0[j] = q_limbs(&fast_rot[j].c._c0_poly);
+      i1[j] = q_limbs(&fast_rot[j].c._c1_poly);
+    }
+    for (int i = 0; i < baby_step; i++) {
+      PLAINTEXT* p0 = conj_pre[step][giant_step * i];
+      ev::init(inners[i], l, c.K, fast_rot[0].c._scaling_factor * p0->_scaling_factor, fast_rot[0].c._sf_degree + p0->_sf_degree,
+               fast_rot[0].c._slots, false);  // the kernel writes every limb
+      o0[i] = q_limbs(&inners[i].c._c0_poly);
+      o1[i] = q_limbs(&inners[i].c._c1_poly);
+      for (int j = 0; j < giant_step; j++)
+        if (j == 0 || giant_step * i + j != num_rot)
+          pts[(size_t)i * giant_step + j] = q_limbs(&conj_pre[step][giant_step * i + j]->_poly);
+    }
+    HIPCHK(acehip_bsgs_inner(c.hip, o0.data(), o1.data(), i0.data(), i1.data(), pts.data(), (u32)giant_step, (u32)baby_step, pt_q, l, nullptr));
+  }
+  Ct outer;
   for (int i = 0; i < baby_step; i++) {
     const int giant = giant_step * i;
-    mul_plain_ext(inner, fast_rot[0], conj_pre[step][giant], false);
-    for (int j = 1; j < giant_step; j++)
-      if (giant + j != num_rot) mul_plain_ext(inner, fast_rot[j], conj_pre[step][giant + j], true);
+    Ct& inner = inners[i];
+    if (!fused) {
+      mul_plain_ext(inner, fast_rot[0], conj_pre[step][giant], false);
+      for (int j = 1; j < giant_step; j++)
+        if (giant + j != num_rot) mul_plain_ext(inner, fast_rot[j], conj_pre[step][giant + j], true);
+    }
     if (i == 0) {
       poly_copy(&first, &inner.c._c0_poly);
       fill_zero((u64*)inner.c._c0_poly._data, E);

@@ -138,6 +138,8 @@ void hw_stats_print();
 void hw_flush_sites_print();
 bool hw_queue_empty();   // nothing queued (a held-back Mod_down / Rescale does not count)
 void hw_pending_flush(); // issue a held-back Mod_down / Rescale now
+// the caller is about to rewrite limbs [out, out + n_limbs) completely with a direct launch: queued fills of them are dead
+void hw_cancel_fills(const u64* out, size_t n_limbs);
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs = 1);
 // queued multi-limb forms, argument meaning as acehip_modadd & co: limbs [pos0, pos0+n) of polynomials extended
 // at `level` (limb p < level is prime p, the others are p primes); scalars[i] belongs to limb pos0+i

@@ -128,10 +128,16 @@ struct ModupCache {
   bool valid = false;
 };
 thread_local ModupCache g_muc;
+void queue_submit();
+void cancel_fills(const u64* out, size_t n_limbs);
+// The held-back op was called after everything that is queued now (a later hw_queue() would have issued it first): hand
+// the queue over, then launch it.  Its output is rewritten completely, so zero fills still queued for it are dead.
 void pending_flush() {
   if (!g_pend.kind) return;
   const PendingPair p = g_pend;
   g_pend.kind = 0;
+  cancel_fills(p.out, p.kind == 1 ? p.level : p.level - 1);
+  queue_submit();
   const int rc = p.kind == 1 ? acehip_mod_down(ctx().hip, p.out, p.in, p.level, nullptr)
                              : acehip_rescale(ctx().hip, p.out, p.in, p.level, nullptr);
   RT_ASSERT(rc >= 0, "deferred %s failed: %s", p.kind == 1 ? "Mod_down" : "Rescale", acehip_last_error());
@@ -143,9 +149,42 @@ static void limbo_release() {
   for (auto& b : pool_limbo) pool_free[b.second].push_back(b.first);
   pool_limbo.clear();
 }
-void hw_flush() {
-  pending_flush();   // it was issued after everything flushed earlier and before everything queued since
-  g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
+namespace {
+// Generated code initialises a result (Init_ciph_*: zero fill on reuse, polynomial.h:331-348) and then has Mod_down /
+// Rescale / ... rewrite it completely; the fill sits in the queue when the direct kernel is about to be launched.
+// Drops queued ZERO / COPY ops on limbs [out, out + n_limbs) that no later queued op reads.
+void cancel_fills(const u64* out, size_t n_limbs) {
+  if (g_hwq.empty() || n_limbs == 0) return;
+  const size_t N = ctx().N;
+  const u64* end = out + n_limbs * N;
+  auto inside = [&](const void* p) { return p != nullptr && (const u64*)p >= out && (const u64*)p < end; };
+  std::vector<const u64*> read_later;
+  bool any = false;
+  for (size_t k = g_hwq.size(); k-- > 0;) {
+    acehip_hw_op& o = g_hwq[k];
+    if (inside(o.res) && (o.op == ACEHIP_HW_ZERO || o.op == ACEHIP_HW_COPY)) {
+      bool live = false;
+      for (const u64* r : read_later) live |= r == o.res;
+      if (!live) {
+        o.res = nullptr;  // marks the op as cancelled
+        any = true;
+        continue;
+      }
+    }
+    // what this op reads: a always (except ZERO); b for the two-operand kinds; res for MULADD
+    if (o.op != ACEHIP_HW_ZERO && inside(o.a)) read_later.push_back(o.a);
+    if ((o.op == ACEHIP_HW_ADD || o.op == ACEHIP_HW_SUB || o.op == ACEHIP_HW_MUL || o.op == ACEHIP_HW_MULADD) && inside(o.b))
+      read_later.push_back((const u64*)o.b);
+    if (o.op == ACEHIP_HW_MULADD && inside(o.res)) read_later.push_back(o.res);
+  }
+  if (any) {
+    size_t w = 0;
+    for (size_t k = 0; k < g_hwq.size(); ++k)
+      if (g_hwq[k].res != nullptr) g_hwq[w++] = g_hwq[k];
+    g_hwq.resize(w);
+  }
+}
+void queue_submit() {
   if (g_hwq.empty()) {
     limbo_release();
     return;
@@ -167,6 +206,13 @@ void hw_flush() {
   RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());
   limbo_release();
 }
+}  // namespace
+void hw_flush() {
+  pending_flush();      // it was called before everything queued since (there is nothing: see hw_queue) and after the rest
+  g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
+  queue_submit();
+}
+void hw_cancel_fills(const u64* out, size_t n_limbs) { cancel_fills(out, n_limbs); }
 // ACEHIP_PROFILE: which call sites hand over how many queued limb-ops (finds what cuts accumulation chains short)
 namespace {
 thread_local std::map<std::pair<std::string, int>, std::pair<size_t, size_t>> g_flush_sites;
@@ -517,9 +563,12 @@ POLY Mod_down(POLY res, POLY poly) {
   if (g_pend.kind == 1 && g_pend.level == level && g_pend.out != out && g_pend.in != in && g_pend.out != in && g_pend.in != out) {
     const PendingPair p = g_pend;
     g_pend.kind = 0;
+    cancel_fills(p.out, level);
+    cancel_fills(out, level);
     HIPCHK(acehip_mod_down2(c.hip, p.out, out, p.in, in, level, nullptr));
   } else {
-    hw_flush_site(__FILE__, __LINE__);  // everything issued so far, including an unpaired predecessor
+    pending_flush();  // an unpaired predecessor; this call is held back (the queue is handed over when it is issued)
+    g_muc.valid = false;
     g_pend.kind = 1;
     g_pend.out = out;
     g_pend.in = in;
@@ -544,9 +593,12 @@ POLY Rescale(POLY res, POLY poly) {
     if (g_pend.kind == 2 && g_pend.level == level && g_pend.out != out && g_pend.in != in && g_pend.out != in && g_pend.in != out) {
       const PendingPair p = g_pend;
       g_pend.kind = 0;
+      cancel_fills(p.out, level - 1);
+      cancel_fills(out, level - 1);
       HIPCHK(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr));
     } else {
-      hw_flush_site(__FILE__, __LINE__);
+      pending_flush();
+      g_muc.valid = false;
       g_pend.kind = 2;
       g_pend.out = out;
       g_pend.in = in;

@@ -232,6 +232,14 @@ int acehip_add_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, co
  *   limbs, no ModDown. */
 int acehip_modup_digits(acehip_ctx* ctx, uint64_t* d_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext, uint32_t level, acehip_stream stream);
+/* Baby-step giant-step inner products of Rotate_iteration (ckks_bootstrap_context.c:1326-1341: Mul_plaintext +
+ * Add_ciphertext over one giant step, for every baby step): d_out{0,1}[i] = sum_{j<g} d_in{0,1}[j] (*) pt[i*g + j],
+ * i < b, over the level+K limbs of PQ-extended ciphertexts, in ONE pass over the plaintext diagonals.  pt entries are
+ * device polynomials with pt_q_limbs >= level q-limbs followed by K p-limbs (Derive_plain); a NULL entry is skipped.
+ * The arrays themselves are host arrays of device pointers.  g, b <= 16, g*b <= 128. */
+int acehip_bsgs_inner(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* const* d_out1, const uint64_t* const* d_in0,
+                      const uint64_t* const* d_in1, const uint64_t* const* d_pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs,
+                      uint32_t level, acehip_stream stream);
 
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
