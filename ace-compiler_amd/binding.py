@@ -82,6 +82,7 @@ SYMBOLS = [
     ("acehip_key_inner_product", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
+    ("acehip_bsgs_inner", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
 ]
 
 _lib = None

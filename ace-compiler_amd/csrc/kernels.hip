@@ -232,26 +232,42 @@ void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const
 // One lane per coefficient; the n_in source residues stay in registers and are reused for the
 // JG output limbs of this workgroup (blockIdx.y selects the group).
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxConvIn = 16;  // alpha and K are <= 12 for every parameter set of the reference
+constexpr int kConvChunk = 16;  // source limbs held in registers at a time (alpha, K <= 12 for the reference's sets)
 constexpr int kConvGroup = 4;
 
+// n_in <= 64: 64 products below 2^122 cannot overflow the 128-bit sums.  Sources are taken in chunks of 16, the output
+// sums of the group stay in registers across chunks (the usual case is a single chunk: the loop runs once).
 __global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ in,
                                                         const u64* __restrict__ hat, const u32* __restrict__ out_gi,
                                                         const u32* __restrict__ out_pos, u32 n_in, u32 n_out,
                                                         u32 hat_ld) {
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
-  u64 y[kMaxConvIn];
-#pragma unroll
-  for (int i = 0; i < kMaxConvIn; ++i) y[i] = (u32)i < n_in ? in[(size_t)i * c.N + n] : 0;
   const u32 j0 = blockIdx.y * kConvGroup;
-  for (u32 j = j0; j < j0 + kConvGroup && j < n_out; ++j) {
-    const DevPrime P = c.primes[out_gi[j]];
-    U128 acc{0, 0};
+  U128 acc[kConvGroup];
 #pragma unroll
-    for (int i = 0; i < kMaxConvIn; ++i)
-      if ((u32)i < n_in) mac128(acc, y[i], hat[(size_t)i * hat_ld + j]);
-    out[(size_t)out_pos[j] * c.N + n] = reduce128(acc, P.q, P.prec128_lo, P.prec128_hi);
+  for (int g = 0; g < kConvGroup; ++g) acc[g] = U128{0, 0};
+  for (u32 i0 = 0; i0 < n_in; i0 += kConvChunk) {
+    u64 y[kConvChunk];
+#pragma unroll
+    for (int i = 0; i < kConvChunk; ++i) y[i] = i0 + i < n_in ? in[(size_t)(i0 + i) * c.N + n] : 0;
+#pragma unroll
+    for (int g = 0; g < kConvGroup; ++g) {
+      const u32 j = j0 + g;
+      if (j < n_out) {
+#pragma unroll
+        for (int i = 0; i < kConvChunk; ++i)
+          if (i0 + i < n_in) mac128(acc[g], y[i], hat[(size_t)(i0 + i) * hat_ld + j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < kConvGroup; ++g) {
+    const u32 j = j0 + g;
+    if (j < n_out) {
+      const DevPrime P = c.primes[out_gi[j]];
+      out[(size_t)out_pos[j] * c.N + n] = reduce128(acc[g], P.q, P.prec128_lo, P.prec128_hi);
+    }
   }
 }
 

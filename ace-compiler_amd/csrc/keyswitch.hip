@@ -6,10 +6,12 @@
 
 namespace acehip {
 
-constexpr int kMaxIn = 16;   // alpha, K <= 12 for the reference parameter sets
+constexpr int kMaxIn = 16;   // source limbs held in registers at a time (alpha, K <= 12 for the reference parameter sets)
 constexpr int kGroup = 8;    // output limbs per workgroup row (sources stay in registers)
 
 // out[pos_j][n] = ( sum_i y_i[n] * hat[i][j] ) mod t_j,  y_i = in[src_pos0+i][n] (* scale_i mod q_i)
+// n_in <= 64 (checked when the context is created): sources go through the registers in chunks of kMaxIn, the 128-bit
+// sums of the group's outputs persist across chunks; one chunk is the usual case.
 __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                               const u64* __restrict__ in, size_t in_stride,
                                                               const ConvDesc* __restrict__ descs, u32 desc_step) {
@@ -20,23 +22,38 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
   if (n >= c.N) return;
   const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + n;
   u64* dst = out + blockIdx.z * out_stride + n;
-  u64 y[kMaxIn];
+  U128 acc[kGroup];
 #pragma unroll
-  for (int i = 0; i < kMaxIn; ++i) {
-    y[i] = 0;
-    if ((u32)i < d.n_in) {
-      u64 v = src[(size_t)i * c.N];
-      if (d.scale) v = mul_shoup(v, d.scale[i], d.scale_prec[i], c.primes[d.src_gi[i]].q);
-      y[i] = v;
+  for (int g = 0; g < kGroup; ++g) acc[g] = U128{0, 0};
+  for (u32 i0 = 0; i0 < d.n_in; i0 += kMaxIn) {
+    u64 y[kMaxIn];
+#pragma unroll
+    for (int i = 0; i < kMaxIn; ++i) {
+      y[i] = 0;
+      if (i0 + i < d.n_in) {
+        u64 v = src[(size_t)(i0 + i) * c.N];
+        if (d.scale) v = mul_shoup(v, d.scale[i0 + i], d.scale_prec[i0 + i], c.primes[d.src_gi[i0 + i]].q);
+        y[i] = v;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      const u32 j = j0 + g;
+      if (j < d.n_out) {
+        const u32 col = d.col ? d.col[j] : j;
+#pragma unroll
+        for (int i = 0; i < kMaxIn; ++i)
+          if (i0 + i < d.n_in) mac128(acc[g], y[i], d.hat[(size_t)(i0 + i) * d.hat_ld + col]);
+      }
     }
   }
-  for (u32 j = j0; j < j0 + kGroup && j < d.n_out; ++j) {
-    const DevPrime& P = c.primes[d.out_gi[j]];
-    U128 acc{0, 0};
 #pragma unroll
-    for (int i = 0; i < kMaxIn; ++i)
-      if ((u32)i < d.n_in) mac128(acc, y[i], d.hat[(size_t)i * d.hat_ld + (d.col ? d.col[j] : j)]);
-    dst[(size_t)d.out_pos[j] * c.N] = reduce128(acc, P.q, P.prec128_lo, P.prec128_hi);
+  for (int g = 0; g < kGroup; ++g) {
+    const u32 j = j0 + g;
+    if (j < d.n_out) {
+      const DevPrime& P = c.primes[d.out_gi[j]];
+      dst[(size_t)d.out_pos[j] * c.N] = reduce128(acc[g], P.q, P.prec128_lo, P.prec128_hi);
+    }
   }
 }
 

@@ -24,6 +24,7 @@ SETS = [  # N, L, q0, sf, dnum, levels
     (4096, 4, 60, 50, 2, [4]),
     (8192, 4, 60, 50, 2, [4, 3]),
     (16384, 4, 60, 50, 2, [4]),
+    (64, 40, 60, 50, 2, [40, 25]),   # alpha = 20, K = 17: more source limbs than one register chunk of the base conversion
 ]
 
 

@@ -91,3 +91,16 @@ def test_no_cpu_fallback():
     if A.load_library().acehip_device_count() == 0:
         with pytest.raises(A.AceHipError):
             A.AceHip(16, 3, 60, 50, 2)
+
+
+def test_digit_size_limit():
+    """Base conversion sums alpha (ModUp) or K (ModDown) products of 122 bits exactly in 128 bits: up to 64 source limbs per
+    digit are supported (the kernels take them through the registers in chunks of 16); more is refused when the context is
+    created instead of dropping limbs silently (keyswitch.hip kMaxIn)."""
+    import ace_compiler_amd as A
+
+    rt = A.AceHip(64, 40, 60, 50, 2, host_only=True)   # alpha = 20, K = 17: fine
+    assert (rt.alpha, rt.K) == (20, 17)
+    rt.close()
+    with pytest.raises(Exception, match="64 limbs"):
+        A.AceHip(16, 70, 40, 30, 1, host_only=True)      # alpha = 70
