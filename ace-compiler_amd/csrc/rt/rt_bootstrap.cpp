@@ -932,7 +932,12 @@ void bootstrap_setup_if_needed() {  // Bootstrap_precom context.c:162-185
   Context& c = ctx();
   const u32 bts_depth = approx_mod_depth(c.hamming) + 3 + 3;
   if (c.L - 1 > bts_depth) {
-    Precom* pre = bootstrap_setup(c.N / 2);
+    Precom* pre;
+    {
+      RtmScope rtm(RTM_BS_SETUP);
+      pre = bootstrap_setup(c.N / 2);
+    }
+    RtmScope rtm(RTM_BS_KEYGEN);
     bootstrap_keygen(pre);
   }
 }
@@ -957,6 +962,7 @@ void bootstrap(Ct& res, Ct& ciph, u32 raise_level) {
   const u32 slots = ciph.c._slots, N = c.N, m = 2 * N;
   Precom* pre = bootstrap_setup(slots);
   bootstrap_keygen(pre);
+  RtmScope rtm_eval(RTM_BS_EVAL);
   const int32_t deg = (int32_t)round(log2((double)c.primes[0] / c.sf));
   Ct raised;
   ev::copy(raised, ciph);
@@ -974,7 +980,10 @@ void bootstrap(Ct& res, Ct& ciph, u32 raise_level) {
   auto& u0 = pre->u0_fft;
   Ct enc;
   if (slots == m / 4) {
-    coeff_slots_transform(enc, nc, u0hatt, pre, true);
+    {
+      RtmScope rtm(RTM_BS_COEFF_TO_SLOT);
+      coeff_slots_transform(enc, nc, u0hatt, pre, true);
+    }
     Ct conj, enc_sub;
     ev::conjugate(conj, enc);
     ev::sub(enc_sub, enc, conj);
@@ -984,25 +993,43 @@ void bootstrap(Ct& res, Ct& ciph, u32 raise_level) {
       ev::rescale(enc, enc);
       ev::rescale(enc_sub, enc_sub);
     }
-    eval_approx_mod(enc, enc);
-    eval_approx_mod(enc_sub, enc_sub);
+    {
+      RtmScope rtm(RTM_BS_APPROX_MOD);
+      eval_approx_mod(enc, enc);
+      eval_approx_mod(enc_sub, enc_sub);
+    }
     ev::mul_monomial(enc_sub, enc_sub, m / 4);
     ev::add(enc, enc, enc_sub);
-    coeff_slots_transform(res, enc, u0, pre, false);
+    {
+      RtmScope rtm(RTM_BS_SLOT_TO_COEFF);
+      coeff_slots_transform(res, enc, u0, pre, false);
+    }
   } else {
     // sparsely packed: partial sums first (:1770-1777)
     Ct temp;
-    for (u32 j = 1; j < N / (2 * slots); j <<= 1) {
-      ev::rotate(temp, nc, (int32_t)(j * slots));
-      ev::add(nc, nc, temp);
+    {
+      RtmScope rtm(RTM_BS_PARTIAL_SUM);
+      for (u32 j = 1; j < N / (2 * slots); j <<= 1) {
+        ev::rotate(temp, nc, (int32_t)(j * slots));
+        ev::add(nc, nc, temp);
+      }
     }
-    coeff_slots_transform(enc, nc, u0hatt, pre, true);
+    {
+      RtmScope rtm(RTM_BS_COEFF_TO_SLOT);
+      coeff_slots_transform(enc, nc, u0hatt, pre, true);
+    }
     Ct conj;
     ev::conjugate(conj, enc);
     ev::add(enc, enc, conj);
     while (enc.c._sf_degree > 1) ev::rescale(enc, enc);
-    eval_approx_mod(enc, enc);
-    coeff_slots_transform(res, enc, u0, pre, false);
+    {
+      RtmScope rtm(RTM_BS_APPROX_MOD);
+      eval_approx_mod(enc, enc);
+    }
+    {
+      RtmScope rtm(RTM_BS_SLOT_TO_COEFF);
+      coeff_slots_transform(res, enc, u0, pre, false);
+    }
     Ct rot;
     ev::rotate(rot, res, (int32_t)slots);
     ev::add(res, res, rot);
@@ -1035,9 +1062,11 @@ CIPHER Bootstrap(CIPHER res, CIPHER ciph, uint32_t level_after_bts) {
   Context& c = ctx();
   const u32 bts_depth = approx_mod_depth(c.hamming) + 3 + 3;
   if (ciph->_sf_degree == 1 && ciph->_c0_poly._num_primes >= level_after_bts) {
+    RtmScope rtm(RTM_BS_COPY);  // cipher_eval.c:389-396 files the early return under BS_COPY
     if (res != ciph) Copy_ciph(res, ciph);
     return res;
   }
+  RtmScope rtm(RTM_BOOTSTRAP);
   RT_ASSERT(!level_after_bts || level_after_bts <= c.L - bts_depth, "The level set after bootstrapping is excessively high");
   const u32 raise_level = level_after_bts ? level_after_bts + bts_depth : c.L;
   Ct in, out;

@@ -186,6 +186,7 @@ extern "C" {
 
 void Prepare_context() {
   if (g_ctx != nullptr) return;
+  RtmScope rtm(RTM_PREPARE_CONTEXT, false);
   std::lock_guard<std::recursive_mutex> prep_lock(shared_mu());
   if (g_primary != nullptr) {  // another thread prepared already: this one becomes a view of that context
     (void)ctx();
@@ -266,6 +267,7 @@ void Finalize_context() {
     return;
   }
   std::lock_guard<std::recursive_mutex> fin_lock(shared_mu());
+  const uint64_t fin_t0 = rtm_enabled() ? rtm_now() : 0;
   Context& c = *g_ctx;
   sync();
   HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
@@ -312,6 +314,8 @@ void Finalize_context() {
   delete g_ctx;
   g_ctx = nullptr;
   g_primary = nullptr;
+  if (fin_t0) rtm_add(RTM_FINALIZE_CONTEXT, rtm_now() - fin_t0);
+  rtm_report();  // RTLIB_TM_REPORT() at the end of Finalize_context (context.c:130-133)
 }
 // Extension: a worker thread that used the API (it attached to the prepared context on first use) gives back
 // its scratch context, pool and queue before it ends; Finalize_context from such a thread does the same.
@@ -341,7 +345,8 @@ POLY Pk1_at(SW_KEY swk, uint32_t idx) {
   return &swk->_parts[idx]._pk1;
 }
 
-void Run_main_graph() {  // common/src/rt_lib.c:16-21
+void Run_main_graph() {
+  RtmScope rtm(RTM_MAIN_GRAPH);  // common/src/rt_lib.c:16-21
   const double t0 = wall_s();
   bool ok = Main_graph();
   const double t1 = wall_s();

@@ -116,6 +116,7 @@ void stage_release() {
 
 // Encode_impl ckks_encoder.c:199-297 on device-resident values (kind: 0 float, 1 double, 2 complex double)
 void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
+  RtmScope rtm(RTM_ENCODE_ARRAY);
   Context& c = ctx();
   RT_ASSERT(res, "null plaintext");
   const double t0 = c.profile ? wall_s() : 0;
@@ -160,6 +161,7 @@ void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u3
 
 // Encode_val_at_level ckks_encoder.c:464-530 (+ Scale_back_up_by_approxfactor :406-460)
 void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree) {
+  RtmScope rtm(RTM_ENCODE_VALUE);
   Context& c = ctx();
   RT_ASSERT(res && sf_degree, "invalid plaintext / scaling factor degree");
   if (level == 0) level = c.L;
@@ -371,6 +373,7 @@ extern "C" {
 
 // plain_eval.c:25-58
 void Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_degree, uint32_t level) {
+  RtmScope rtm(RTM_PT_ENCODE);
   if (len == 1) {
     encode_value(plain, (double)*input, level, sc_degree);
     return;
@@ -380,6 +383,7 @@ void Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_
   ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }
 void Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t sc_degree, uint32_t level) {
+  RtmScope rtm(RTM_PT_ENCODE);
   if (len == 1) {
     encode_value(plain, *input, level, sc_degree);
     return;

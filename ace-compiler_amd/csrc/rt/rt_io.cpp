@@ -339,9 +339,11 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
   rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }
 void Pt_from_msg(void* pt, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
+  rt::RtmScope rtm(rt::RTM_PT_ENCODE);
   pt_encode((PLAIN)pt, index, len, scale, level);
 }
 void Pt_from_msg_validate(void* pt, float* buf, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
+  rt::RtmScope rtm(rt::RTM_PT_ENCODE);
   float* data = pt_entry(index, len);
   for (uint32_t i = 0; i < len; ++i)
     RT_ASSERT(fabs(buf[i] - data[i]) < 0.000001, "Pt_from_msg_validate failed. index=%d, i=%d: %f != %f.", index, i, buf[i], data[i]);

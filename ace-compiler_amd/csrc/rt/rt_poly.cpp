@@ -402,6 +402,7 @@ void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p) 
 }
 
 void poly_ntt(POLYNOMIAL* p, bool inverse) {
+  RtmScope rtm(inverse ? RTM_INTT : RTM_NTT);
   Context& c = ctx();
   auto fn = inverse ? acehip_ntt_inverse : acehip_ntt_forward;
   const u32 l = (u32)p->_num_primes;
@@ -461,7 +462,10 @@ void Free_poly(POLY poly) {
   poly_free(poly);
   free(poly);
 }
-void Copy_poly(POLY res, POLY poly) { poly_copy(res, poly); }
+void Copy_poly(POLY res, POLY poly) {
+  RtmScope rtm(RTM_COPY_POLY, false);
+  poly_copy(res, poly);
+}
 void Set_coeffs(POLY dst, uint32_t level, uint32_t degree, int64_t* src) {
   int64_t* d = Coeffs(dst, level, degree);
   if (d == src) return;  // generated code does self-copies (resnet20 .inc:1546)
@@ -471,14 +475,17 @@ size_t Num_decomp(POLY poly) { return acehip_num_decomp(ctx().hip, (uint32_t)pol
 
 // ---- poly_arith.c:14-56: one limb per call, modulus = Q_modulus()+i or P_modulus()+i ----
 int64_t* Hw_modadd(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
+  RtmScope rtm(RTM_HW_ADD, false);
   hw_queue(ACEHIP_HW_ADD, m->_gi, (u64*)res, (const u64*)a, b);
   return res + degree;
 }
 int64_t* Hw_modmul(int64_t* res, int64_t* a, int64_t* b, MODULUS* m, uint32_t degree) {
+  RtmScope rtm(RTM_HW_MUL, false);
   hw_queue(ACEHIP_HW_MUL, m->_gi, (u64*)res, (const u64*)a, b);
   return res + degree;
 }
 int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, uint32_t degree) {
+  RtmScope rtm(RTM_HW_ROT, false);
   if (res == a) {  // the reference loop would read overwritten data too; keep it well defined
     u64* tmp = dalloc(degree, false);
     copy_limbs((u64*)tmp, (const u64*)a, (size_t)degree);
@@ -492,6 +499,7 @@ int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, u
 
 // ---- poly_eval.c:11-49 ----
 POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
+  RtmScope rtm(RTM_DECOMP);
   Context& c = ctx();
   const u32 level = (u32)poly->_num_primes;
   const u32 start = c.alpha * q_part_idx;
@@ -509,6 +517,7 @@ POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
   return res;
 }
 POLY Mod_up(POLY new_poly, POLY old_poly, uint32_t q_part_idx) {
+  RtmScope rtm(RTM_MOD_UP);
   Context& c = ctx();
   const u32 level = (u32)new_poly->_num_primes;  // Raise_rns_base_with_parts(.., Poly_level(new_poly), ..)
   RT_ASSERT(new_poly->_num_primes_p == c.K && new_poly->_num_alloc_primes - c.K == level,
@@ -519,6 +528,7 @@ POLY Mod_up(POLY new_poly, POLY old_poly, uint32_t q_part_idx) {
   return new_poly;
 }
 POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
+  RtmScope rtm(RTM_DECOMP_MODUP);
   Context& c = ctx();
   const u32 level = (u32)poly->_num_primes;
   RT_ASSERT(res->_num_primes == level && res->_num_primes_p == c.K && res->_num_alloc_primes == level + c.K,
@@ -554,6 +564,7 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
   return res;
 }
 POLY Mod_down(POLY res, POLY poly) {
+  RtmScope rtm(RTM_MOD_DOWN);
   Context& c = ctx();
   const u32 level = (u32)poly->_num_primes;
   RT_ASSERT(res->_num_primes == level && poly->_num_primes_p == c.K, "reduce_rns_base: result size not match");
@@ -578,6 +589,7 @@ POLY Mod_down(POLY res, POLY poly) {
   return res;
 }
 POLY Rescale(POLY res, POLY poly) {
+  RtmScope rtm(RTM_RESCALE_POLY);
   Context& c = ctx();
   const u32 level = (u32)poly->_num_primes;
   RT_ASSERT(res->_num_primes == level, "Rescale_poly: primes not match");
@@ -646,21 +658,28 @@ static void init_cipher_from(CIPHER res, CIPHER ciph, double sf, u32 sf_degree) 
 }
 
 void Init_ciph_same_scale(CIPHER res, CIPHER ciph1, CIPHER ciph2) {
+  RtmScope rtm(RTM_INIT_CIPH_SM_SC, false);
   CIPHER c = ciph2 != nullptr ? lower_level(ciph1, ciph2) : ciph1;
   init_ciphertext(res, c->_c0_poly._ring_degree, c->_c0_poly._num_primes, c->_c0_poly._num_primes_p, c->_scaling_factor,
                   c->_sf_degree, c->_slots);
   res->_c0_poly._is_ntt = true;
   res->_c1_poly._is_ntt = true;
 }
-void Init_ciph_same_scale_plain(CIPHER res, CIPHER ciph, PLAIN) { init_cipher_from(res, ciph, ciph->_scaling_factor, ciph->_sf_degree); }
+void Init_ciph_same_scale_plain(CIPHER res, CIPHER ciph, PLAIN) {
+  RtmScope rtm(RTM_INIT_CIPH_SM_SC, false);
+  init_cipher_from(res, ciph, ciph->_scaling_factor, ciph->_sf_degree);
+}
 void Init_ciph_up_scale(CIPHER res, CIPHER c1, CIPHER c2) {
+  RtmScope rtm(RTM_INIT_CIPH_UP_SC, false);
   CIPHER c = lower_level(c1, c2);
   init_cipher_from(res, c, c1->_scaling_factor * c2->_scaling_factor, c1->_sf_degree + c2->_sf_degree);
 }
 void Init_ciph_up_scale_plain(CIPHER res, CIPHER ciph, PLAIN plain) {
+  RtmScope rtm(RTM_INIT_CIPH_UP_SC, false);
   init_cipher_from(res, ciph, ciph->_scaling_factor * plain->_scaling_factor, ciph->_sf_degree + plain->_sf_degree);
 }
 void Init_ciph_down_scale(CIPHER res, CIPHER ciph) {
+  RtmScope rtm(RTM_INIT_CIPH_DN_SC, false);
   init_cipher_from(res, ciph, ciph->_scaling_factor / ctx().sf, ciph->_sf_degree - 1);
 }
 static void init_from3(POLYNOMIAL* r0, POLYNOMIAL* r1, POLYNOMIAL* s0, POLYNOMIAL* s1) {
@@ -668,6 +687,7 @@ static void init_from3(POLYNOMIAL* r0, POLYNOMIAL* r1, POLYNOMIAL* s0, POLYNOMIA
   poly_init_like(r1, s1);
 }
 void Init_ciph_same_scale_ciph3(CIPHER res, CIPHER3 ciph) {
+  RtmScope rtm(RTM_INIT_CIPH_SM_SC, false);
   RT_ASSERT(res, "invalid ciphertext");
   res->_scaling_factor = ciph->_scaling_factor;
   res->_sf_degree = ciph->_sf_degree;
@@ -677,6 +697,7 @@ void Init_ciph_same_scale_ciph3(CIPHER res, CIPHER3 ciph) {
   set_level(res, ciph->_c0_poly._num_primes);
 }
 void Init_ciph3_same_scale_ciph3(CIPHER3 res, CIPHER3 c1, CIPHER3 c2) {
+  RtmScope rtm(RTM_INIT_CIPH_SM_SC, false);
   RT_ASSERT(res, "invalid ciphertext");
   CIPHER3 c = c1;
   if (c2 != nullptr && c1->_c0_poly._data != nullptr && c2->_c0_poly._num_primes < c1->_c0_poly._num_primes) c = c2;
@@ -693,6 +714,7 @@ void Init_ciph3_same_scale_ciph3(CIPHER3 res, CIPHER3 c1, CIPHER3 c2) {
   res->_c0_poly._num_primes = res->_c1_poly._num_primes = res->_c2_poly._num_primes = c->_c0_poly._num_primes;
 }
 void Init_ciph3_up_scale(CIPHER3 res, CIPHER c1, CIPHER c2) {
+  RtmScope rtm(RTM_INIT_CIPH_UP_SC, false);
   RT_ASSERT(res, "invalid ciphertext");
   CIPHER c = lower_level(c1, c2);
   res->_scaling_factor = c1->_scaling_factor * c2->_scaling_factor;
@@ -705,7 +727,8 @@ void Init_ciph3_up_scale(CIPHER3 res, CIPHER c1, CIPHER c2) {
   res->_c0_poly._is_ntt = res->_c1_poly._is_ntt = res->_c2_poly._is_ntt = true;
   res->_c0_poly._num_primes = res->_c1_poly._num_primes = res->_c2_poly._num_primes = c->_c0_poly._num_primes;
 }
-void Copy_ciph(CIPHER res, CIPHER ciph) {  // Copy_ciphertext ciphertext.h:247-253
+void Copy_ciph(CIPHER res, CIPHER ciph) {
+  RtmScope rtm(RTM_COPY_CIPH, false);  // Copy_ciphertext ciphertext.h:247-253
   if (res == ciph) return;
   res->_scaling_factor = ciph->_scaling_factor;
   res->_sf_degree = ciph->_sf_degree;

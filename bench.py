@@ -8,7 +8,7 @@ Headline workload (BASELINE.json metric, configs[3] = SURVEY 8d "C4"): encrypted
 ACE-compiled ResNet-20/CIFAR-10 program (the reference's checked-in generated source, N=2^16, L=34,
 dnum=3, 19 bootstraps) on a synthetic 3x32x32 image with synthetic weights.  A step = one image:
 encode+encrypt, Main_graph, decrypt+decode, through the rt_ant drop-in API (libFHErt_ant.so over the
-acehip C ABI).  The generated program is oracle/_ref/models/libmodel_resnet20.so (compiled unchanged from
+acehip C ABI).  The generated program is workloads/_gen/models/libmodel_resnet20.so (compiled unchanged from
 /root/reference by tools/build_models.py in the dev container; it travels with the snapshot).  If that
 library is absent the bench falls back to the largest configuration that needs no generated source:
 C3, the full key-switch at N=2^16, L=25, dnum=4 (and says so in config.workload).
@@ -43,7 +43,7 @@ N, L, Q0, SF, DNUM = 65536, 25, 60, 56, 4   # C2/C3 parameter set
 # (scripts/ace_pre.log:28) -- the same metric on the reference's own hardware
 BASELINE_IMAGES_PER_S = 1.0 / 1453.96
 N_CT = 16                                    # ciphertext pairs in the resident NTT batch
-MODEL_LIB = os.path.join(ROOT, "oracle", "_ref", "models", "libmodel_resnet20.so")
+MODEL_LIB = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet20.so")
 
 
 def cpu_topology():
@@ -371,7 +371,7 @@ def main():
             return None
 
         unit, metric = "key-switches/s", "full key-switch throughput (N=2^16, L=25, dnum=4)"
-        workload = ("C3 (BASELINE configs[2]) FALLBACK: oracle/_ref/models/libmodel_resnet20.so not present, so the headline ResNet-20 "
+        workload = ("C3 (BASELINE configs[2]) FALLBACK: workloads/_gen/models/libmodel_resnet20.so not present, so the headline ResNet-20 "
                     "workload cannot run; full key-switch N=2^16 L=25 dnum=4 K=7 on resident inputs")
 
     if use_model:

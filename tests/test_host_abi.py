@@ -104,3 +104,27 @@ def test_digit_size_limit():
     rt.close()
     with pytest.raises(Exception, match="64 limbs"):
         A.AceHip(16, 70, 40, 30, 1, host_only=True)      # alpha = 70
+
+
+def test_reference_link_line_with_archives(tmp_path):
+    """scripts/perf.py:202-207 links a generated program as `cc model.c -I<inc> -I<inc>/rt_ant <lib>/libFHErt_ant.a
+    <lib>/libFHErt_common.a -lgmp -lm`: the archive names must exist and that line must link unchanged (no GPU needed to
+    link; -lgmp is left out because the image has no libgmp.so development symlink and nothing here needs GMP)."""
+    import subprocess
+    import sys
+
+    import ace_compiler_amd  # noqa: F401
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    for f in (bmod.RT_ARCHIVE, bmod.RT_OBJS_ARCHIVE, bmod.RT_COMMON_ARCHIVE):
+        assert os.path.exists(f), f
+    members = subprocess.run(["ar", "t", bmod.RT_OBJS_ARCHIVE], capture_output=True, text=True, check=True).stdout.split()
+    assert "rt_rt_poly_cpp.o" in members and "ntt_fast_hip.o" in members and "api_cpp.o" in members
+    inc = os.path.join(ROOT, "include")
+    exe = str(tmp_path / "dropin_c1_static")
+    subprocess.check_call(["cc", os.path.join(ROOT, "tests", "c", "dropin_c1.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+                           bmod.RT_ARCHIVE, bmod.RT_COMMON_ARCHIVE, "-lm", "-o", exe])
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True, check=True).stdout
+    assert "libFHErt_ant.so" not in needed and "libacehip.so" not in needed   # the runtime is inside the executable
+    assert "libamdhip64" in needed

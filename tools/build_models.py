@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compile the reference's checked-in ACE-generated model sources (rtlib/ant/dataset/*.onnx.inc), unchanged
-and from where they lie under /root/reference, into oracle/_ref/models/libmodel_<name>.so against OUR headers
-(everything compiled from reference sources lives under oracle/_ref/, which is git-ignored).
+and from where they lie under /root/reference, into workloads/_gen/models/libmodel_<name>.so against OUR headers
+and OUR runtime (workloads/_gen/ is git-ignored; it holds generated callers only, no reference runtime code).
 These libraries are the benchmark workload (BASELINE.json configs[3]/[4]); they only exist where
 /root/reference exists (dev container) and travel to the GPU box with the snapshot.
 """
@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/fhe-cmplr/rtlib/ant/dataset"
-OUT = os.path.join(ROOT, "oracle", "_ref", "models")
+OUT = os.path.join(ROOT, "workloads", "_gen", "models")
 MODELS = {"resnet20": "resnet20_cifar10_pre.onnx.inc", "resnet110": "resnet110_cifar10_train.onnx.inc"}
 
 

@@ -7,7 +7,7 @@ TAG=${1:-pmcimg}
 IMAGES=${2:-1}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-EXE=$ROOT/oracle/_ref/examples/model_resnet20_cifar10_pre
+EXE=$ROOT/workloads/_gen/examples/model_resnet20_cifar10_pre
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp ACEHIP_RT_DATA_SYNTH=1
 for ctr in FETCH_SIZE WRITE_SIZE; do
