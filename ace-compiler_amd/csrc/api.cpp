@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -105,11 +106,12 @@ int acehip_device_count(void) {
 }
 
 acehip_ctx* acehip_ctx_create_host(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum) {
+  std::unique_ptr<acehip_ctx> ctx;
   try {
-    auto* ctx = new acehip_ctx();
+    ctx.reset(new acehip_ctx());
     ctx->hp = make_params(N, L, q0_bits, sf_bits, dnum);
-    return ctx;
-  } catch (const std::exception& e) {
+    return ctx.release();
+  } catch (const std::exception& e) {  // the half-built context is released (found by `make -C oracle asan`)
     g_err = e.what();
     return nullptr;
   }
