@@ -83,6 +83,20 @@ SYMBOLS = [
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_bsgs_inner", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    ("acehip_shard_create", _vp, [_vp, _u32, _u32]),
+    ("acehip_shard_destroy", None, [_vp]),
+    ("acehip_shard_num_q", _u32, [_vp, _u32]),
+    ("acehip_shard_num_p", _u32, [_vp]),
+    ("acehip_shard_pad_q", _u32, [_vp, _u32]),
+    ("acehip_shard_pad_p", _u32, [_vp]),
+    ("acehip_shard_owned", _u32, [_vp, _u32, _vp, _vp]),
+    ("acehip_shard_ks_phase1", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    ("acehip_shard_ks_phase2", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_shard_ks_phase3", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_shard_rescale_send", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_shard_rescale_apply", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_encode_message", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _vp]),
+    ("acehip_shard_encode_limbs", C.c_int, [_vp, _vp, _vp, C.c_double, _u32, _u32, _vp]),
 ]
 
 _lib = None

@@ -93,6 +93,10 @@ struct NttFuse {
   const u64* inv_scale = nullptr;
   // forward, last pass: v = NTT value; 1: out = x*w + v (Rescale tail polynomial.c:1145-1158),
   // 2: out = (x - v)*w (ModDown tail :956-965); x_z, out_z are polynomials of q-limbs, w/wp per limb
+  // limb-sharded execution: the launch covers n PACKED limbs (limb y at poly + y*N, z-th polynomial poly_stride further);
+  // limb y belongs to prime gi_tab[y] (device table).  level / pos0 / skip_alpha are ignored, per-limb tables of the
+  // fused neighbours (msg_scale, inv_scale, w, wp) are indexed by y.
+  const u32* gi_tab = nullptr;
   int epi = 0;
   u64* out0 = nullptr;
   u64* out1 = nullptr;
@@ -142,6 +146,25 @@ struct BsgsArgs {
   u32 g, b, pt_q_alloc;
 };
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s);
+// ---- limb-sharded execution (shard.hip): kernels over PACKED limb lists, limb y of prime gi[y] ----
+// Rescale spread on the owned limbs: t_z[y] = shoup(switch_modulus(last_z, q_last, q_gi[y]), c1[y])
+void launch_packed_rescale_spread(const DevCtx& c, u64* t, size_t t_stride, const u64* last, size_t last_stride, const u32* gi,
+                                  u32 gi_last, const u64* c1, const u64* c1p, u32 n_limbs, u32 n_polys, hipStream_t s);
+// out_z[y] = shoup(x_z[y], inv[y]) + t_z[y]
+void launch_packed_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
+                                const u32* gi, const u64* inv, const u64* invp, u32 n_limbs, u32 n_polys, hipStream_t s);
+// out_z[y] = shoup(x_z[y] - t_z[y], w[y])      (ModDown tail on the owned q-limbs)
+void launch_packed_moddown_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
+                                const u32* gi, const u64* w, const u64* wp, u32 n_limbs, u32 n_polys, hipStream_t s);
+// acc_z[y] = sum_d key[(d*2+z)*key_stride + y*N] * e_d[y],  e_d[y] = src[d*n_limbs + y] (device pointer table: the
+// digit's own limbs point into the input, the others into the raised digits)
+struct PackedPtrs {  // limb pointers as a kernel argument (2 KiB): no table upload, nothing to keep alive
+  const u64* p[256];
+};
+void launch_packed_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, size_t key_stride, const PackedPtrs& src,
+                           const u32* gi, u32 nd, u32 n_limbs, hipStream_t s);
+// dst[y] = src.p[y] (limb copies: assembling gathered limbs in position order)
+void launch_packed_gather(const DevCtx& c, u64* dst, const PackedPtrs& src, u32 n_limbs, hipStream_t s);
 // ModDown tail for two polynomials: out_z = shoup(x_z - t_z, pinv), z in {0,1}
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
                           const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys = 2);

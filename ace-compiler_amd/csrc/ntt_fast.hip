@@ -217,10 +217,16 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
                                                            u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[256 * kRowPitch];
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
-  u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+  u32 pos, gi;
+  if (f.gi_tab != nullptr) {  // packed limb list (limb-sharded execution)
+    pos = blk.y;
+    gi = f.gi_tab[pos];
+  } else {
+    if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+    gi = limb_prime(pos, level, c.L);
+  }
   pos = __builtin_amdgcn_readfirstlane(pos);  // wave-uniform: prime constants and base pointers live in SGPRs
-  const u32 gi = limb_prime(pos, level, c.L);
+  gi = __builtin_amdgcn_readfirstlane(gi);
   const DevPrime& P = c.primes[gi];
   const u64 q = P.q, q4 = 4 * q;
   u64* __restrict__ X = poly + blk.z * poly_stride + (size_t)(pos - pos_off) * c.N;
@@ -315,10 +321,16 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
                                                           u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[16 * kBlkPitch];
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
-  u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+  u32 pos, gi;
+  if (f.gi_tab != nullptr) {  // packed limb list (limb-sharded execution)
+    pos = blk.y;
+    gi = f.gi_tab[pos];
+  } else {
+    if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blk.y, blk.z)) return;
+    gi = limb_prime(pos, level, c.L);
+  }
   pos = __builtin_amdgcn_readfirstlane(pos);  // wave-uniform: prime constants and base pointers live in SGPRs
-  const u32 gi = limb_prime(pos, level, c.L);
+  gi = __builtin_amdgcn_readfirstlane(gi);
   const DevPrime& P = c.primes[gi];
   const u64 q = P.q, q4 = 4 * q;
   u64* __restrict__ X = poly + blk.z * poly_stride + (size_t)(pos - pos_off) * c.N + (size_t)blk.tile * 4096;

@@ -225,6 +225,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["auto", "resnet20", "keyswitch"], default="auto")
+    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
+                    help="replicas (default, the headline): independent images per GPU; shard: latency of ONE limb-sharded "
+                         "key-switch + rescale over the ranks (tools/shard_keyswitch_bench.py: acehip_shard_* phases + RCCL "
+                         "all-gathers), the building block of BASELINE configs[4]")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
@@ -232,6 +236,13 @@ def main():
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     args = ap.parse_args()
+
+    if args.mode == "shard":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import shard_keyswitch_bench
+
+        shard_keyswitch_bench.main(["--steps", str(max(args.steps, 20)), "--warmup", str(max(args.warmup, 3))])
+        return
 
     # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues two image
     # streams serialise behind each other (measured: 4 image streams + this thread's own = 0.99 images/s with 4 queues,

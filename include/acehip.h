@@ -241,6 +241,40 @@ int acehip_bsgs_inner(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* const*
                       const uint64_t* const* d_in1, const uint64_t* const* d_pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs,
                       uint32_t level, acehip_stream stream);
 
+/* ---- limb-sharded execution (BASELINE configs[4]: RNS limbs spread over the GPUs of a node) ----
+ * Rank r of `world` owns the limbs gi with gi % world == r (q_i: gi = i, p_j: gi = L + j) of every polynomial and
+ * switch key, PACKED in ascending gi; ownership does not depend on the level.  One hybrid key-switch
+ * (Decompose_modup polynomial.c:1241-1335 + Multiply_add :148-183 + Reduce_rns_base :928-967) is three local phases
+ * around two all-gathers that the CALLER performs (RCCL over xGMI on a node: torch.distributed all_gather_into_tensor of
+ * the send buffer, rank-major):
+ *   phase1: owned q-limbs -> coefficient domain                          send [pad_q][N]      gather [world][pad_q][N]
+ *   phase2: ModUp of every digit onto the owned limbs, NTT, key inner product, owned p-limbs of both accumulators ->
+ *           coefficient domain                                           send [2][pad_p][N]   gather [world][2][pad_p][N]
+ *   phase3: P -> owned q-limbs, NTT, (acc - conv) * P^-1                 out: owned q-limbs of both results, packed
+ * Rescale (Rescale_poly :1097-1163): the owner of limb level-1 sends its coefficient-domain limb of c0 and c1 ([2][N],
+ * broadcast by the caller), every rank applies it to its owned limbs.  Encode: the integer message (N words) is computed
+ * once and broadcast, or computed redundantly; each rank reduces and transforms its own limbs.
+ * Every call is a few batched launches on `stream` and never synchronises; results are bit-identical to the unsharded
+ * entry points.  d_key_own: [num_q_parts][2][n_own][N], the rank's limbs of a switch key in packed order (owned
+ * q-limbs of the full chain, then owned p-limbs). */
+typedef struct acehip_shard acehip_shard;
+acehip_shard* acehip_shard_create(acehip_ctx* ctx, uint32_t rank, uint32_t world);
+void     acehip_shard_destroy(acehip_shard* shard);
+uint32_t acehip_shard_num_q(const acehip_shard* shard, uint32_t level);  /* owned q-limbs below `level` */
+uint32_t acehip_shard_num_p(const acehip_shard* shard);
+uint32_t acehip_shard_pad_q(const acehip_shard* shard, uint32_t level);  /* most q-limbs any rank owns: slots per rank of exchange 1 */
+uint32_t acehip_shard_pad_p(const acehip_shard* shard);
+uint32_t acehip_shard_owned(const acehip_shard* shard, uint32_t level, uint32_t* q_idx_out, uint32_t* p_idx_out); /* returns num_q */
+int acehip_shard_ks_phase1(acehip_shard* shard, uint64_t* d_send, const uint64_t* d_x_own, uint32_t level, acehip_stream stream);
+int acehip_shard_ks_phase2(acehip_shard* shard, uint64_t* d_send2, const uint64_t* d_gathered, const uint64_t* d_x_own,
+                           const uint64_t* d_key_own, uint32_t level, acehip_stream stream);
+int acehip_shard_ks_phase3(acehip_shard* shard, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_gathered2, uint32_t level, acehip_stream stream);
+int acehip_shard_rescale_send(acehip_shard* shard, uint64_t* d_send, const uint64_t* d_c0_own, const uint64_t* d_c1_own, uint32_t level, acehip_stream stream); /* 1: this rank is the sender */
+int acehip_shard_rescale_apply(acehip_shard* shard, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_c0_own, const uint64_t* d_c1_own,
+                               const uint64_t* d_last, uint32_t level, acehip_stream stream);
+int acehip_encode_message(acehip_ctx* ctx, int64_t* d_msg, const void* d_vals, int kind, size_t len, uint32_t slots, double scaling_factor, acehip_stream stream);
+int acehip_shard_encode_limbs(acehip_shard* shard, uint64_t* d_q_own, const int64_t* d_msg, double scaling_factor, uint32_t sf_degree, uint32_t level, acehip_stream stream);
+
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
 

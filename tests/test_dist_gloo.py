@@ -62,39 +62,56 @@ def test_single_rank_defaults():
 SHARD_WORKER = textwrap.dedent("""
     import sys
     sys.path.insert(0, %r)
+    import ctypes as C
     import torch
     import torch.distributed as dist
-    import ace_compiler_amd
+    import ace_compiler_amd as A
     from ace_compiler_amd import shard
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    L, K, level, N = 7, 3, 5, 4
-    sh = shard.LimbShard(L, K, world, rank)
+    # the partition and the exchange layout come from the C library (a host-only context: no GPU needed)
+    rt = A.AceHip(8, 7, 60, 51, 3, host_only=True)
+    L, K, level, N = rt.L, rt.K, 5, 8
+    sh = rt.lib.acehip_shard_create(rt.h, rank, world)
+    assert sh
+    q = (C.c_uint32 * L)()
+    p = (C.c_uint32 * max(K, 1))()
+    nq = rt.lib.acehip_shard_owned(sh, level, q, p)
+    q_own, p_own = list(q[:nq]), list(p[:rt.lib.acehip_shard_num_p(sh)])
+    assert q_own == shard.owned_q(L, world, rank, level) and p_own == shard.owned_p(L, K, world, rank)
+    assert nq == rt.lib.acehip_shard_num_q(sh, level)
+    pad_q, pad_p = rt.lib.acehip_shard_pad_q(sh, level), rt.lib.acehip_shard_pad_p(sh)
     comm = shard.TorchComm(dist, "cpu")
-    # exchange 1: every rank contributes its owned q-limbs (filled with 100 + i), padded to the largest share
-    pad = sh.max_q(level)
-    local = torch.zeros((pad, N), dtype=torch.int64)
-    for k, i in enumerate(sh.q_owned(level)):
+    # exchange 1: every rank sends its owned q-limbs (filled with 100 + i) in pad_q slots; phase 2 of the library expects
+    # limb i in slot (i mod world) * pad_q + i // world of the rank-major gather
+    local = torch.zeros((pad_q, N), dtype=torch.int64)
+    for k, i in enumerate(q_own):
         local[k] = 100 + i
-    got = comm.all_gather_tensor(local)
-    slot = shard.gather_slots([sh.q_owned(level, r) for r in range(world)], pad)
-    full = torch.stack([got[slot[i]] for i in range(level)])
-    assert full[:, 0].tolist() == [100 + i for i in range(level)], full
-    # exchange 2: both accumulators' p-limbs, [comp][pad_p] per rank
-    pad_p = sh.max_p()
+    got = comm.all_gather(local)
+    assert got.shape[0] == world * pad_q
+    assert [int(got[(i %% world) * pad_q + i // world][0]) for i in range(level)] == [100 + i for i in range(level)]
+    # exchange 2: [2][pad_p] per rank; phase 3 expects p-limb j of accumulator z at ((r*2 + z) * pad_p + k), r = (L+j) %% world,
+    # k = its index among the p-limbs rank r owns
     local = torch.zeros((2 * pad_p, N), dtype=torch.int64)
-    for comp in range(2):
-        for k, j in enumerate(sh.p_owned()):
-            local[comp * pad_p + k] = 1000 * (comp + 1) + j
-    got = comm.all_gather_tensor(local)
-    pslot = shard.gather_slots([[(comp, j) for comp in range(2) for j in sh.p_owned(r) + [None] * (pad_p - len(sh.p_owned(r)))]
-                                for r in range(world)], 2 * pad_p)
-    for comp in range(2):
+    for z in range(2):
+        for k, j in enumerate(p_own):
+            local[z * pad_p + k] = 1000 * (z + 1) + j
+    got = comm.all_gather(local)
+    for z in range(2):
         for j in range(K):
-            assert int(got[pslot[(comp, j)]][0]) == 1000 * (comp + 1) + j
-    # every limb has exactly one owner
-    owners = [[r for r in range(world) if gi in (sh.q_owned(L, r) + [L + j for j in sh.p_owned(r)])] for gi in range(L + K)]
-    assert all(len(o) == 1 for o in owners), owners
+            r = (L + j) %% world
+            k = shard.owned_p(L, K, world, r).index(j)
+            assert int(got[(r * 2 + z) * pad_p + k][0]) == 1000 * (z + 1) + j
+    # rescale: the owner of the last limb broadcasts
+    t = torch.full((2, N), 7 if rank == shard.owner(level - 1, world) else 0, dtype=torch.int64)
+    comm.broadcast(t, shard.owner(level - 1, world))
+    assert int(t[0][0]) == 7
+    # every limb has exactly one owner; phases fail cleanly without a GPU
+    owners = [sum(1 for r in range(world) if gi %% world == r) for gi in range(L + K)]
+    assert all(n == 1 for n in owners)
+    assert rt.lib.acehip_shard_ks_phase1(sh, 8, 8, level, None) < 0
+    rt.lib.acehip_shard_destroy(sh)
+    rt.close()
     dist.barrier()
     dist.destroy_process_group()
     import os
@@ -103,8 +120,9 @@ SHARD_WORKER = textwrap.dedent("""
 
 
 def test_limb_shard_exchange_layout_two_ranks_gloo(tmp_path):
-    """the two all-gathers of the limb-sharded key-switch (ace-compiler_amd/shard.py) on CPU tensors: padded rank-major
-    gather + slot map must reassemble the limbs in position order on every rank"""
+    """the exchanges of limb-sharded execution on CPU tensors with two gloo ranks: ownership lists and pad sizes from the C
+    library (acehip_shard_* on a host-only context), padded rank-major all-gathers and the slot arithmetic phases 2 and 3
+    use to reassemble the limbs, broadcast from the owner of the last limb for the rescale"""
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER % ROOT)
     with socket.socket() as s:

@@ -1,6 +1,8 @@
-"""Limb-sharded key-switch (ace-compiler_amd/shard.py): G simulated ranks on one GPU, limb gi on rank gi % G,
-two all-gathers per key-switch.  Assembling the ranks' owned output limbs must reproduce the unsharded key-switch of
-the oracle bit for bit, for every world size including ones that leave some ranks without p-limbs or q-limbs."""
+"""Limb-sharded execution (BASELINE configs[4]) through the C-ABI phases acehip_shard_* (csrc/api.cpp, shard.hip):
+`world` simulated ranks on one GPU, limb gi on rank gi % world, exchanges replaced by device copies
+(ace-compiler_amd/shard.py LocalWorld).  Assembling the ranks' owned output limbs must reproduce the unsharded oracle
+results bit for bit -- key-switch (two all-gathers), rescale (broadcast of the last limb) and encode (broadcast message)
+-- for every world size including ones that leave ranks without p-limbs or q-limbs."""
 import numpy as np
 import pytest
 
@@ -8,25 +10,95 @@ import _oracle as O
 
 pytestmark = pytest.mark.gpu
 
+CFGS = [(64, 7, 60, 51, 3, [7, 4]), (4096, 6, 60, 50, 3, [6, 5, 2]), (65536, 5, 60, 56, 2, [5, 3])]
 
-@pytest.mark.parametrize("cfg", [(64, 7, 60, 51, 3, [7, 4]), (4096, 6, 60, 50, 3, [6, 5, 2]), (65536, 5, 60, 56, 2, [5, 3])],
-                         ids=["n64", "n4096", "n65536"])
+
+@pytest.mark.parametrize("cfg", CFGS, ids=["n64", "n4096", "n65536"])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_sharded_key_switch_matches_oracle(cfg, world):
+def test_sharded_key_switch_rescale_encode_match_oracle(cfg, world):
     import ace_compiler_amd as A
     from ace_compiler_amd import shard
 
     N, L, q0, sf, dnum, levels = cfg
     o = O.Oracle(N, L, q0, sf, dnum)
     rt = A.AceHip(N, L, q0, sf, dnum, device=0)
+    lw = shard.LocalWorld(rt, world)
     try:
-        key = o.make_key(3000)
+        key = np.ascontiguousarray(o.make_key(3000)).reshape(o.dnum, 2, L + o.K, N)
+        key_own = [rt.to_device(shard.pack_key(key, L, o.K, world, r)) for r in range(world)]
         for level in levels:
+            # key-switch
             x = o.uniform(level, level, 81 + level)
             e0, e1 = o.key_switch(x, key, level)
-            g0, g1 = shard.run_local(rt, world, level, x, np.ascontiguousarray(key).reshape(o.dnum, 2, L + o.K, N))
-            assert np.array_equal(g0, e0) and np.array_equal(g1, e1), (world, level)
+            x_own = lw.split(x, level)
+            out0 = [rt.buf(max(s.num_q(level), 1) * N) for s in lw.shards]
+            out1 = [rt.buf(max(s.num_q(level), 1) * N) for s in lw.shards]
+            lw.key_switch(x_own, key_own, out0, out1, level)
+            rt.sync()
+            assert np.array_equal(lw.join(out0, level), e0) and np.array_equal(lw.join(out1, level), e1), (world, level)
+            assert np.array_equal(lw.join(x_own, level), x)  # inputs intact
+            # rescale of the pair (x, y)
+            if level > 1:
+                y = o.uniform(level, level, 181 + level)
+                y_own = lw.split(y, level)
+                lw.rescale(x_own, y_own, out0, out1, level)
+                rt.sync()
+                assert np.array_equal(lw.join(out0, level - 1), o.rescale(x, level)), (world, level)
+                assert np.array_equal(lw.join(out1, level - 1), o.rescale(y, level)), (world, level)
+                for b in y_own:
+                    b.free()
+            for b in x_own + out0 + out1:
+                b.free()
+        # encode: one integer message, every rank reduces and transforms its own limbs (scale degree 1 and 2)
+        level = levels[0]
+        slots = N // 2
+        msg = (np.cos(0.37 * np.arange(slots)) * 0.5).astype(np.float64)
+        d_vals, d_msg = rt.to_device(msg.view(np.uint64)), rt.buf(N)
+        rt.check(rt.lib.acehip_encode_message(rt.h, d_msg.ptr, d_vals.ptr, 1, slots, slots, float(2 ** sf), None))
+        for deg in (1, 2):
+            exp, _ = o.encode(msg.astype(np.complex128), level, sf_degree=deg)
+            outs = [rt.buf(max(s.num_q(level), 1) * N) for s in lw.shards]
+            for s, ob in zip(lw.shards, outs):
+                rt.check(rt.lib.acehip_shard_encode_limbs(s.h, ob.ptr, d_msg.ptr, float(2 ** sf), deg, level, None))
+            rt.sync()
+            assert np.array_equal(lw.join(outs, level), exp), (world, deg)
+            for b in outs:
+                b.free()
+        for b in key_own + [d_vals, d_msg]:
+            b.free()
     finally:
+        lw.close()
+        rt.close()
+        o.close()
+
+
+def test_sharded_key_switch_c3_is_batched():
+    """BASELINE configs[2] size (N = 2^16, L = 25, dnum = 4) on ONE rank: the C++ path is a handful of batched launches per
+    phase -- under 1 ms per key-switch (the Python-driven per-limb schedule of round 1 took 6.7 ms; the fused single-GPU
+    acehip_key_switch 0.28 ms) -- and still bit-exact."""
+    import ace_compiler_amd as A
+    from ace_compiler_amd import shard
+
+    N, L, q0, sf, dnum = 65536, 25, 60, 56, 4
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum, device=0)
+    lw = shard.LocalWorld(rt, 1)
+    try:
+        key = np.ascontiguousarray(o.make_key(5000)).reshape(o.dnum, 2, L + o.K, N)
+        x = o.uniform(L, L, 7)
+        e0, e1 = o.key_switch(x, key, L)
+        key_own, x_own = [rt.to_device(key)], lw.split(x, L)
+        out0, out1 = [rt.buf(L * N)], [rt.buf(L * N)]
+        lw.key_switch(x_own, key_own, out0, out1, L)
+        rt.sync()
+        assert np.array_equal(out0[0].download((L, N)), e0) and np.array_equal(out1[0].download((L, N)), e1)
+        ms = rt.time_ms(lambda: lw.key_switch(x_own, key_own, out0, out1, L), 20)
+        print("sharded key-switch, 1 rank, C3: %.3f ms" % ms)
+        assert ms < 1.0, ms
+        for b in key_own + x_own + out0 + out1:
+            b.free()
+    finally:
+        lw.close()
         rt.close()
         o.close()
 
@@ -50,15 +122,21 @@ from ace_compiler_amd import shard
 N, L, q0, sf, dnum, level = 4096, 6, 60, 50, 3, 5
 o = O.Oracle(N, L, q0, sf, dnum)
 rt = A.AceHip(N, L, q0, sf, dnum, device=0)
-key = np.ascontiguousarray(o.make_key(4000))
-x = o.uniform(level, level, 91)
+key = np.ascontiguousarray(o.make_key(4000)).reshape(o.dnum, 2, L + o.K, N)
+x, y = o.uniform(level, level, 91), o.uniform(level, level, 92)
 e0, e1 = o.key_switch(x, key, level)
-d_key, d_x = rt.to_device(key), rt.to_device(x)
-T = L + o.K
-ks = shard.ShardedKeySwitch(rt, 0, 1)
+d_key, d_x, d_y = rt.to_device(key), rt.to_device(x), rt.to_device(y)
+o0, o1 = rt.buf(level * N), rt.buf(level * N)
 comm = shard.TorchComm(dist, torch.device("cuda", 0))
-o0, o1 = shard.run_rank(ks, ks.run(level, d_x, lambda d, comp, gi: d_key.at(((d * 2 + comp) * T + gi) * N)), comm)
+rr = shard.RankRunner(rt, comm, 0)
+keep = rr.key_switch(d_x.ptr, d_key.ptr, o0.ptr, o1.ptr, level)
+torch.cuda.synchronize()
 assert np.array_equal(o0.download((level, N)), e0) and np.array_equal(o1.download((level, N)), e1)
+rr.rescale(d_x.ptr, d_y.ptr, o0.ptr, o1.ptr, level)
+torch.cuda.synchronize()
+assert np.array_equal(o0.download((level, N))[:level - 1], o.rescale(x, level))
+assert np.array_equal(o1.download((level, N))[:level - 1], o.rescale(y, level))
+rr.close()
 rt.close()
 dist.destroy_process_group()
 print("nccl shard ok")
@@ -66,11 +144,11 @@ print("nccl shard ok")
 
 
 def test_torch_communicator_single_rank_nccl(tmp_path):
-    """the torch.distributed driver (shard.run_rank + TorchComm, backend "nccl" = RCCL) with world size 1 on this box, in a
+    """the torch.distributed driver (shard.RankRunner + TorchComm, backend "nccl" = RCCL) with world size 1 on this box, in a
     process of its own (torch initialises its HIP runtime first, as in bench.py): exchange buffers are torch tensors whose
-    device addresses go through the C ABI; result = the oracle's key-switch.  World sizes > 1 need more GPUs than a test
-    box has; the partition / gather layout for them is covered by the simulated ranks above and by the gloo test of
-    tests/test_dist_gloo.py."""
+    device addresses go through the C ABI, launches and collectives share torch's stream; results = the oracle's.  World
+    sizes > 1 need more GPUs than a test box has; the partition / gather layout for them is covered by the simulated ranks
+    above and by the gloo test of tests/test_dist_gloo.py."""
     import subprocess
     import sys
 
