@@ -3,6 +3,7 @@
 // Reference: common/src/{tensor.c,io_lib.c,rt_stat.c,pt_mgr.c:182-191,rt_data_file.c},
 // ant/src/rtlib/rtlib.c:20-87, include/fhe/core/rt_data_def.h:90-109.
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 
@@ -78,8 +79,26 @@ struct PtMgr {
   std::vector<char> buf;  // all messages (file bytes [4096, lut_ofst))
   char* dbuf = nullptr;   // the same bytes resident in HBM: Pt_from_msg encodes straight from here
   std::map<uint32_t, std::pair<float*, size_t>> synth_dev;  // synthetic mode: device copy per entry
+  std::vector<float*> synth_old;                             // replaced (shorter) copies, kept until Pt_mgr_fini
   bool open = false;
+  // DE_PLAINTEXT files (pre-encoded weights, pt_mgr.c:63-159): entries are PLAINTEXT_BUFFERs (rt_encode_api.h:22-27).
+  // The reference recycles PT_ENTRY_COUNT host slots and prefetches with io_uring; here every entry is read once, on first
+  // use, into an HBM block of its own (288 GB hold any model's plaintexts: ResNet-20 is 12.3 GB) and stays there.
+  int fd = -1;
+  bool plaintext = false;
+  struct PtEntry {
+    PLAINTEXT shell;       // as stored in the file, _data -> HBM
+    rt::u64* data = nullptr;
+  };
+  std::map<uint32_t, PtEntry> pt_dev;
 };
+// PLAINTEXT_BUFFER rt_encode_api.h:22-27 and RT_VERSION_FULL rt_version.h:15-24
+struct PlainBufferHdr {
+  char _magic[8];
+  uint32_t _version;
+  uint32_t _size;
+};
+constexpr uint32_t kRtVersionFull = 0x00000001;
 PtMgr g_pt;  // one weight file per process: read and uploaded once, shared by every thread (shared_mu guards the lazily filled maps)
 
 }  // namespace
@@ -225,9 +244,22 @@ bool Pt_mgr_init(const char* fname) {
     const size_t lut_bytes = sizeof(DataLutEntry) * g_pt.lut.size();
     ok = pread(fd, g_pt.lut.data(), lut_bytes, g_pt.hdr._lut_ofst) == (ssize_t)lut_bytes;
   }
+  if (ok) {  // the header is untrusted input: offsets must lie inside the file, in order
+    struct stat st;
+    ok = fstat(fd, &st) == 0 && g_pt.hdr._lut_ofst >= 4096 && g_pt.hdr._lut_ofst <= (uint64_t)st.st_size &&
+         g_pt.hdr._ent_count <= ((uint64_t)st.st_size - g_pt.hdr._lut_ofst) / sizeof(DataLutEntry);
+    for (size_t i = 0; ok && i < g_pt.lut.size(); ++i)
+      ok = g_pt.lut[i]._ent_ofst >= 4096 && g_pt.lut[i]._ent_ofst <= g_pt.hdr._lut_ofst &&
+           g_pt.lut[i]._size <= g_pt.hdr._lut_ofst - g_pt.lut[i]._ent_ofst;
+    RT_ASSERT(ok, "weight data file %s: header or lookup table points outside the file", fname);
+  }
+  if (ok && g_pt.hdr._ent_type == DE_PLAINTEXT) {
+    g_pt.plaintext = true;
+    g_pt.fd = fd;  // entries are read on first use (Pt_get)
+    g_pt.open = true;
+    return true;
+  }
   if (ok) {
-    RT_ASSERT(g_pt.hdr._ent_type != DE_PLAINTEXT,
-              "DE_PLAINTEXT data files are not supported yet by the HIP provider (use DE_MSG_F32)");
     const size_t sz = g_pt.hdr._lut_ofst - 4096;
     g_pt.buf.resize(sz);
     ok = pread(fd, g_pt.buf.data(), sz, 4096) == (ssize_t)sz;
@@ -248,14 +280,67 @@ void Pt_mgr_fini() {
   g_pt.dbuf = nullptr;
   for (auto& kv : g_pt.synth_dev) acehip_free(kv.second.first);
   g_pt.synth_dev.clear();
+  for (float* p : g_pt.synth_old) acehip_free(p);
+  g_pt.synth_old.clear();
+  for (auto& kv : g_pt.pt_dev) acehip_free(kv.second.data);
+  g_pt.pt_dev.clear();
+  if (g_pt.fd >= 0) close(g_pt.fd);
+  g_pt.fd = -1;
+  g_pt.plaintext = false;
   g_pt.buf.clear();
   g_pt.lut.clear();
   g_pt.open = false;
 }
-void Pt_prefetch(uint32_t) {}
-void* Pt_get(uint32_t, size_t, uint32_t, uint32_t) {
-  RT_ASSERT(false, "Pt_get: DE_PLAINTEXT data files are not supported yet");
-  return nullptr;
+// entry -> HBM, once (Cast_buffer_to_plain plain_eval.c:132-158 checks included)
+static PtMgr::PtEntry& pt_load(uint32_t index) {
+  std::lock_guard<std::recursive_mutex> lk(rt::shared_mu());
+  auto it = g_pt.pt_dev.find(index);
+  if (it != g_pt.pt_dev.end()) return it->second;
+  rt::Context& c = rt::ctx();
+  RT_ASSERT(g_pt.open && g_pt.plaintext, "bad entry type: the weight data file does not hold plaintexts");
+  RT_ASSERT(index < g_pt.lut.size(), "index out of entry range");
+  const DataLutEntry& e = g_pt.lut[index];
+  PlainBufferHdr pb;
+  PtMgr::PtEntry ent;
+  RT_ASSERT(e._size >= sizeof(pb) + sizeof(PLAINTEXT), "Plaintext buffer too small");
+  RT_ASSERT(pread(g_pt.fd, &pb, sizeof(pb), e._ent_ofst) == (ssize_t)sizeof(pb), "cannot read plaintext entry %u", index);
+  RT_ASSERT(memcmp(pb._magic, "ANTPLAIN", 8) == 0, "Plaintext buffer magic mismatch");
+  RT_ASSERT(pb._version == kRtVersionFull, "Plaintext buffer version mismatch");
+  RT_ASSERT((uint64_t)pb._size + sizeof(pb) <= e._size, "Plaintext buffer too small");
+  RT_ASSERT(pread(g_pt.fd, &ent.shell, sizeof(PLAINTEXT), e._ent_ofst + sizeof(pb)) == (ssize_t)sizeof(PLAINTEXT), "cannot read plaintext entry %u", index);
+  POLYNOMIAL& poly = ent.shell._poly;
+  RT_ASSERT(poly._data == nullptr, "Plaintext poly data is not NULL");
+  RT_ASSERT(poly._ring_degree == c.N && poly._num_alloc_primes <= c.L && poly._num_primes <= poly._num_alloc_primes && poly._num_primes_p == 0,
+            "plaintext entry %u does not fit the context (degree %u, %zu limbs)", index, poly._ring_degree, poly._num_alloc_primes);
+  const size_t words = poly._num_alloc_primes * (size_t)c.N;
+  RT_ASSERT(pb._size == words * 8 + sizeof(PLAINTEXT), "Plaintext size mismatch");
+  ent.data = (rt::u64*)acehip_malloc(words * 8);
+  RT_ASSERT(ent.data, "plaintext upload: %s", acehip_last_error());
+  std::vector<char> chunk(std::min<size_t>(words * 8, 8u << 20));
+  const uint64_t data_ofst = e._ent_ofst + sizeof(pb) + sizeof(PLAINTEXT);
+  for (size_t off = 0; off < words * 8; off += chunk.size()) {
+    const size_t n = std::min(chunk.size(), words * 8 - off);
+    RT_ASSERT(pread(g_pt.fd, chunk.data(), n, data_ofst + off) == (ssize_t)n, "cannot read plaintext entry %u", index);
+    HIPCHK(acehip_memcpy_h2d((char*)ent.data + off, chunk.data(), n, nullptr));  // pageable source: the copy is complete on return
+  }
+  rt::sync();  // complete before another thread's stream may read it
+  poly._data = (int64_t*)ent.data;
+  c.weight_plain_cnt++;
+  c.weight_plain_bytes += words * 8;
+  return g_pt.pt_dev[index] = ent;
+}
+void Pt_prefetch(uint32_t pt_idx) {
+  if (g_pt.open && g_pt.plaintext && pt_idx < g_pt.lut.size()) pt_load(pt_idx);
+}
+// pt_mgr.c:128-159: a PLAINTEXT whose coefficients the caller only reads (Coeffs(&pt->_poly, ...) in Hw_modmul loops), valid
+// until Pt_free(pt_idx); here it stays valid until Pt_mgr_fini.  len / scale / level describe what the compiler stored.
+void* Pt_get(uint32_t pt_idx, size_t, uint32_t scale, uint32_t level) {
+  rt::RtmScope rtm(rt::RTM_PT_GET, false);
+  PtMgr::PtEntry& e = pt_load(pt_idx);
+  RT_ASSERT(level == 0 || e.shell._poly._num_primes == level, "plaintext entry %u is stored at level %zu, asked for %u", pt_idx,
+            e.shell._poly._num_primes, level);
+  RT_ASSERT(scale == 0 || e.shell._sf_degree == scale, "plaintext entry %u has scale degree %u, asked for %u", pt_idx, e.shell._sf_degree, scale);
+  return &e.shell;
 }
 void* Pt_get_validate(float*, uint32_t, size_t, uint32_t, uint32_t) {
   RT_ASSERT(false, "TODO: not implemented");
@@ -264,6 +349,7 @@ void* Pt_get_validate(float*, uint32_t, size_t, uint32_t, uint32_t) {
 void Pt_free(uint32_t) {}
 static float* pt_entry(uint32_t index, size_t len) {
   RT_ASSERT(g_pt.open, "weight data file is not open");
+  RT_ASSERT(!g_pt.plaintext, "bad entry type: the weight data file holds plaintexts (use Pt_get)");
   if (g_pt_synth) {
     static FILE* trace = getenv("ACEHIP_PT_TRACE") ? fopen(getenv("ACEHIP_PT_TRACE"), "w") : nullptr;
     if (trace) fprintf(trace, "%u %zu\n", index, len);
@@ -271,8 +357,8 @@ static float* pt_entry(uint32_t index, size_t len) {
   }
   RT_ASSERT(index < g_pt.lut.size(), "index out of entry range");
   RT_ASSERT(g_pt.lut[index]._size >= len * sizeof(float), "entry size too small");
-  const uint64_t ofst = g_pt.lut[index]._ent_ofst - 4096;
-  RT_ASSERT(ofst + len * sizeof(float) <= g_pt.buf.size(), "entry offset too large");
+  const uint64_t ofst = g_pt.lut[index]._ent_ofst - 4096;  // >= 0: checked when the file was opened
+  RT_ASSERT(ofst <= g_pt.buf.size() && len <= (g_pt.buf.size() - ofst) / sizeof(float), "entry offset too large");
   return (float*)&g_pt.buf[ofst];
 }
 // device address of the entry (weights stay resident in HBM; no host copy per encode)
@@ -282,7 +368,7 @@ static const float* pt_entry_dev(uint32_t index, size_t len) {
   std::lock_guard<std::recursive_mutex> lk(rt::shared_mu());
   auto it = g_pt.synth_dev.find(index);
   if (it != g_pt.synth_dev.end() && it->second.second >= len) return it->second.first;
-  if (it != g_pt.synth_dev.end()) acehip_free(it->second.first);
+  if (it != g_pt.synth_dev.end()) g_pt.synth_old.push_back(it->second.first);  // another image stream may still read it: freed at Pt_mgr_fini
   float* d = (float*)acehip_malloc(len * sizeof(float));
   RT_ASSERT(d, "weight upload: %s", acehip_last_error());
   HIPCHK(acehip_memcpy_h2d(d, host, len * sizeof(float), nullptr));

@@ -57,3 +57,5 @@ for s in "${ENC[@]}"; do
   $D encode $2 $3 $4 $5 $6 $7 $8 > $G/ref_encode_$1.json
 done
 ls -la $G
+# pre-encoded plaintext data file (DE_PLAINTEXT; entries made by the reference's Encode_plain_buffer): Pt_get fixture
+$D ptfile 64 5 60 50 2 3 $G/ref_ptfile_n64_l5_lv3.bin 3 1 77

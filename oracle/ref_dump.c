@@ -9,6 +9,9 @@
  *   ref_dump ops    N L q0 sf dnum level seed -> per-op input/output vectors (full if N<=64,
  *                                                checksums otherwise)
  *   ref_dump bench  N L q0 sf dnum level ks_reps ntt_reps -> timings of the reference ops (JSON)
+ *   ref_dump ptfile N L q0 sf dnum level out n_entries sc_degree seed -> a DE_PLAINTEXT data file ("!ANTFHE" container of
+ *                   rt_data_def.h:90-111 whose entries are PLAINTEXT_BUFFERs made by the reference's Encode_plain_buffer,
+ *                   plain_eval.c:107-130): the fixture of the pre-encoded weight path (Pt_get, pt_mgr.c:128-159)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -428,6 +431,60 @@ static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, siz
   return 0;
 }
 
+/* DE_PLAINTEXT data file written the way the compiler's RT_DATA_WRITER lays it out: header page, entries aligned to
+ * 4096 bytes, lookup table at the end.  Entry e holds the message m[i] = ((splitmix64(seed + e, i) % 2001) - 1000) / 1024
+ * (N/2 floats, exactly representable) encoded at `level` with scale degree sc_degree by the reference. */
+#include "fhe/core/rt_data_def.h"
+#include "fhe/core/rt_encode_api.h"
+#include "fhe/core/rt_version.h"
+#include "rtlib/context.h"
+static int do_ptfile(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, const char* out, int n_entries,
+                     uint32_t sc_degree, u64 seed) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CKKS_CONTEXT*   ctxt = (CKKS_CONTEXT*)calloc(1, sizeof(CKKS_CONTEXT));
+  ctxt->_params = (PTR_TY)p;
+  ctxt->_encoder = (PTR_TY)Alloc_ckks_encoder(p);
+  Context = ctxt;
+  FILE* f = fopen(out, "wb");
+  if (!f) { perror(out); return 3; }
+  struct DATA_FILE_HDR hdr;
+  memset(&hdr, 0, sizeof(hdr));
+  memcpy(hdr._magic, DATA_FILE_MAGIC, 8);
+  hdr._rt_ver = RT_VERSION_FULL;
+  hdr._ent_type = DE_PLAINTEXT;
+  hdr._ent_align = 12;
+  hdr._ent_count = n_entries;
+  char page[DATA_FILE_PAGE_SIZE];
+  memset(page, 0, sizeof(page));
+  fwrite(page, 1, sizeof(page), f); /* header page, rewritten at the end */
+  struct DATA_LUT_ENTRY* lut = calloc(n_entries, sizeof(struct DATA_LUT_ENTRY));
+  size_t len = N / 2;
+  float* msg = malloc(sizeof(float) * len);
+  uint64_t ofst = DATA_FILE_PAGE_SIZE;
+  for (int e = 0; e < n_entries; e++) {
+    for (size_t i = 0; i < len; i++) msg[i] = (float)((double)((int64_t)(splitmix64(seed + e, i) % 2001) - 1000) / 1024.0);
+    struct PLAINTEXT_BUFFER* pb = Encode_plain_buffer(msg, len, sc_degree, (uint32_t)level);
+    uint64_t sz = Plain_buffer_length(pb);
+    snprintf(lut[e]._name, sizeof(lut[e]._name), "pt_%d", e);
+    lut[e]._index = e;
+    lut[e]._size = (uint32_t)sz;
+    lut[e]._ent_ofst = ofst;
+    fwrite(pb, 1, sz, f);
+    uint64_t padded = (sz + DATA_FILE_PAGE_SIZE - 1) & ~(uint64_t)(DATA_FILE_PAGE_SIZE - 1);
+    fwrite(page, 1, padded - sz, f);
+    ofst += padded;
+    Free_plain_buffer(pb);
+  }
+  hdr._lut_ofst = ofst;
+  fwrite(lut, sizeof(struct DATA_LUT_ENTRY), n_entries, f);
+  fseek(f, 0, SEEK_SET);
+  fwrite(&hdr, sizeof(hdr), 1, f);
+  fclose(f);
+  printf("{\"entries\": %d, \"level\": %zu, \"sc_degree\": %u, \"entry_bytes\": %u, \"lut_ofst\": %llu}\n", n_entries, level, sc_degree,
+         lut[0]._size, (u64)hdr._lut_ofst);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 7) {
     fprintf(stderr, "usage: %s params|ops|bench N L q0 sf dnum [level seed|reps]\n", argv[0]);
@@ -438,6 +495,8 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[1], "params")) return do_params(N, L, q0, sf, dnum);
   if (!strcmp(argv[1], "ops")) return do_ops(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
   if (!strcmp(argv[1], "encode")) return do_encode(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
+  if (!strcmp(argv[1], "ptfile") && argc >= 12)
+    return do_ptfile(N, L, q0, sf, dnum, atoi(argv[7]), argv[8], atoi(argv[9]), (uint32_t)atoi(argv[10]), strtoull(argv[11], 0, 10));
   if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1, argc > 9 ? atoi(argv[9]) : 20);
   return 2;
 }

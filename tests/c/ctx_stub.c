@@ -32,7 +32,17 @@ DATA_SCHEME* Get_decode_scheme(int idx) {
   static DATA_SCHEME scheme = {"output", {0, 0, 0, 0}, 1, {NORMAL, 0, 0, 0, 0}};
   return &scheme;
 }
-RT_DATA_INFO* Get_rt_data_info() { return NULL; }
+/* weight data file (DE_MSG_F32 or DE_PLAINTEXT): set before Prepare_context, which then opens it (context.c:81-84) */
+static RT_DATA_INFO Data_info;
+static char         Data_file[1024];
+void Stub_set_data_file(const char* path, int entry_type) {
+  if (path == NULL) { Data_info._file_name = NULL; return; }
+  strncpy(Data_file, path, sizeof(Data_file) - 1);
+  Data_info._file_name = Data_file;
+  Data_info._file_uuid = "test";
+  Data_info._entry_type = (DATA_ENTRY_TYPE)entry_type;
+}
+RT_DATA_INFO* Get_rt_data_info() { return Data_info._file_name ? &Data_info : NULL; }
 int  Get_output_count() { return 1; }
 int  Get_input_count() { return 1; }
 bool Main_graph() { return true; }

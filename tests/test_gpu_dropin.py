@@ -153,3 +153,28 @@ def test_static_archive_program_and_timing_table(tmp_path):
     assert items["BOOTSTRAP"][0][:2] == (1, "1") and items["BS_EVAL"][0][0] == 2 and items["BS_APPROX_MOD"][0][0] == 3
     assert ("sub total" in [e[1] for e in items["MAIN_GRAPH"]])          # what perf.py looks for to end the table
     assert items["BS_EVAL"][0][2] <= items["BOOTSTRAP"][0][2] * 1.05      # nested time is part of its parent's
+
+
+def test_resnet110_workload_runs_on_one_gpu():
+    """BASELINE configs[4]'s workload (the UNCHANGED ACE-generated ResNet-110 source, resnet110_cifar10_train.onnx.inc: N = 2^16,
+    Delta = 2^48, 109 bootstraps) on ONE GPU with synthetic weights: the 8-GPU limb-sharded run cannot be made on a test box,
+    but the program itself must execute and its bookkeeping must be the reference's -- 227 rotation keys, one weight plaintext
+    per Pt_from_msg call site (36 464, tests/golden/resnet110_pt_entries.txt), ten finite logits.  (Synthetic N(0, 0.05)
+    weights drive a 110-layer network out of its numeric range on the reference's CPU run too: the values are not compared.)"""
+    import math
+    import re
+
+    exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
+    if not os.path.exists(exe):
+        pytest.skip("workloads/_gen/examples/model_* not built (needs /root/reference: make -C workloads models)")
+    env = dict(os.environ, ACEHIP_RT_DATA_SYNTH="1")
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "_poly_degree = 65536" in r.stdout and "_scaling_mod_size = 48" in r.stdout and "_num_rot_idx = 197" in r.stdout
+    assert "rot_key_cnt = 227," in r.stdout
+    n_entries = sum(1 for _ in open(os.path.join(ROOT, "tests", "golden", "resnet110_pt_entries.txt")))
+    assert "Total memory size for weight plain: cnt = %d," % n_entries in r.stdout
+    m = re.search(r"logits:((?: -?\d+\.\d+)+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    vals = [float(x) for x in m.group(1).split()]
+    assert len(vals) == 10 and all(math.isfinite(v) for v in vals)

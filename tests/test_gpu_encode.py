@@ -189,3 +189,96 @@ def test_two_host_threads_own_independent_contexts(stub):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+# ---- pre-encoded weight files (DE_PLAINTEXT): Pt_get / Pt_prefetch / Pt_free (pt_mgr.c:63-159) ----
+def _ptfile_message(e, n, seed):
+    """the message ref_dump.c `ptfile` encodes into entry e: ((splitmix64(seed + e, i) % 2001) - 1000) / 1024"""
+    return ((O.splitmix64(seed + e, np.arange(n, dtype=np.uint64)) % np.uint64(2001)).astype(np.int64) - 1000).astype(np.float32) / np.float32(1024.0)
+
+
+PT_FILES = [("ref_ptfile_n64_l5_lv3.bin", 64, 5, 60, 50, 2, 3, 3, 1, 77, None),
+            (None, 65536, 5, 51, 50, 2, 4, 2, 1, 78, "65536 5 51 50 2 4 %s 2 1 78"),     # generated on the box when oracle/_ref is there
+            (None, 4096, 6, 60, 50, 3, 6, 3, 2, 79, "4096 6 60 50 3 6 %s 3 2 79")]
+
+
+@pytest.mark.parametrize("cfg", PT_FILES, ids=["n64_committed", "n65536", "n4096_deg2"])
+def test_pt_get_serves_reference_plaintext_file(stub, cfg, tmp_path):
+    """A DE_PLAINTEXT data file written with the reference's own Encode_plain_buffer (oracle/ref_dump.c `ptfile`): Pt_get must
+    hand out exactly the stored residues (resident in HBM), which in turn equal what our device encode makes of the same
+    message -- the pre-encoded and the encode-on-the-fly weight paths are interchangeable bit for bit."""
+    fname, N, L, q0, sf, dnum, level, n_ent, deg, seed, gen = cfg
+    if fname:
+        path = os.path.join(GOLDEN, fname)
+    else:
+        ref = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+        if not os.path.exists(ref):
+            pytest.skip("oracle/_ref/ref_dump not built (needs /root/reference)")
+        path = str(tmp_path / "pt.bin")
+        subprocess.check_call([ref, "ptfile"] + (gen % path).split())
+    stub.Stub_set_data_file.argtypes = [C.c_char_p, C.c_int]
+    stub.Pt_get.restype = C.c_void_p
+    stub.Pt_get.argtypes = [C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32]
+    stub.Pt_prefetch.argtypes = [C.c_uint32]
+    stub.Pt_free.argtypes = [C.c_uint32]
+    stub.Stub_set_params(N, L - 1, q0, sf, dnum, 192)
+    stub.Stub_set_data_file(path.encode(), 2)
+    stub.Prepare_context()
+    try:
+        raw = open(path, "rb").read()
+        import struct
+
+        lut_ofst = struct.unpack_from("<Q", raw, 24)[0]
+        stub.Pt_prefetch(n_ent - 1)
+        for e in range(n_ent):
+            name, idx, size, ofst = struct.unpack_from("<16sIIQ", raw, lut_ofst + 32 * e)
+            words = level * N
+            stored = np.frombuffer(raw, dtype=np.uint64, count=words, offset=ofst + 16 + stub.Stub_sizeof_plaintext()).reshape(level, N)
+            pt = stub.Pt_get(e, N // 2, deg, level)
+            assert stub.Stub_plain_level(pt) == level
+            got = _download(stub, pt, N)
+            assert np.array_equal(got, stored), e
+            msg = _ptfile_message(e, N // 2, seed)
+            mine = C.create_string_buffer(stub.Stub_sizeof_plaintext())
+            stub.Encode_plain_from_float(mine, msg.ctypes.data, N // 2, deg, level)
+            assert np.array_equal(_download(stub, mine, N), stored), e
+            stub.Free_plain(mine)
+            assert stub.Pt_get(e, N // 2, deg, level) == pt   # resident: the same plaintext on every request
+            stub.Pt_free(e)
+    finally:
+        stub.Finalize_context()
+        stub.Stub_set_data_file(None, 0)
+
+
+def test_plaintext_cache_equals_encoding(stub, tmp_path):
+    """ACEHIP_PT_CACHE=1 (weight plaintexts kept in HBM after their first encode): what Pt_from_msg returns from the cache on
+    the second and third request equals what it encodes without the cache, for two entries, levels and scale degrees."""
+    N, L, q0, sf, dnum = 4096, 6, 60, 50, 3
+    ent = tmp_path / "entries.txt"
+    ent.write_text("0 2048\n1 1024\n2 1\n")
+    wfile = str(tmp_path / "w.msg")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_weight_file.py"), "--entries", str(ent), "--out", wfile])
+    stub.Stub_set_data_file.argtypes = [C.c_char_p, C.c_int]
+    stub.Pt_from_msg.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32]
+    stub.Stub_set_params(N, L - 1, q0, sf, dnum, 192)
+    stub.Stub_set_data_file(wfile.encode(), 0)
+    results = {}
+    try:
+        for cache in ("0", "1"):
+            os.environ["ACEHIP_PT_CACHE"] = cache
+            stub.Prepare_context()
+            for rep in range(3 if cache == "1" else 1):
+                for (idx, n, deg, level) in [(0, 2048, 1, 6), (1, 1024, 2, 4), (0, 2048, 1, 3), (2, 1, 1, 5)]:
+                    pt = C.create_string_buffer(stub.Stub_sizeof_plaintext())
+                    stub.Pt_from_msg(pt, idx, n, deg, level)
+                    got = _download(stub, pt, N)
+                    key = (idx, n, deg, level)
+                    if cache == "0":
+                        results[key] = got
+                    else:
+                        assert np.array_equal(got, results[key]), (key, rep)
+                    stub.Free_plain(pt)
+            stub.Finalize_context()
+    finally:
+        os.environ.pop("ACEHIP_PT_CACHE", None)
+        stub.Stub_set_data_file(None, 0)
