@@ -360,6 +360,12 @@ static inline void stat(int k, u64 units, u64 bytes) {
 static int check_dev(acehip_ctx* c) {
   if (!c) return fail(ACEHIP_EINVAL, "null context");
   if (!c->on_device) return fail(ACEHIP_ENODEV, "context was created without a GPU; the HIP path has no CPU fallback");
+  // every entry point launches on the context's own device, whichever device the calling thread last selected (a thread
+  // may hold contexts on several GPUs; hipGetDevice is a thread-local read)
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
+    if (hipSetDevice(c->device) != hipSuccess) return fail(ACEHIP_EHIP, "hipSetDevice failed");
+  }
   return ACEHIP_OK;
 }
 static int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n) {

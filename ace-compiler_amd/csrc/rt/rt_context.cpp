@@ -7,6 +7,11 @@
 
 #include "rt_internal.hpp"
 
+// Programs generated for the CKKS-level provider interface (rt_seal examples) do not define this callback: it is an
+// optional (weak) reference here, a missing definition means "no weight data file".
+extern "C" RT_DATA_INFO* Get_rt_data_info() __attribute__((weak));
+static RT_DATA_INFO* rt_data_info() { return Get_rt_data_info ? Get_rt_data_info() : nullptr; }
+
 namespace rt {
 
 // Sample_triangle random_sample.c:78-97: -1 w.p. 1/4, +1 w.p. 1/4, 0 w.p. 1/2
@@ -217,9 +222,18 @@ void Prepare_context() {
   c->pmod.resize(c->K ? c->K : 1);
   for (u32 i = 0; i < c->L; ++i) c->qmod[i] = MODULUS{(int64_t)c->primes[i], i, 0};
   for (u32 j = 0; j < c->K; ++j) c->pmod[j] = MODULUS{(int64_t)c->primes[c->L + j], c->L + j, 0};
-  u64 seed = std::random_device{}() ^ ((u64)time(nullptr) << 20);
-  if (const char* e = getenv("ACEHIP_SEED")) seed = strtoull(e, nullptr, 10);
-  c->rng.seed(seed);
+  // 8 x 32 bits from the OS entropy source (the reference seeds rand() with the time of day, random_sample.c:23); a fixed
+  // ACEHIP_SEED makes runs reproducible.  seed_rng only ever hands out seeds for attaching threads, under shared_mu.
+  if (const char* e = getenv("ACEHIP_SEED")) {
+    const u64 seed = strtoull(e, nullptr, 10);
+    c->rng.seed(seed);
+    c->seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
+  } else {
+    std::random_device rd;
+    std::seed_seq s1{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()}, s2{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()};
+    c->rng.seed(s1);
+    c->seed_rng.seed(s2);
+  }
   // canonical-embedding tables (Precompute_fft ntt.c:587-610), m = 2N
   const size_t m = 2ull * c->N;
   c->fft_rou.resize(m);
@@ -252,7 +266,7 @@ void Prepare_context() {
   }
   if (!have_keys) generate_keys();
   bootstrap_setup_if_needed();
-  RT_DATA_INFO* di = Get_rt_data_info();
+  RT_DATA_INFO* di = rt_data_info();
   if (di != nullptr) {
     bool ok = Pt_mgr_init(di->_file_name);
     RT_ASSERT(ok, "Pt_mgr_init(%s) failed", di->_file_name);
@@ -272,7 +286,7 @@ void Finalize_context() {
   sync();
   HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
   if (!c.keys_save_path.empty()) RT_ASSERT(save_keys(c.keys_save_path.c_str()) == 0, "cannot write key file %s", c.keys_save_path.c_str());
-  if (Get_rt_data_info() != nullptr) Pt_mgr_fini();
+  if (rt_data_info() != nullptr) Pt_mgr_fini();
   const size_t key_words = (size_t)c.dnum * 2 * (c.L + c.K) * c.N;
   const size_t rot_cnt = c.auto_keys.size();
   const size_t rot_bytes = rot_cnt * key_words * 8;

@@ -48,9 +48,13 @@ void set_level(Ct& a, u32 level) {
   RT_ASSERT(level <= a.level(), "set_level: cannot raise a ciphertext");
   if (a.np() && level != a.level()) {
     // keep the "p-limbs follow the q-limbs" layout the kernels assume: compact the p part
+    // (limb by limb, ascending: the destination range may overlap the source range when fewer than np limbs are dropped,
+    // but a single limb never overlaps its own source, and limb i is read before limb i+1's destination is written)
     Context& c = ctx();
-    copy_limbs((u64*)q_limbs(&a.c._c0_poly) + (size_t)level * c.N, (const u64*)p_limbs(&a.c._c0_poly), (size_t)a.np() * c.N);
-    copy_limbs((u64*)q_limbs(&a.c._c1_poly) + (size_t)level * c.N, (const u64*)p_limbs(&a.c._c1_poly), (size_t)a.np() * c.N);
+    for (u32 i = 0; i < a.np(); ++i) {
+      copy_limbs((u64*)q_limbs(&a.c._c0_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c0_poly) + (size_t)i * c.N, c.N);
+      copy_limbs((u64*)q_limbs(&a.c._c1_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c1_poly) + (size_t)i * c.N, c.N);
+    }
     a.c._c0_poly._num_alloc_primes = a.c._c1_poly._num_alloc_primes = level + a.np();
   }
   a.c._c0_poly._num_primes = a.c._c1_poly._num_primes = level;
@@ -238,6 +242,14 @@ using namespace rt;
 extern "C" {
 
 CIPHER Add_ciph(CIPHER res, CIPHER a, CIPHER b) {
+  // provider-level programs accumulate into a ciphertext they cleared with Zero_ciph (rt_seal.h Seal_zero: "res = 0"):
+  // an empty operand is the additive identity
+  if (a->_c0_poly._data == nullptr || b->_c0_poly._data == nullptr) {
+    CIPHER src = a->_c0_poly._data == nullptr ? b : a;
+    RT_ASSERT(src->_c0_poly._data != nullptr, "Add_ciph: both operands are empty");
+    Copy_ciph(res, src);
+    return res;
+  }
   Ct x, y, r;
   ev::from_ciph(x, a);
   if (a == b) {

@@ -84,7 +84,8 @@ struct Context {
   std::map<u32, SwitchKeyStore*> auto_keys;   // automorphism index -> key
   std::map<int32_t, u32> rot2auto;            // rotation -> automorphism index
   std::vector<int64_t> sk_coef;               // ternary secret, host copy (signed)
-  std::mt19937_64 rng;
+  std::mt19937_64 rng;                        // this thread's sampler (secret key, errors, seeds of the device sampler)
+  std::mt19937_64 seed_rng;                   // primary context only: seeds of attaching threads, used under shared_mu
   // FFT tables for the canonical embedding of decode (ntt.c:587-610): m = 2N
   std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
   std::vector<u32> rot_group;     // 5^i mod 2N

@@ -424,6 +424,21 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
   rt::ctx().weight_plain_cnt++;
   rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
 }
+// provider-level debug aids (rt_seal.h:90-92)
+void Dump_ciph(CIPHER ct, size_t start, size_t len) {
+  double* m = Get_msg(ct);
+  printf("ciph[%zu..%zu):", start, start + len);
+  for (size_t i = start; i < start + len && i < ct->_slots; ++i) printf(" %f", m[i]);
+  printf("\n");
+  free(m);
+}
+void Dump_plain(PLAIN pt, size_t start, size_t len) {
+  double* m = Get_msg_from_plain(pt);
+  printf("plain[%zu..%zu):", start, start + len);
+  for (size_t i = start; i < start + len && i < pt->_slots; ++i) printf(" %f", m[i]);
+  printf("\n");
+  free(m);
+}
 void Pt_from_msg(void* pt, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
   rt::RtmScope rtm(rt::RTM_PT_ENCODE);
   pt_encode((PLAIN)pt, index, len, scale, level);

@@ -34,7 +34,7 @@ static void attach_thread() {
   c->hip = acehip_ctx_create(p->prm->_poly_degree, (uint32_t)p->prm->_mul_depth + 1, (uint32_t)p->prm->_first_mod_size,
                              (uint32_t)p->prm->_scaling_mod_size, (uint32_t)p->prm->_num_q_parts, dev);
   RT_ASSERT(c->hip != nullptr, "acehip_ctx_create failed: %s", acehip_last_error());
-  c->rng.seed(p->rng() ^ (u64)(uintptr_t)c);  // encryption noise of this thread
+  c->rng.seed(p->seed_rng() ^ (u64)(uintptr_t)c);  // encryption noise of this thread (seed_rng: never touched outside shared_mu)
   c->weight_plain_cnt = c->weight_plain_bytes = 0;
   c->t_encode = c->t_main = c->t_issue = c->t_bootstrap = 0;
   c->n_bootstrap = 0;

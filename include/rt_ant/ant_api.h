@@ -42,13 +42,21 @@ static inline int64_t Get_mod_val(MODULUS* m) { return m->_val; }
 
 /* ---- POLYNOMIAL (reference include/util/polynomial.h:35-44): limb-major RNS polynomial.
  * _data -> HBM; q-limbs first, p-limbs at index (_num_alloc_primes - _num_primes_p) ---- */
+/* C programs zero the shells with memset like the reference's generated code does.  CKKS-level provider programs are C++
+ * and declare `CIPHERTEXT out;` expecting an empty object (rt_acehip/rt_acehip.h defines ACEHIP_SHELL_ZERO_INIT): the
+ * members then value-initialise; layout and C linkage are unchanged. */
+#if defined(__cplusplus) && defined(ACEHIP_SHELL_ZERO_INIT)
+#define ACEHIP_ZI = {}
+#else
+#define ACEHIP_ZI
+#endif
 typedef struct {
-  uint32_t _ring_degree;
-  size_t   _num_alloc_primes;
-  size_t   _num_primes;
-  size_t   _num_primes_p;
-  bool     _is_ntt;
-  int64_t* _data;
+  uint32_t _ring_degree ACEHIP_ZI;
+  size_t   _num_alloc_primes ACEHIP_ZI;
+  size_t   _num_primes ACEHIP_ZI;
+  size_t   _num_primes_p ACEHIP_ZI;
+  bool     _is_ntt ACEHIP_ZI;
+  int64_t* _data ACEHIP_ZI;
 } POLYNOMIAL;
 typedef POLYNOMIAL* POLY;
 
@@ -56,23 +64,23 @@ typedef POLYNOMIAL* POLY;
 typedef struct {
   POLYNOMIAL _c0_poly;
   POLYNOMIAL _c1_poly;
-  uint32_t   _slots;
-  double     _scaling_factor;
-  uint32_t   _sf_degree;
+  uint32_t   _slots ACEHIP_ZI;
+  double     _scaling_factor ACEHIP_ZI;
+  uint32_t   _sf_degree ACEHIP_ZI;
 } CIPHERTEXT;
 typedef struct {
   POLYNOMIAL _c0_poly;
   POLYNOMIAL _c1_poly;
   POLYNOMIAL _c2_poly;
-  uint32_t   _slots;
-  double     _scaling_factor;
-  uint32_t   _sf_degree;
+  uint32_t   _slots ACEHIP_ZI;
+  double     _scaling_factor ACEHIP_ZI;
+  uint32_t   _sf_degree ACEHIP_ZI;
 } CIPHERTEXT3;
 typedef struct {
   POLYNOMIAL _poly;
-  uint32_t   _slots;
-  double     _scaling_factor;
-  uint32_t   _sf_degree;
+  uint32_t   _slots ACEHIP_ZI;
+  double     _scaling_factor ACEHIP_ZI;
+  uint32_t   _sf_degree ACEHIP_ZI;
 } PLAINTEXT;
 typedef CIPHERTEXT*  CIPHER;
 typedef CIPHERTEXT3* CIPHER3;

@@ -178,3 +178,17 @@ def test_resnet110_workload_runs_on_one_gpu():
     assert m, r.stdout[-2000:]
     vals = [float(x) for x in m.group(1).split()]
     assert len(vals) == 10 and all(math.isfinite(v) for v in vals)
+
+
+@pytest.mark.parametrize("name", ["add", "add_const", "mult_const", "conv2d_keep_shape"])
+def test_ckks_level_provider_programs(name):
+    """SURVEY 8f-2, the provider-level (ciphertext-granular) API: the reference's programs generated for the CKKS-level provider
+    interface (rtlib/seal/example/eg_rtseal_*.cxx + .inc, `#include "rt_seal/rt_seal.h"`: Add_ciph / Add_plain / Mul_plain /
+    Rotate_ciph / Copy_ciph / Encode_plain_from_float ... on whole ciphertexts) compiled UNCHANGED against
+    include/rt_seal/rt_seal.h -> include/rt_acehip/rt_acehip.h and libFHErt_ant (make -C workloads provider).  Each embeds its
+    expected output (tolerance 1e-2) and prints SUCCESS!."""
+    exe = os.path.join(EX_DIR, "egseal_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("workloads/_gen/examples/egseal_* not built (needs /root/reference: make -C workloads provider)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SUCCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
