@@ -474,10 +474,12 @@ def main():
 
     if rank == 0:
         achieved = bytes_per_dir / (fwd_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = image_traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_path):
-            traffic = json.load(open(tr_path)).get("ntt_forward_bytes_per_launch")
+        if os.path.exists(tr_path):  # PMC passes (tools/pmc_roofline.sh, tools/pmc_image.sh) recorded under profiles/
+            tr = json.load(open(tr_path))
+            traffic = tr.get("ntt_forward_bytes_per_launch")
+            image_traffic = tr.get("resnet20_bytes_per_image")
         out = {
             "metric": metric, "value": round(value, 6), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -501,12 +503,18 @@ def main():
         alg = sum(v[2] for k, v in stats.items() if k != "zero_fill_executed")  # that family is a subset of "elementwise"
         out["workload_roofline"] = {
             "algorithmic_bytes_per_image": int(alg / args.steps),
-            "achieved_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
-            "frac_of_hbm_peak": round(n_streams * alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
+            "algorithmic_frac_of_hbm_peak": round(n_streams * alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
+            # counter-based: L2-miss traffic of one image (FETCH_SIZE x2 + WRITE_SIZE over every dispatch of a one-stream run,
+            # profiles/traffic.json) times the measured images/s of this run; Infinity-Cache hits are inside this figure
+            "measured_bytes_per_image": image_traffic,
+            "measured_GBs": (round(image_traffic * value / world / 1e9, 2) if (image_traffic and use_model) else None),
+            "measured_frac_of_hbm_peak": (round(image_traffic * value / world / 1e9 / HBM_PEAK_GBS, 4) if (image_traffic and use_model) else None),
             "calls_per_step": {k: round(v[0] / args.steps, 1) for k, v in stats.items() if v[0]},
             "GB_per_step": {k: round(v[2] / args.steps / 1e9, 2) for k, v in stats.items() if v[2]},
-            "note": "sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) of one "
-                    "stream, times the streams of the GPU, / wall time"}
+            "note": "algorithmic_*: sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) of one "
+                    "stream, times the streams of the GPU, / wall time -- NOT a memory-traffic figure (chains of per-limb ops keep "
+                    "intermediates in registers, dead fills are dropped); measured_*: hardware counters"}
         if cache_run is not None:
             out["with_plaintext_cache"] = cache_run
         if logits is not None:
