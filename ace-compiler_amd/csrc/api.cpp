@@ -1,5 +1,7 @@
 // api.cpp -- C ABI (include/acehip.h) over the HIP kernels: context/table upload, workspace, and the
 // host-side sequencing of Decomp_modup / Mod_down / Rescale / key-switch.
+#include <unordered_map>
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -146,6 +148,11 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   ctx->dc.logN = hp.logN;
   ctx->dc.L = hp.L;
   ctx->dc.K = hp.K;
+  {
+    u32 max_bits = 0;
+    for (u32 i = 0; i < T; ++i) max_bits = std::max(max_bits, (u32)hp.primes[i].nbits);
+    ctx->dc.split_bits = (max_bits + 1) / 2;  // <= 31: primes are below 2^61 (host_params)
+  }
   ctx->phat_inv = ctx->up(hp.phat_inv_modp);
   ctx->phat_inv_prec = ctx->up(hp.phat_inv_modp_prec);
   // base_conv wants hat[i_src][j_dst]: transpose phat_modq[L][K] -> [K][L]
@@ -585,7 +592,73 @@ static void plan_append(const HwBatchOp& o, u32 seg) {
   }
   ++p.n;
 }
+// ACEHIP_HW_TRAFFIC=1: limb loads / stores the elementwise launches actually perform, per op kind (the kernel's forwarding
+// rules replayed on the host), printed at exit -- where the bytes of the generated per-limb code go
+static std::atomic<u64> g_hw_traffic[9][4];  // [kind][ops, limb loads, limb stores, segments started]
+static bool hw_traffic_on() {
+  static const bool on = [] {
+    const bool v = getenv("ACEHIP_HW_TRAFFIC") != nullptr;
+    if (v)
+      atexit([] {
+        static const char* const kn[9] = {"add", "mul", "rotate", "copy", "zero", "sub", "muladd", "mulc", "addc"};
+        u64 tl = 0, ts = 0;
+        for (int k = 0; k < 9; ++k) {
+          const u64 o = g_hw_traffic[k][0], l = g_hw_traffic[k][1], w = g_hw_traffic[k][2];
+          if (o) fprintf(stderr, "[hw traffic] %-7s ops %10llu  limb loads %10llu  limb stores %10llu\n", kn[k], (unsigned long long)o,
+                         (unsigned long long)l, (unsigned long long)w);
+          tl += l;
+          ts += w;
+        }
+        fprintf(stderr, "[hw traffic] total limb loads %llu stores %llu\n", (unsigned long long)tl, (unsigned long long)ts);
+      });
+    return v;
+  }();
+  return on;
+}
+static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg) {
+  static std::atomic<u64> n_launch{0};
+  static const u64 every = getenv("ACEHIP_HW_DUMP_EVERY") ? strtoull(getenv("ACEHIP_HW_DUMP_EVERY"), nullptr, 0) : 0;
+  if (every && n_launch++ % every == 0) {  // a sample of launches, limbs numbered in order of appearance
+    static const char* const kn[9] = {"add", "mul", "rot", "copy", "zero", "sub", "muladd", "mulc", "addc"};
+    std::unordered_map<const void*, int> id;
+    auto name = [&](const void* p) { return id.emplace(p, (int)id.size()).first->second; };
+    std::string out = "[hw dump] launch " + std::to_string((u64)n_launch) + " segs " + std::to_string(n_seg) + "\n";
+    for (u32 sgm = 0; sgm < n_seg; ++sgm) {
+      out += "  seg:";
+      for (u32 k = args.seg_start[sgm]; k < args.seg_start[sgm + 1]; ++k) {
+        const HwBatchOp& o = args.op[k];
+        char buf[96];
+        const bool has_b = o.kind == HW_OP_ADD || o.kind == HW_OP_SUB || o.kind == HW_OP_MUL || o.kind == HW_OP_MULADD;
+        if (o.kind == HW_OP_ZERO) snprintf(buf, sizeof buf, " L%d=0", name(o.res));
+        else if (has_b) snprintf(buf, sizeof buf, " L%d=%s(L%d,L%d)q%u", name(o.res), kn[o.kind], name(o.a), name(o.b), o.gi);
+        else snprintf(buf, sizeof buf, " L%d=%s(L%d)q%u", name(o.res), kn[o.kind], name(o.a), o.gi);
+        out += buf;
+      }
+      out += "\n";
+    }
+    fputs(out.c_str(), stderr);
+  }
+  for (u32 sgm = 0; sgm < n_seg; ++sgm) {
+    const u64* prev = nullptr;
+    const u32 beg = args.seg_start[sgm], end = args.seg_start[sgm + 1];
+    for (u32 k = beg; k < end; ++k) {
+      const HwBatchOp& o = args.op[k];
+      u64 loads = 0;
+      if (o.kind != HW_OP_ZERO) {
+        loads += o.a != prev;
+        if (o.kind == HW_OP_ADD || o.kind == HW_OP_SUB || o.kind == HW_OP_MUL || o.kind == HW_OP_MULADD) loads += o.b != prev;
+        if (o.kind == HW_OP_MULADD) loads += o.res != prev;
+      }
+      const bool keep = k + 1 < end && args.op[k + 1].res == o.res;
+      g_hw_traffic[o.kind][0] += 1;
+      g_hw_traffic[o.kind][1] += loads;
+      g_hw_traffic[o.kind][2] += !keep;
+      prev = o.res;
+    }
+  }
+}
 static void emit_ew(acehip_ctx* c, const HwBatchArgs& args, u32 n_seg, hipStream_t st) {
+  if (hw_traffic_on()) hw_traffic_count(args, n_seg);
   if (!g_plan) {
     launch_hw_batch_ew(c->dc, args, n_seg, st);
     return;
@@ -966,7 +1039,7 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
     launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
   }
   // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
-  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s);
+  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s, hp.K);
   if (c->dc.logN == 16) {
     NttFuse fo;
     fo.epi = 2;
@@ -1094,7 +1167,7 @@ int acehip_base_conv(acehip_ctx* c, uint64_t* d_out, const uint64_t* d_in, uint3
   cd.n_out = n_out;
   HIP_TRY(hipMemcpy(d_desc, &cd, sizeof(ConvDesc), hipMemcpyHostToDevice));
   hipStream_t s = (hipStream_t)s_;
-  launch_base_conv_batch(c->dc, d_out, 0, d_in, 0, d_desc, 0, 1, n_out, s);
+  launch_base_conv_batch(c->dc, d_out, 0, d_in, 0, d_desc, 0, 1, n_out, s, cd.n_in);
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(d_blob);
   (void)hipFree(d_desc);
@@ -1261,7 +1334,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
     launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
   }
   // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the load), one launch
-  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
+  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
   // 3. NTT of every digit's complement limbs, one launch (own digit limbs are skipped)
   launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E,
              hp.alpha);
@@ -1275,7 +1348,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   } else {
     launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
   }
-  launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s);
+  launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
   if (fused) {  // the ModDown tail rides in the last NTT pass
     NttFuse fo;
     fo.epi = 2;
@@ -1471,7 +1544,7 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
     HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
     launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
   }
-  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s);
+  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
   launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E, hp.alpha);
   {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
     HwBatchArgs cp;
@@ -1798,7 +1871,7 @@ int acehip_shard_ks_phase2(acehip_shard* sh, uint64_t* d_send2, const uint64_t* 
   launch_packed_gather(c->dc, sh->full, gt, level, s);
   // (b) ModUp: all digits in one launch onto the owned complement limbs; ext digit d at ext + d*nown_full*N
   const size_t ext_stride = (size_t)nown_full * N;
-  if (pl->max_tgt) launch_base_conv_batch(c->dc, sh->ext, ext_stride, sh->full, 0, pl->d_up, 1, pl->nd, pl->max_tgt, s);
+  if (pl->max_tgt) launch_base_conv_batch(c->dc, sh->ext, ext_stride, sh->full, 0, pl->d_up, 1, pl->nd, pl->max_tgt, s, hp.alpha);
   // (c) NTT of the raised limbs
   for (u32 d = 0; d < pl->nd; ++d) {
     std::vector<u32> h_gi(pl->n_tgt[d]);
@@ -1859,7 +1932,7 @@ int acehip_shard_ks_phase3(acehip_shard* sh, uint64_t* d_out0, uint64_t* d_out1,
     }
   launch_packed_gather(c->dc, sh->pfull, gt, 2 * hp.K, s);
   // both accumulators: P -> owned q-limbs (problem z reads pfull + z*K*N, writes conv + z*nq_full*N)
-  launch_base_conv_batch(c->dc, sh->conv, (size_t)nq_full * N, sh->pfull, (size_t)hp.K * N, pl->d_down, 0, 2, nq, s);
+  launch_base_conv_batch(c->dc, sh->conv, (size_t)nq_full * N, sh->pfull, (size_t)hp.K * N, pl->d_down, 0, 2, nq, s, hp.K);
   ntt_packed(c, sh->conv, nullptr, nullptr, sh->d_q_gi, sh->q_own.data(), nq, 2, (size_t)nq_full * N, false, s);
   u64 *acc0 = sh->acc, *acc1 = sh->acc + (size_t)nown_full * N;
   launch_packed_moddown_tail(c->dc, d_out0, d_out1, acc0, acc1, sh->conv, (size_t)nq_full * N, sh->d_q_gi, pl->d_pinv, pl->d_pinv_prec, nq, 2, s);

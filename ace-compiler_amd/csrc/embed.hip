@@ -116,6 +116,7 @@ __global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict_
 // msg[N] (device) <- rounded, scaled inverse embedding of `vals` (len values, zero padded to `slots`)
 void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
                       const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_EMBED);
   u32 logn = 0, log2m = 1;
   while ((1u << logn) < slots) ++logn;
   while ((1u << log2m) < 2 * N) ++log2m;

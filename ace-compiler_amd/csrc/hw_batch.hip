@@ -139,6 +139,7 @@ static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
 }
 
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_EW);
   if (n_seg == 0) return;
   dim3 grid((c.N / kHwLanes + 255) / 256, n_seg), block(256);
   const u32 n_ops = args.seg_start[n_seg];
@@ -148,6 +149,7 @@ void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hip
 }
 
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_ROTATE);
   if (n_ops == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_ops), block(256);
   if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_rotate_kernel<16>, grid, block, 0, s, c.N, shrink<16>(args, n_ops, 0));

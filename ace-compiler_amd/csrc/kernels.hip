@@ -4,9 +4,21 @@
 // Everything here is 64-bit integer modular arithmetic (no MFMA).  The kernels are HBM-bandwidth
 // bound by design: limb-major [limb][N] layout, 16-byte per-lane accesses, LDS-staged butterflies.
 // Reference algorithms: fhe-cmplr/rtlib/ant/src/util/{ntt.c,polynomial.c}, src/poly/poly_arith.c.
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace acehip {
+
+#ifdef ACEHIP_ABLATION
+unsigned ablate_mask() {
+  static const unsigned m = [] {
+    const char* e = getenv("ACEHIP_ABLATE");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+  }();
+  return m;
+}
+#endif
+
 
 // ------------------------------------------------------------------------------------------------
 // NTT passes.
@@ -111,6 +123,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
 template <bool CONTIG, bool INVERSE>
 static void launch_pass(const DevCtx& c, u64* poly, size_t poly_stride, u32 n_polys, u32 level, u32 pos0, u32 pos_off, u32 n_limbs, u32 s0, u32 r,
                         u32 log_c, hipStream_t s, u32 skip_alpha) {
+  ACEHIP_ABLATE(ABL_NTT);
   const u32 tiles = c.N >> (r + log_c);
   dim3 grid(tiles, n_limbs, n_polys), block(256);
   size_t lds = sizeof(u64) << (r + log_c);
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(256) void ew_kernel(DevCtx c, u64* __restrict__ r, 
 
 void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs,
                hipStream_t s, u32 pos_off) {
+  ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
   switch (op) {
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(256) void rotate_kernel(u32 N, u64* __restrict__ r,
 }
 
 void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 pos0, u32 n_limbs, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_ROTATE);
   if (n_limbs == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(rotate_kernel, grid, block, 0, s, c.N, r, a, perm, pos0);
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(256) void mul_const_kernel(DevCtx c, u64* __restric
 
 void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const u64* wp, const u32* gi, u32 n_limbs,
                       hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(mul_const_kernel, grid, block, 0, s, c, r, a, w, wp, gi);
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* __restric
 
 void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, const u32* out_gi, const u32* out_pos,
                       u32 n_in, u32 n_out, u32 hat_ld, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_CONV);
   if (n_out == 0) return;
   dim3 grid((c.N + 255) / 256, (n_out + kConvGroup - 1) / kConvGroup), block(256);
   hipLaunchKernelGGL(base_conv_kernel, grid, block, 0, s, c, out, in, hat, out_gi, out_pos, n_in, n_out, hat_ld);
@@ -296,6 +313,7 @@ __global__ __launch_bounds__(256) void moddown_tail_kernel(DevCtx c, u64* __rest
 
 void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level,
                          hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   dim3 grid((c.N / 2 + 255) / 256, level), block(256);
   hipLaunchKernelGGL(moddown_tail_kernel, grid, block, 0, s, c, out, x, pinv, pinv_prec);
 }
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* __re
 
 void launch_rescale_spread(const DevCtx& c, u64* t, size_t t_stride, const u64* last, size_t last_stride, const u64* c1,
                            const u64* c1p, u32 level, u32 n_polys, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
   hipLaunchKernelGGL(rescale_spread_kernel, grid, block, 0, s, c, t, t_stride, last, last_stride, c1, c1p, level);
 }
@@ -344,6 +363,7 @@ __global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __rest
 
 void launch_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
                          const u64* inv, const u64* invp, u32 level, u32 n_polys, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
   hipLaunchKernelGGL(rescale_tail_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t, t_stride, inv, invp);
 }
@@ -381,6 +401,7 @@ __global__ __launch_bounds__(256) void key_mac_kernel(DevCtx c, u64* __restrict_
 
 void launch_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext, u32 level,
                     bool accumulate, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_KEYMAC);
   dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
   if (accumulate) hipLaunchKernelGGL(key_mac_kernel<true>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);
   else            hipLaunchKernelGGL(key_mac_kernel<false>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);

@@ -6,12 +6,25 @@
 
 namespace acehip {
 
+// Throughput-sensitivity experiments (tools/ablate.sh): a library built with -DACEHIP_ABLATION skips the launches of the kernel
+// families named by the bit mask in $ACEHIP_ABLATE (results are wrong; only the time of what is left is of interest).  Product
+// builds compile this to nothing.
+enum AblateFamily : unsigned { ABL_NTT = 1, ABL_EW = 2, ABL_ROTATE = 4, ABL_KEYMAC = 8, ABL_CONV = 16, ABL_BSGS = 32, ABL_EMBED = 64,
+                               ABL_OTHER = 128 };
+#ifdef ACEHIP_ABLATION
+unsigned ablate_mask();
+#define ACEHIP_ABLATE(family) do { if (ablate_mask() & (family)) return; } while (0)
+#else
+#define ACEHIP_ABLATE(family) do { } while (0)
+#endif
+
 // Tables resident in HBM for one context (passed by value to kernels).
 struct DevCtx {
   const DevPrime* primes;  // [L+K]
   const ulong2* tw_fwd;    // [L+K][N] {rou[bitrev], Shoup companion}
   const ulong2* tw_inv;    // [L+K][N] {rou_inv[bitrev], Shoup companion}
   u32 N, logN, L, K;
+  u32 split_bits;  // ceil(max prime bits / 2): base conversion multiplies in halves of this width (keyswitch.hip)
 };
 
 // prime (global index) of the limb at position pos of a polynomial extended at `level`
@@ -130,7 +143,8 @@ void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, 
 // batched form: problem z = blockIdx.z uses descs[z*desc_step], reads in + z*in_stride (coefficient domain
 // limbs at positions src_pos0..), writes out + z*out_stride
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
-                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s);
+                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s,
+                            u32 max_n_in = 0);  // max_n_in: largest n_in of the problems when known (selects the <= 16 kernel)
 // fused key inner product over all digits (generated code inc:7011-7036 for every part):
 //   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,

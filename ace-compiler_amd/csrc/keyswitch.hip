@@ -6,45 +6,64 @@
 
 namespace acehip {
 
-constexpr int kMaxIn = 16;   // source limbs held in registers at a time (alpha, K <= 12 for the reference parameter sets)
-constexpr int kGroup = 8;    // output limbs per workgroup row (sources stay in registers)
+constexpr int kGroup = 8;       // output limbs per workgroup row: a source value is loaded once for all of them
+constexpr int kConvMaxIn = 64;  // source limbs of one conversion (digit size alpha, or K): checked at context creation
 
-// out[pos_j][n] = ( sum_i y_i[n] * hat[i][j] ) mod t_j,  y_i = in[src_pos0+i][n] (* scale_i mod q_i)
-// n_in <= 64 (checked when the context is created): sources go through the registers in chunks of kMaxIn, the 128-bit
-// sums of the group's outputs persist across chunks; one chunk is the usual case.
+// out[pos_j][n] = ( sum_i y_i[n] * hat[i][j] ) mod t_j,  y_i = in[src_pos0+i][n] (* scale_i mod q_i): canonical residues in,
+// canonical residues out, the sum is exact (Reduce_rns_base polynomial.c:928-967 accumulates in 128 bits and reduces once).
+//
+// The multiply-accumulate is the whole cost of this kernel (n_in products per output), so it is arranged for
+// v_mad_u64_u32 and nothing else: both factors are below 2^(2h) (h = DevCtx::split_bits = 30 for primes below 2^60) and
+// are split into halves of h bits; the four partial products of a term are below 2^(2h), so 2^(64-2h) terms (16 for
+// h = 30) accumulate in four plain 64-bit sums without any carry -- four multiply-adds per term, whose 64-bit addend is
+// free -- and the sums are combined into the 128-bit total once per chunk of terms.  The constants hat[i][j] of the row are
+// staged in LDS, already split (every lane reads the same address: a broadcast).
 __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                               const u64* __restrict__ in, size_t in_stride,
                                                               const ConvDesc* __restrict__ descs, u32 desc_step) {
+  __shared__ uint2 s_hat[kConvMaxIn * kGroup];  // this row's constants, already split: {low half, high half}
   const ConvDesc d = descs[blockIdx.z * desc_step];
   const u32 j0 = blockIdx.y * kGroup;
-  if (j0 >= d.n_out) return;
+  if (j0 >= d.n_out) return;  // uniform for the workgroup
+  const u32 h = c.split_bits, mask = (1u << h) - 1u;
+  for (u32 t = threadIdx.x; t < d.n_in * kGroup; t += 256) {
+    const u32 i = t / kGroup, j = min(j0 + t % kGroup, d.n_out - 1);  // rows past n_out repeat the last one (computed, not stored)
+    const u64 b = d.hat[(size_t)i * d.hat_ld + (d.col ? d.col[j] : j)];
+    s_hat[t] = uint2{(u32)b & mask, (u32)(b >> h)};
+  }
+  __syncthreads();
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
   const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + n;
   u64* dst = out + blockIdx.z * out_stride + n;
-  U128 acc[kGroup];
+  const u32 chunk = h <= 30 ? 16u : (h == 31 ? 4u : 1u);  // terms whose partial products fit 64-bit sums
+  unsigned __int128 tot[kGroup];
+  u64 s00[kGroup], s01[kGroup], s10[kGroup], s11[kGroup];
 #pragma unroll
-  for (int g = 0; g < kGroup; ++g) acc[g] = U128{0, 0};
-  for (u32 i0 = 0; i0 < d.n_in; i0 += kMaxIn) {
-    u64 y[kMaxIn];
+  for (int g = 0; g < kGroup; ++g) {
+    tot[g] = 0;
+    s00[g] = s01[g] = s10[g] = s11[g] = 0;
+  }
+  for (u32 i0 = 0; i0 < d.n_in; i0 += chunk) {
+    const u32 i1 = min(i0 + chunk, d.n_in);
+#pragma unroll 2
+    for (u32 i = i0; i < i1; ++i) {
+      u64 v = src[(size_t)i * c.N];
+      if (d.scale) v = mul_shoup(v, d.scale[i], d.scale_prec[i], c.primes[d.src_gi[i]].q);
+      const u32 a0 = (u32)v & mask, a1 = (u32)(v >> h);
 #pragma unroll
-    for (int i = 0; i < kMaxIn; ++i) {
-      y[i] = 0;
-      if (i0 + i < d.n_in) {
-        u64 v = src[(size_t)(i0 + i) * c.N];
-        if (d.scale) v = mul_shoup(v, d.scale[i0 + i], d.scale_prec[i0 + i], c.primes[d.src_gi[i0 + i]].q);
-        y[i] = v;
+      for (int g = 0; g < kGroup; ++g) {
+        const uint2 b = s_hat[i * kGroup + g];  // same address in every lane: an LDS broadcast
+        s00[g] += (u64)a0 * b.x;
+        s01[g] += (u64)a0 * b.y;
+        s10[g] += (u64)a1 * b.x;
+        s11[g] += (u64)a1 * b.y;
       }
     }
 #pragma unroll
     for (int g = 0; g < kGroup; ++g) {
-      const u32 j = j0 + g;
-      if (j < d.n_out) {
-        const u32 col = d.col ? d.col[j] : j;
-#pragma unroll
-        for (int i = 0; i < kMaxIn; ++i)
-          if (i0 + i < d.n_in) mac128(acc[g], y[i], d.hat[(size_t)(i0 + i) * d.hat_ld + col]);
-      }
+      tot[g] += (unsigned __int128)s00[g] + (((unsigned __int128)s01[g] + s10[g]) << h) + ((unsigned __int128)s11[g] << (2 * h));
+      s00[g] = s01[g] = s10[g] = s11[g] = 0;
     }
   }
 #pragma unroll
@@ -52,16 +71,84 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
     const u32 j = j0 + g;
     if (j < d.n_out) {
       const DevPrime& P = c.primes[d.out_gi[j]];
-      dst[(size_t)d.out_pos[j] * c.N] = reduce128(acc[g], P.q, P.prec128_lo, P.prec128_hi);
+      dst[(size_t)d.out_pos[j] * c.N] = reduce128(U128{(u64)tot[g], (u64)(tot[g] >> 64)}, P.q, P.prec128_lo, P.prec128_hi);
+    }
+  }
+}
+
+// The usual case -- at most 16 sources, primes below 2^60 -- as its own kernel: every source value of the lane is requested
+// before anything else waits (the loads overlap the descriptor / constant chain), one chunk of terms needs no 128-bit
+// running total (<= 128 VGPRs: 4 workgroups per CU), and the per-output reduction constants come from LDS.
+__global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
+                                                                   const u64* __restrict__ in, size_t in_stride,
+                                                                   const ConvDesc* __restrict__ descs, u32 desc_step) {
+  constexpr u32 kIn = 16;
+  __shared__ uint2 s_hat[kIn * kGroup];
+  __shared__ u64 s_q[kGroup], s_ml[kGroup], s_mh[kGroup];
+  __shared__ u32 s_pos[kGroup];
+  const ConvDesc d = descs[blockIdx.z * desc_step];
+  const u32 j0 = blockIdx.y * kGroup;
+  if (j0 >= d.n_out) return;  // uniform for the workgroup
+  const u32 n = blockIdx.x * 256 + threadIdx.x;
+  const bool active = n < c.N;
+  const u32 h = c.split_bits, mask = (1u << h) - 1u;
+  const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + (active ? n : 0);
+  u64 y[kIn];
+#pragma unroll
+  for (u32 i = 0; i < kIn; ++i) y[i] = i < d.n_in ? src[(size_t)i * c.N] : 0;
+  for (u32 t = threadIdx.x; t < d.n_in * kGroup; t += 256) {
+    const u32 i = t / kGroup, j = min(j0 + t % kGroup, d.n_out - 1);
+    const u64 b = d.hat[(size_t)i * d.hat_ld + (d.col ? d.col[j] : j)];
+    s_hat[t] = uint2{(u32)b & mask, (u32)(b >> h)};
+  }
+  if (threadIdx.x < kGroup) {
+    const u32 j = min(j0 + threadIdx.x, d.n_out - 1);
+    const DevPrime& P = c.primes[d.out_gi[j]];
+    s_q[threadIdx.x] = P.q;
+    s_ml[threadIdx.x] = P.prec128_lo;
+    s_mh[threadIdx.x] = P.prec128_hi;
+    s_pos[threadIdx.x] = d.out_pos[j];
+  }
+  __syncthreads();
+  if (!active) return;
+  u64 s00[kGroup], s01[kGroup], s10[kGroup], s11[kGroup];
+#pragma unroll
+  for (int g = 0; g < kGroup; ++g) s00[g] = s01[g] = s10[g] = s11[g] = 0;
+#pragma unroll
+  for (u32 i = 0; i < kIn; ++i) {
+    if (i >= d.n_in) break;  // uniform
+    u64 v = y[i];
+    if (d.scale) v = mul_shoup(v, d.scale[i], d.scale_prec[i], c.primes[d.src_gi[i]].q);
+    const u32 a0 = (u32)v & mask, a1 = (u32)(v >> h);
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      const uint2 b = s_hat[i * kGroup + g];
+      s00[g] += (u64)a0 * b.x;
+      s01[g] += (u64)a0 * b.y;
+      s10[g] += (u64)a1 * b.x;
+      s11[g] += (u64)a1 * b.y;
+    }
+  }
+  u64* dst = out + blockIdx.z * out_stride + n;
+#pragma unroll
+  for (int g = 0; g < kGroup; ++g) {
+    if (j0 + g < d.n_out) {
+      const unsigned __int128 tot =
+          (unsigned __int128)s00[g] + (((unsigned __int128)s01[g] + s10[g]) << h) + ((unsigned __int128)s11[g] << (2 * h));
+      dst[(size_t)s_pos[g] * c.N] = reduce128(U128{(u64)tot, (u64)(tot >> 64)}, s_q[g], s_ml[g], s_mh[g]);
     }
   }
 }
 
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
-                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s) {
+                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s, u32 max_n_in) {
+  ACEHIP_ABLATE(ABL_CONV);
   if (n_problems == 0 || max_n_out == 0) return;
   dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems), block(256);
-  hipLaunchKernelGGL(base_conv_batch_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
+  if (max_n_in != 0 && max_n_in <= 16 && c.split_bits <= 30)
+    hipLaunchKernelGGL(base_conv_batch16_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
+  else
+    hipLaunchKernelGGL(base_conv_batch_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
 }
 
 // acc{0,1}[pos][n] = sum_d key{0,1}[d][gi][n] * e_d[pos][n];  key layout [nd][2][L+K][N]
@@ -96,6 +183,7 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __res
 
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_KEYMAC);
   dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha);
 }
@@ -153,6 +241,7 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
 }
 
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_BSGS);
   dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
   if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
   else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
@@ -181,6 +270,7 @@ __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __res
 
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
                           const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys) {
+  ACEHIP_ABLATE(ABL_OTHER);
   dim3 grid((c.N / 2 + 255) / 256, level, n_polys), block(256);
   hipLaunchKernelGGL(moddown_tail2_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t0, t1, pinv, pinv_prec);
 }

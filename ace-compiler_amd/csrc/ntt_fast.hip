@@ -27,9 +27,17 @@ struct Tw {
   u64 w, p;
 };
 
+#ifndef NTT_EXP
+#define NTT_EXP 0  // timing experiments only (results are wrong): 1 no butterflies, 2 no data loads/stores, 4 no twiddle loads,
+                   // 8 no strided pass at all (what a one-pass transform would save)
+#endif
 __device__ __forceinline__ Tw ldtw(const ulong2* __restrict__ t, u32 idx) {
+#if NTT_EXP & 4
+  return Tw{(u64)idx * 0x9E3779B97F4A7C15ull, (u64)idx * 0xC2B2AE3D27D4EB4Full + threadIdx.x};
+#else
   const ulong2 v = t[idx];
   return Tw{v.x, v.y};
+#endif
 }
 
 // a*w mod q in [0,2q) for any 64-bit a (exact Shoup quotient: at most 1 below the true quotient)
@@ -38,10 +46,35 @@ __device__ __forceinline__ u64 shoup_lazy(u64 a, Tw t, u64 q) { return a * t.w -
 // a*w mod q in [0,4q) for any 64-bit a: quotient estimate h = a1*p1 + hi32(a0*p1) + hi32(a1*p0), which is
 // floor(a*wp/2^64) less at most 2 (the dropped a0*p0 and the two truncated cross terms), itself at most 1 below
 // floor(a*w/q)
+// Every partial product is written as a full 32x32->64 product and pinned by an empty asm, so that the compiler emits
+// v_mad_u64_u32 (with its free 64-bit accumulate) for it instead of narrowing to the quarter-rate v_mul_lo_u32 /
+// v_mul_hi_u32: 9 v_mad_u64_u32 per product and no separate 64-bit subtraction (the result is a*w + h*(2^64-q)).
+#define ACEHIP_PIN(x) asm("" : "+v"(x))
 __device__ __forceinline__ u64 shoup4(u64 a, Tw t, u64 q) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)t.p, p1 = (u32)(t.p >> 32);
+#ifdef ACEHIP_SHOUP_COMPILER_MULS
   const u64 h = (u64)a1 * p1 + __umulhi(a0, p1) + __umulhi(a1, p0);
   return a * t.w - h * q;
+#else
+  const u32 w0 = (u32)t.w, w1 = (u32)(t.w >> 32);
+  const u64 nq = 0 - q;
+  const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  u64 U = (u64)a0 * p1;
+  ACEHIP_PIN(U);
+  u64 V = (u64)a1 * p0;
+  ACEHIP_PIN(V);
+  const u64 h = (u64)a1 * p1 + (U >> 32) + (V >> 32);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32);
+  u64 c = (u64)a0 * w1;
+  c += (u64)a1 * w0;
+  c += (u64)h0 * n1;
+  c += (u64)h1 * n0;
+  ACEHIP_PIN(c);
+  u64 r = (u64)a0 * w0;
+  r += (u64)h0 * n0;
+  ACEHIP_PIN(r);
+  return r + ((u64)(u32)c << 32);
+#endif
 }
 
 // primes for which 16 forward stages without any reduction stay below 2^64: q + 16*4q = 65q
@@ -51,6 +84,10 @@ constexpr u64 kSmallPrimeMax = ~0ull / 65;
 // !SMALL: X,Y in [0,8q) -> [0,8q) (q < 2^61)
 template <bool SMALL>
 __device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, u64 q, u64 q4) {
+#if NTT_EXP & 1
+  X ^= t.w; Y += t.p;
+  return;
+#endif
   u64 x = X;
   if (!SMALL) x = X >= q4 ? X - q4 : X;
   const u64 m = shoup4(Y, t, q);
@@ -140,10 +177,16 @@ __device__ __forceinline__ LimbBuf limb_buf(const u64* base, u32 bytes) {
   return LimbBuf{__builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000)};
 }
 __device__ __forceinline__ u64 bld(const LimbBuf& b, u32 voff, u32 soff) {
+#if NTT_EXP & 2
+  return (u64)voff * 0x9E3779B97F4A7C15ull + soff;
+#endif
   const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
   return ((u64)v.y << 32) | v.x;
 }
 __device__ __forceinline__ void bst(const LimbBuf& b, u32 voff, u32 soff, u64 v) {
+#if NTT_EXP & 2
+  if (v != 0x123456789ull) return;
+#endif
   u32x2_t w;
   w.x = (u32)v;
   w.y = (u32)(v >> 32);
@@ -216,6 +259,9 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
                                                            u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                            u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[256 * kRowPitch];
+#if NTT_EXP & 8
+  if (!FROM_MSG) return;
+#endif
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   u32 pos, gi;
   if (f.gi_tab != nullptr) {  // packed limb list (limb-sharded execution)
@@ -298,7 +344,11 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
 #pragma unroll
+#if NTT_EXP & 2
+  for (int k = 0; k < 16; ++k) x[k] = (u64)(b * 256 + 16 * k + lo4) * 0x9E3779B97F4A7C15ull + o;
+#else
   for (int k = 0; k < 16; ++k) x[k] = X[b * 256 + 16 * k + lo4];
+#endif
   load_tw(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
 #pragma unroll
@@ -366,6 +416,9 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
         v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
         v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
       }
+#if NTT_EXP & 2
+      if (v.x != 0x123456789ull) continue;
+#endif
       *reinterpret_cast<ulong2*>(dst + e) = v;
     }
   } else {
@@ -417,6 +470,7 @@ void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limb
 
 void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                       u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
+  ACEHIP_ABLATE(ABL_NTT);
   if (n_limbs == 0) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
@@ -436,6 +490,7 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
 
 void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
                         u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
+  ACEHIP_ABLATE(ABL_NTT);
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);
   const NttFuse f{};
   if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys);

@@ -1,6 +1,7 @@
 // rt_poly.cpp -- device memory pool, POLYNOMIAL helpers and the polynomial/ciphertext part of the
 // rt_ant API (reference: include/poly/poly_eval.h, src/poly/{poly_eval,poly_arith}.c,
 // src/ckks/cipher_eval.c:18-123, include/util/{polynomial,ciphertext}.h).
+#include <algorithm>
 #include <cstring>
 #include <ctime>
 
@@ -96,6 +97,7 @@ namespace {
 thread_local std::vector<acehip_hw_op> g_hwq;
 struct HwqStats {
   size_t flushes = 0, ops = 0, by_kind[9] = {}, hist[8] = {};  // hist: <=1, <=4, <=16, <=64, <=256, <=1024, <=4096, more
+  size_t res_limbs = 0, res_limbs_freed = 0;  // distinct result limbs per flush; those whose block was already freed
 };
 thread_local HwqStats g_hwq_stats;
 }
@@ -105,6 +107,7 @@ void hw_stats_print() {
          "ops per flush <=1:%zu <=4:%zu <=16:%zu <=64:%zu <=256:%zu <=1024:%zu <=4096:%zu more:%zu\n",
          s.flushes, s.ops, s.by_kind[0], s.by_kind[1], s.by_kind[2], s.by_kind[3], s.by_kind[4], s.by_kind[5], s.by_kind[6],
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
+  printf("[ACEHIP] hw queue: %zu distinct result limbs, %zu of them in blocks freed before the flush\n", s.res_limbs, s.res_limbs_freed);
 }
 // ---- pairing of Mod_down / Rescale calls, speculative ModUp of all digits ----
 // Generated code handles the two polynomials of a ciphertext with two consecutive calls (Mod_down(c0); Mod_down(c1),
@@ -200,6 +203,17 @@ void queue_submit() {
       lim *= 4;
     }
     st.hist[b]++;
+    std::vector<const u64*> res;
+    for (const auto& o : g_hwq) res.push_back(o.res);
+    std::sort(res.begin(), res.end());
+    res.erase(std::unique(res.begin(), res.end()), res.end());
+    st.res_limbs += res.size();
+    for (const u64* r : res)
+      for (const auto& b : pool_limbo)
+        if (r >= b.first && r < b.first + b.second) {
+          ++st.res_limbs_freed;
+          break;
+        }
   }
   const int rc = acehip_hw_batch(ctx().hip, g_hwq.data(), g_hwq.size(), nullptr);
   g_hwq.clear();

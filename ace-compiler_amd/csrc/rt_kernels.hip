@@ -30,6 +30,7 @@ void launch_center(const DevCtx& c, int64_t* out, const u64* in, u32 gi, hipStre
 }
 
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
   dim3 grid((c.N + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(values_to_rns_kernel, grid, block, 0, s, c, out, vals, level, pos0);
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(DevCtx c, u64* __re
 }
 
 void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
   dim3 grid((c.N + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(sample_uniform_kernel, grid, block, 0, s, c, out, level, pos0, seed);
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void add_scalars_kernel(DevCtx c, u64* __restr
 
 void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs,
                         hipStream_t s) {
+  ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(add_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);
@@ -96,6 +99,7 @@ void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts&
 
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs,
                         hipStream_t s) {
+  ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
   dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
   hipLaunchKernelGGL(mul_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);

@@ -54,6 +54,42 @@ __device__ __forceinline__ u64 shoup4_hyb(u64 a, u64 w, u64 p, u64 nq) {
   c = mad64(h1, n0, c);
   return (u64)(u32)t | ((u64)((u32)(t >> 32) + (u32)c) << 32);
 }
+// opaque barriers: no instruction, but the compiler must materialise the full 64-bit value, which stops it from narrowing
+// a product to v_mul_lo_u32 / v_mul_hi_u32 (quarter rate) -- it emits v_mad_u64_u32 and allocates the pairs itself
+#define OPQ(x) asm("" : "+v"(x))
+__device__ __forceinline__ u64 shoup4_opq(u64 a, u64 w, u64 p, u64 nq) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+  const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  u64 U = (u64)a0 * p1;
+  OPQ(U);
+  u64 V = (u64)a1 * p0;
+  OPQ(V);
+  const u64 h = (u64)a1 * p1 + (U >> 32) + (V >> 32);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32);
+  u64 c = (u64)a0 * w1;
+  c += (u64)a1 * w0;
+  c += (u64)h0 * n1;
+  c += (u64)h1 * n0;
+  OPQ(c);
+  u64 t = (u64)a0 * w0;
+  t += (u64)h0 * n0;
+  return t + ((u64)(u32)c << 32);
+}
+// quotient by mul_hi (compiler), low products as opaque mad chains
+__device__ __forceinline__ u64 shoup4_opq2(u64 a, u64 w, u64 p, u64 nq) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+  const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  const u64 h = (u64)a1 * p1 + __umulhi(a0, p1) + __umulhi(a1, p0);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32);
+  u64 c = (u64)a0 * w1;
+  c += (u64)a1 * w0;
+  c += (u64)h0 * n1;
+  c += (u64)h1 * n0;
+  OPQ(c);
+  u64 t = (u64)a0 * w0;
+  t += (u64)h0 * n0;
+  return t + ((u64)(u32)c << 32);
+}
 template <int V> __global__ __launch_bounds__(256) void k(u64* out, u64 seed, int check) {
   const u64 q = 0x100000001a40001ull;  // a 57-bit prime of the C3 chain
   u64 a[4];
@@ -69,6 +105,8 @@ template <int V> __global__ __launch_bounds__(256) void k(u64* out, u64 seed, in
       if (V == 1) r = shoup4_c(a[i], w, p, q);
       if (V == 2) r = shoup4_mad(a[i], w, p, nq);
       if (V == 3) r = shoup4_hyb(a[i], w, p, nq);
+      if (V == 4) r = shoup4_opq(a[i], w, p, nq);
+      if (V == 5) r = shoup4_opq2(a[i], w, p, nq);
       a[i] = r + it;  // keeps the chain dependent and the operand < 2^63
     }
   }
@@ -102,6 +140,12 @@ int main() {
   run<3>(d, "sloppy Shoup (mul_hi quotient, mad chains)");
   hipMemcpy(h2, d, 8 * 256 * 4096, hipMemcpyDeviceToHost);
   size_t bad = 0;
+  for (size_t i = 0; i < 256 * 4096; ++i) bad += h1[i] != h2[i];
+  run<4>(d, "sloppy Shoup (opaque barriers, all mad)");
+  hipMemcpy(h2, d, 8 * 256 * 4096, hipMemcpyDeviceToHost);
+  for (size_t i = 0; i < 256 * 4096; ++i) bad += h1[i] != h2[i];
+  run<5>(d, "sloppy Shoup (mul_hi quotient, opaque mad)");
+  hipMemcpy(h2, d, 8 * 256 * 4096, hipMemcpyDeviceToHost);
   for (size_t i = 0; i < 256 * 4096; ++i) bad += h1[i] != h2[i];
   printf("variant 2 vs 1: %zu mismatching lanes\n", bad);
   return bad != 0;
