@@ -5,16 +5,20 @@
 // per workgroup.  N = 2^16 is exactly two passes:
 //   STRIDED pass: stages [0,8)          rows = index bits [logN-8, logN), 16 adjacent columns/tile
 //   CONTIG  pass: stages [logN-8,logN)  16 consecutive 256-coefficient blocks per tile
-// The kernels are bound by 32-bit integer multiplies (tools/ubench_int.hip), so the butterflies are built to need as
-// few of them, and as little else, as possible:
-//   * twiddle products use a "sloppy" Shoup reduction (shoup4): the quotient estimate takes three of the four partial
-//     products of a * floor(w*2^64/q), is at most 3 below the true quotient, and the result lies in [0,4q) -- 9
-//     multiply instructions instead of 10 and none of the register shuffling of a full 64x64 high product;
-//   * forward transforms of primes with 65q < 2^64 (every q-limb of the 50..57-bit scaling primes) never reduce the
-//     butterfly sums: values grow by 4q per stage, stay below 65q over the 16 stages (33q between the passes) and
-//     are reduced once, at the very end (quotient from floor(2^64/q));  larger primes (q0, the P primes, < 2^61) keep
-//     values in [0,8q) with one conditional subtraction of 4q per butterfly;
-//   * inverse transforms keep values in [0,4q) (one conditional subtraction per butterfly).
+// The kernels are bound by VALU issue: on gfx950 every VOP3 / 64-bit instruction (v_mad_u64_u32, v_lshl_add_u64, v_mul_lo_u32,
+// v_cmp_*_u64 ...) costs the same ~4 cycles per wave and a plain VOP1/VOP2 ~2 (tools/ubench_ops.hip), so the butterflies are
+// built to need as few INSTRUCTIONS as possible, not only as few multiplies:
+//   * twiddle products use a "sloppy" Shoup reduction: the quotient estimate takes three of the four partial products of
+//     a * companion and every partial product is a v_mad_u64_u32 whose 64-bit accumulate is free -- 9 multiply-adds per product;
+//   * SMALL primes (81q < 2^63: every q-limb of the 50..56-bit scaling primes): values stay below 2^63 and the companion is
+//     used as floor(w*2^63/q), so the two cross products of the quotient add without carry in ONE accumulation chain (3
+//     instructions + a move); the product comes out in [0,5q).  Forward transforms never reduce the butterfly sums: the low
+//     product chain starts from x, so X' = x + m costs no instruction of its own, Y' = (2x + 4q) - X' one shift-add and one
+//     64-bit subtraction (15 instructions per butterfly); values grow by 5q per stage, stay below 81q over the 16 stages and
+//     are reduced once, at the very end (quotient from floor(2^64/q));
+//   * larger primes (q0, the P primes, < 2^61) use a 64-bit companion (shoup4, result in [0,4q)) and keep values in [0,8q) with
+//     one conditional subtraction of 4q per forward butterfly;
+//   * inverse transforms keep values in [0,5q) (SMALL) or [0,4q) with one conditional subtraction per butterfly.
 // The last pass writes canonical residues in [0,q), so results are bit-identical to the reference (ntt.c:190-353),
 // which keeps every intermediate canonical.  Twiddles come from the interleaved {w, floor(w*2^64/q)} tables (16-byte
 // loads); workgroups that share twiddles are placed on one XCD (kernels.hpp ntt_block).
@@ -31,31 +35,37 @@ struct Tw {
 #define NTT_EXP 0  // timing experiments only (results are wrong): 1 no butterflies, 2 no data loads/stores, 4 no twiddle loads,
                    // 8 no strided pass at all (what a one-pass transform would save)
 #endif
+// SMALL: the companion is used as floor(w*2^63/q) = floor(w*2^64/q) >> 1 (see shoup5_add)
+template <bool SMALL>
 __device__ __forceinline__ Tw ldtw(const ulong2* __restrict__ t, u32 idx) {
 #if NTT_EXP & 4
-  return Tw{(u64)idx * 0x9E3779B97F4A7C15ull, (u64)idx * 0xC2B2AE3D27D4EB4Full + threadIdx.x};
+  return Tw{(u64)idx * 0x9E3779B97F4A7C15ull, ((u64)idx * 0xC2B2AE3D27D4EB4Full + threadIdx.x) >> 1};
 #else
   const ulong2 v = t[idx];
-  return Tw{v.x, v.y};
+  return Tw{v.x, SMALL ? v.y >> 1 : v.y};
 #endif
 }
 
 // a*w mod q in [0,2q) for any 64-bit a (exact Shoup quotient: at most 1 below the true quotient)
 __device__ __forceinline__ u64 shoup_lazy(u64 a, Tw t, u64 q) { return a * t.w - mulhi64(a, t.p) * q; }
 
-// a*w mod q in [0,4q) for any 64-bit a: quotient estimate h = a1*p1 + hi32(a0*p1) + hi32(a1*p0), which is
-// floor(a*wp/2^64) less at most 2 (the dropped a0*p0 and the two truncated cross terms), itself at most 1 below
-// floor(a*w/q)
-// Every partial product is written as a full 32x32->64 product and pinned by an empty asm, so that the compiler emits
-// v_mad_u64_u32 (with its free 64-bit accumulate) for it instead of narrowing to the quarter-rate v_mul_lo_u32 /
-// v_mul_hi_u32: 9 v_mad_u64_u32 per product and no separate 64-bit subtraction (the result is a*w + h*(2^64-q)).
 #define ACEHIP_PIN(x) asm("" : "+v"(x))
-__device__ __forceinline__ u64 shoup4(u64 a, Tw t, u64 q) {
+// {r.lo, r.hi + c.lo}: the low product chain r and the cross-term chain c of a 64-bit product joined with ONE 32-bit add
+// (inline asm keeps the compiler from rewriting it as a 64-bit add of a shifted value: two moves and a v_lshl_add_u64)
+__device__ __forceinline__ u64 join_hi_add(u64 r, u64 c) {
+  u32 rhi;
+  asm("v_add_u32 %0, %1, %2" : "=v"(rhi) : "v"((u32)(r >> 32)), "v"((u32)c));
+  return ((u64)rhi << 32) | (u32)r;
+}
+
+// addend + (a*w - h*q) mod 2^64 with a*w - h*q in [0,4q), for any 64-bit a: quotient estimate
+// h = a1*p1 + hi32(a0*p1) + hi32(a1*p0), which is floor(a*wp/2^64) less at most 2 (the dropped a0*p0 and the two truncated
+// cross terms), itself at most 1 below floor(a*w/q).
+// Every partial product is written as a full 32x32->64 product and pinned by an empty asm, so that the compiler emits
+// v_mad_u64_u32 (with its free 64-bit accumulate) for it instead of narrowing to v_mul_lo_u32 / v_mul_hi_u32: 9
+// v_mad_u64_u32 per product and no separate 64-bit subtraction (the result is a*w + h*(2^64-q)).
+__device__ __forceinline__ u64 shoup4_add(u64 a, Tw t, u64 q, u64 addend) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)t.p, p1 = (u32)(t.p >> 32);
-#ifdef ACEHIP_SHOUP_COMPILER_MULS
-  const u64 h = (u64)a1 * p1 + __umulhi(a0, p1) + __umulhi(a1, p0);
-  return a * t.w - h * q;
-#else
   const u32 w0 = (u32)t.w, w1 = (u32)(t.w >> 32);
   const u64 nq = 0 - q;
   const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
@@ -70,38 +80,81 @@ __device__ __forceinline__ u64 shoup4(u64 a, Tw t, u64 q) {
   c += (u64)h0 * n1;
   c += (u64)h1 * n0;
   ACEHIP_PIN(c);
-  u64 r = (u64)a0 * w0;
+  u64 r = (u64)a0 * w0 + addend;
   r += (u64)h0 * n0;
   ACEHIP_PIN(r);
-  return r + ((u64)(u32)c << 32);
-#endif
+  return join_hi_add(r, c);
 }
 
-// primes for which 16 forward stages without any reduction stay below 2^64: q + 16*4q = 65q
-constexpr u64 kSmallPrimeMax = ~0ull / 65;
+// SMALL primes: addend + (a*w - 2h*q) mod 2^64 for a < 2^63 and t.p = floor(w*2^63/q) < 2^63 (ldtw<true>), nq2 = -2q.
+// The cross products a0*p1 + a1*p0 cannot carry out of 64 bits (a1, p1 < 2^31), so the quotient estimate is one chain:
+// h = a1*p1 + hi32(a0*p1 + a1*p0) >= floor(a*p/2^64) - 1, 2h > a*w/q - 5, and the product a*w - 2h*q lies in [0,5q).
+__device__ __forceinline__ u64 shoup5_add(u64 a, Tw t, u64 nq2, u64 addend) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)t.p, p1 = (u32)(t.p >> 32);
+  const u32 w0 = (u32)t.w, w1 = (u32)(t.w >> 32), m0 = (u32)nq2, m1 = (u32)(nq2 >> 32);
+  u64 M = (u64)a0 * p1;
+  M += (u64)a1 * p0;
+  ACEHIP_PIN(M);
+  const u64 h = (u64)a1 * p1 + (M >> 32);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32);
+  u64 c = (u64)a0 * w1;
+  c += (u64)a1 * w0;
+  c += (u64)h0 * m1;
+  c += (u64)h1 * m0;
+  ACEHIP_PIN(c);
+  u64 r = (u64)a0 * w0 + addend;
+  r += (u64)h0 * m0;
+  ACEHIP_PIN(r);
+  return join_hi_add(r, c);
+}
 
-// forward (Cooley-Tukey) lazy butterfly.  SMALL: X,Y < B -> X,Y < B + 4q, no reduction.
+// SMALL primes: 16 forward stages without any reduction grow a canonical input to q + 16*5q = 81q, which must stay below
+// 2^63 (shoup5_add); the inverse keeps values below 10q
+constexpr u64 kSmallPrimeMax = (~0ull >> 1) / 81;
+
+// per-prime constants of the butterflies: SMALL: lim = 5q (inverse range), nq = -2q; otherwise lim = 4q, nq unused
+struct BfK {
+  u64 q, q4, lim, nq;
+};
+// (pinned to SGPRs: otherwise the compiler re-derives 5q inside every butterfly with a multiply-add and an add)
+template <bool SMALL>
+__device__ __forceinline__ BfK bf_consts(u64 q) {
+  BfK k{q, 4 * q, SMALL ? 5 * q : 4 * q, SMALL ? 0 - 2 * q : 0 - q};
+  asm("" : "+s"(k.q4));
+  asm("" : "+s"(k.lim));
+  asm("" : "+s"(k.nq));
+  return k;
+}
+
+// forward (Cooley-Tukey) lazy butterfly.  SMALL: X,Y < B -> X,Y < B + 5q, no reduction.
 // !SMALL: X,Y in [0,8q) -> [0,8q) (q < 2^61)
 template <bool SMALL>
-__device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, u64 q, u64 q4) {
+__device__ __forceinline__ void bf_fwd(u64& X, u64& Y, Tw t, const BfK& k) {
 #if NTT_EXP & 1
   X ^= t.w; Y += t.p;
   return;
 #endif
-  u64 x = X;
-  if (!SMALL) x = X >= q4 ? X - q4 : X;
-  const u64 m = shoup4(Y, t, q);
-  X = x + m;
-  Y = x + q4 - m;
+  if (SMALL) {
+    const u64 x = X;
+    const u64 nx = shoup5_add(Y, t, k.nq, x);  // x + m: the low product chain starts from x
+    X = nx;
+    Y = (x << 1) + k.lim - nx;                 // x + 5q - m  (m < 5q), as (2x + 5q) - (x + m): one shift-add, one subtraction
+  } else {
+    const u64 x = X >= k.q4 ? X - k.q4 : X;
+    const u64 nx = shoup4_add(Y, t, k.q, x);   // x + m, m < 4q
+    X = nx;
+    Y = (x << 1) + k.q4 - nx;
+  }
 }
-// inverse (Gentleman-Sande) lazy butterfly: X,Y in [0,4q) -> [0,4q)
-__device__ __forceinline__ void bf_inv(u64& X, u64& Y, Tw t, u64 q, u64 q4) {
+// inverse (Gentleman-Sande) lazy butterfly: X,Y in [0,lim) -> [0,lim), lim = 5q (SMALL) or 4q
+template <bool SMALL>
+__device__ __forceinline__ void bf_inv(u64& X, u64& Y, Tw t, const BfK& k) {
   const u64 s = X + Y;
-  const u64 d = X + q4 - Y;
-  X = s >= q4 ? s - q4 : s;
-  Y = shoup4(d, t, q);
+  const u64 d = X + k.lim - Y;
+  X = s >= k.lim ? s - k.lim : s;
+  Y = SMALL ? shoup5_add(d, t, k.nq, 0) : shoup4_add(d, t, k.q, 0);
 }
-// canonical residue of a forward result: v < 65q (SMALL; mu = floor(2^64/q)) or v < 8q
+// canonical residue of a forward result: v < 81q (SMALL; mu = floor(2^64/q)) or v < 8q
 template <bool SMALL>
 __device__ __forceinline__ u64 canon_fwd(u64 v, u64 q, u64 mu) {
   if (SMALL) {
@@ -117,50 +170,53 @@ __device__ __forceinline__ u64 canon_fwd(u64 v, u64 q, u64 mu) {
 // 4 forward stages on 16 registers; stage u pairs (k, k + (8>>u)), twiddle T_u[k / (16>>u)]
 template <bool SMALL>
 __device__ __forceinline__ void radix16_fwd(u64 (&x)[16], const Tw& t0, const Tw (&t1)[2], const Tw (&t2)[4],
-                                            const Tw (&t3)[8], u64 q, u64 q4) {
+                                            const Tw (&t3)[8], const BfK& k) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bf_fwd<SMALL>(x[k], x[k + 8], t0, q, q4);
+  for (int i = 0; i < 8; ++i) bf_fwd<SMALL>(x[i], x[i + 8], t0, k);
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bf_fwd<SMALL>(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q4);
+    for (int i = 0; i < 4; ++i) bf_fwd<SMALL>(x[8 * g + i], x[8 * g + i + 4], t1[g], k);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) bf_fwd<SMALL>(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q4);
+    for (int i = 0; i < 2; ++i) bf_fwd<SMALL>(x[4 * g + i], x[4 * g + i + 2], t2[g], k);
 #pragma unroll
-  for (int g = 0; g < 8; ++g) bf_fwd<SMALL>(x[2 * g], x[2 * g + 1], t3[g], q, q4);
+  for (int g = 0; g < 8; ++g) bf_fwd<SMALL>(x[2 * g], x[2 * g + 1], t3[g], k);
 }
 
 // 4 inverse stages (u = 3..1); stage u = 0 is handled by the caller (it may carry the N^-1 fold)
+template <bool SMALL>
 __device__ __forceinline__ void radix16_inv_321(u64 (&x)[16], const Tw (&t1)[2], const Tw (&t2)[4], const Tw (&t3)[8],
-                                                u64 q, u64 q4) {
+                                                const BfK& k) {
 #pragma unroll
-  for (int g = 0; g < 8; ++g) bf_inv(x[2 * g], x[2 * g + 1], t3[g], q, q4);
+  for (int g = 0; g < 8; ++g) bf_inv<SMALL>(x[2 * g], x[2 * g + 1], t3[g], k);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) bf_inv(x[4 * g + k], x[4 * g + k + 2], t2[g], q, q4);
+    for (int i = 0; i < 2; ++i) bf_inv<SMALL>(x[4 * g + i], x[4 * g + i + 2], t2[g], k);
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bf_inv(x[8 * g + k], x[8 * g + k + 4], t1[g], q, q4);
+    for (int i = 0; i < 4; ++i) bf_inv<SMALL>(x[8 * g + i], x[8 * g + i + 4], t1[g], k);
 }
-__device__ __forceinline__ void radix16_inv_0(u64 (&x)[16], const Tw& t0, u64 q, u64 q4) {
+template <bool SMALL>
+__device__ __forceinline__ void radix16_inv_0(u64 (&x)[16], const Tw& t0, const BfK& k) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bf_inv(x[k], x[k + 8], t0, q, q4);
+  for (int i = 0; i < 8; ++i) bf_inv<SMALL>(x[i], x[i + 8], t0, k);
 }
 
 // twiddles of the 16-group with index `prefix` at stage `sbase`: T_u[i] = TW[2^(sbase+u) + (prefix<<u) + i]
+template <bool SMALL>
 __device__ __forceinline__ void load_tw(const ulong2* __restrict__ TW, u32 sbase, u32 prefix, Tw& t0, Tw (&t1)[2],
                                         Tw (&t2)[4], Tw (&t3)[8]) {
-  t0 = ldtw(TW, (1u << sbase) + prefix);
+  t0 = ldtw<SMALL>(TW, (1u << sbase) + prefix);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) t1[i] = ldtw(TW, (2u << sbase) + (prefix << 1) + i);
+  for (int i = 0; i < 2; ++i) t1[i] = ldtw<SMALL>(TW, (2u << sbase) + (prefix << 1) + i);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t2[i] = ldtw(TW, (4u << sbase) + (prefix << 2) + i);
+  for (int i = 0; i < 4; ++i) t2[i] = ldtw<SMALL>(TW, (4u << sbase) + (prefix << 2) + i);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t3[i] = ldtw(TW, (8u << sbase) + (prefix << 3) + i);
+  for (int i = 0; i < 8; ++i) t3[i] = ldtw<SMALL>(TW, (8u << sbase) + (prefix << 3) + i);
 }
 
 // One limb seen through a buffer descriptor: addresses are descriptor (SGPRs) + one 32-bit per-lane byte offset + a scalar
@@ -211,13 +267,14 @@ struct StridedArgs {
   static constexpr u32 log_s = 8;
 };
 
-// forward: rows 16k+hg are read in place unless FROM_MSG filled x[]; the result (lazy: < 33q SMALL, < 8q otherwise) is
+// forward: rows 16k+hg are read in place unless FROM_MSG filled x[]; the result (lazy: < 41q SMALL, < 8q otherwise) is
 // stored in place.  The two prime classes are separate code regions from the first load to the last store (one
 // scalar branch at the top): sharing the loads lets the compiler hoist both paths' twiddles above the branch, which
 // costs half of the occupancy.
 template <bool SMALL, bool FROM_MSG>
 __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 z, u32 n_bytes) {
-  const u64 q = a.q, q4 = 4 * q;
+  const u64 q = a.q;
+  const BfK bk = bf_consts<SMALL>(q);
   u64 x[16];
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch (no hoisting / merging across paths)
@@ -238,19 +295,66 @@ __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const Dev
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, (a.hg << 11) + a.col * 8, (u32)k << 15);  // row 16k+hg, row pitch 2 KiB
   }
-  load_tw(a.TW, 0, 0, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
-  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+  load_tw<SMALL>(a.TW, 0, 0, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) a.lds[(16 * k + a.hg) * kRowPitch + a.cc] = x[k];
-  load_tw(a.TW, 4, a.hg, t0, t1, t2, t3);
+  load_tw<SMALL>(a.TW, 4, a.hg, t0, t1, t2, t3);
   __syncthreads();
   // round B: stages 4..7
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = a.lds[(16 * a.hg + k) * kRowPitch + a.cc];
-  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) bst(a.buf, (a.hg << 15) + a.col * 8, (u32)k << 11, x[k]);  // row 16hg+k
   asm volatile("" ::: "memory");  // and its stores above the join
+}
+
+// inverse: round B first (stages 7..4 on rows 16h+g'; input lazy [0,lim) from the contiguous pass), then round A (stages
+// 3..1 and stage 0 with N^-1 -- or the caller's scale -- folded in); canonical (or centred) output
+template <bool SMALL>
+__device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
+                                                 const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
+  constexpr u32 log_s = 8;
+  const u64 q = P.q;
+  const BfK bk = bf_consts<SMALL>(q);
+  u64 x[16];
+  Tw t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * hg + k) << log_s) + col];
+  load_tw<SMALL>(TW, 4, hg, t0, t1, t2, t3);
+  radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+  radix16_inv_0<SMALL>(x, t0, bk);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
+  load_tw<SMALL>(TW, 0, 0, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
+  radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+  Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+  if (f.inv_scale) {
+    const u64* sc = f.inv_scale + 4 * (size_t)pos;
+    tn = Tw{sc[0], sc[1]};
+    tw = Tw{sc[2], sc[3]};
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u64 s = x[k] + x[k + 8];            // [0,2 lim)
+    const u64 d = x[k] + bk.lim - x[k + 8];   // (0,2 lim)
+    u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);  // exact quotient: [0,2q)
+    x[k] = a >= q ? a - q : a;
+    x[k + 8] = b >= q ? b - q : b;
+  }
+  if (f.center_out) {
+    const u64 half = q >> 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = x[k] > half ? x[k] - q : x[k];  // two's complement of the negative lift
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) X[((size_t)(16 * k + hg) << log_s) + col] = x[k];
+  asm volatile("" ::: "memory");
 }
 
 // FROM_MSG (forward only): the input of every limb is the signed message f.msg reduced mod the limb's prime
@@ -286,43 +390,8 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
     if (q <= kSmallPrimeMax) strided_fwd_body<true, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
     else                     strided_fwd_body<false, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
   } else {
-    u64 x[16];
-    Tw t0, t1[2], t2[4], t3[8];
-    // round B first: stages 7..4 on rows 16h+g'; input lazy [0,4q) from the contiguous pass
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = X[((size_t)(16 * hg + k) << log_s) + col];
-    load_tw(TW, 4, hg, t0, t1, t2, t3);
-    radix16_inv_321(x, t1, t2, t3, q, q4);
-    radix16_inv_0(x, t0, q, q4);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
-    load_tw(TW, 0, 0, t0, t1, t2, t3);
-    __syncthreads();
-    // round A: stages 3..1, then stage 0 with N^-1 folded in, canonical output
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
-    radix16_inv_321(x, t1, t2, t3, q, q4);
-    Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
-    if (f.inv_scale) {
-      const u64* sc = f.inv_scale + 4 * (size_t)pos;
-      tn = Tw{sc[0], sc[1]};
-      tw = Tw{sc[2], sc[3]};
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u64 s = x[k] + x[k + 8];            // [0,8q)
-      const u64 d = x[k] + q4 - x[k + 8];       // (0,8q)
-      u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);  // exact quotient: [0,2q)
-      x[k] = a >= q ? a - q : a;
-      x[k + 8] = b >= q ? b - q : b;
-    }
-    if (f.center_out) {
-      const u64 half = q >> 1;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = x[k] > half ? x[k] - q : x[k];  // two's complement of the negative lift
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) X[((size_t)(16 * k + hg) << log_s) + col] = x[k];
+    if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, pos, cc, hg, col);
+    else                     strided_inv_body<false>(X, TW, lds, P, f, pos, cc, hg, col);
   }
 }
 
@@ -332,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 // hold rho = 16k+g (each load instruction reads whole 128-byte lines); round B lanes (h = tid&15, b)
 // hold the 16 contiguous rho = 16h+g'.  The contiguous side goes through LDS so that global accesses
 // stay 16 bytes per lane, 1 KiB contiguous per wave instruction.
-// CANON_OUT (inverse only): write canonical values instead of lazy [0,4q) (needed when a generic
+// CANON_OUT (inverse only): write canonical values instead of lazy [0,lim) (needed when a generic
 // pass follows instead of the strided fast pass).
 // ------------------------------------------------------------------------------------------------
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
@@ -340,7 +409,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 template <bool SMALL>
 __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, u32 s8, u32 o,
                                                 u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
-  const u64 q4 = 4 * q;
+  const BfK bk = bf_consts<SMALL>(q);
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
 #pragma unroll
@@ -349,18 +418,63 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
 #else
   for (int k = 0; k < 16; ++k) x[k] = X[b * 256 + 16 * k + lo4];
 #endif
-  load_tw(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
-  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+  load_tw<SMALL>(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
-  load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
   __syncthreads();
   // round B: stages s8+4..s8+7 on rho = 16h + g'
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-  radix16_fwd<SMALL>(x, t0, t1, t2, t3, q, q4);
+  radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = canon_fwd<SMALL>(x[k], q, mu);
+}
+
+// inverse rounds: the tile is read from S (coalesced 16-byte loads through LDS), round B first (stages s8+7..s8+4 on the 16
+// contiguous rho = 16h + g'), then round A (stages s8+3..s8 on rho = 16k + g); lazy [0,lim) output unless CANON_OUT
+template <bool SMALL, bool CANON_OUT>
+__device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW, u64* lds,
+                                                u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
+  const BfK bk = bf_consts<SMALL>(q);
+  const u32 tid = threadIdx.x;
+  u64 x[16];
+  Tw t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
+    const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
+    const ulong2 v = *reinterpret_cast<const ulong2*>(S + e);
+    lds[bb * kBlkPitch + cpad(rho)] = v.x;
+    lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
+  }
+  load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
+  radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+  radix16_inv_0<SMALL>(x, t0, bk);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
+  load_tw<SMALL>(TW, s8, o, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * k + lo4];
+  radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+  radix16_inv_0<SMALL>(x, t0, bk);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    u64 v = x[k];  // [0,lim)
+    if (CANON_OUT) {
+      if (SMALL) v = v >= 4 * q ? v - 4 * q : v;
+      v = v >= 2 * q ? v - 2 * q : v;
+      v = v >= q ? v - q : v;
+    }
+    X[b * 256 + 16 * k + lo4] = v;
+  }
+  asm volatile("" ::: "memory");
 }
 
 // FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
@@ -422,42 +536,10 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
       *reinterpret_cast<ulong2*>(dst + e) = v;
     }
   } else {
-    Tw t0, t1[2], t2[4], t3[8];
     const u64* __restrict__ S =
         FUSE ? (blk.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)blk.tile * 4096 : X;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
-      const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-      const ulong2 v = *reinterpret_cast<const ulong2*>(S + e);
-      lds[bb * kBlkPitch + cpad(rho)] = v.x;
-      lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
-    }
-    load_tw(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
-    __syncthreads();
-    // round B first: stages s8+7..s8+4 on the 16 contiguous rho = 16h + g'
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-    radix16_inv_321(x, t1, t2, t3, q, q4);
-    radix16_inv_0(x, t0, q, q4);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
-    load_tw(TW, s8, o, t0, t1, t2, t3);
-    __syncthreads();
-    // round A: stages s8+3..s8 on rho = 16k + g
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * k + lo4];
-    radix16_inv_321(x, t1, t2, t3, q, q4);
-    radix16_inv_0(x, t0, q, q4);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      u64 v = x[k];  // [0,4q)
-      if (CANON_OUT) {
-        v = v >= 2 * q ? v - 2 * q : v;
-        v = v >= q ? v - q : v;
-      }
-      X[b * 256 + 16 * k + lo4] = v;
-    }
+    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
+    else                     contig_inv_body<false, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
   }
 }
 
