@@ -410,6 +410,16 @@ static const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit) {
   return &(c->modup[key] = d);
 }
 
+// The base conversion can ride in the first pass of the following forward NTT (N = 2^16: ntt_fast.hip SRC_CONV*): the converted
+// limbs are then never written / re-read in coefficient form (-104 MB of HBM traffic per C3 key-switch), but every output limb
+// re-reads its alpha sources through L2 and the pass becomes VALU-bound.  Measured (MI355X, round 2): key-switch 0.256 ms
+// either way, ResNet-20 1.51 images/s fused vs 1.56 unfused -- so it is OFF unless ACEHIP_CONV_FUSION=1 (bit-exact both ways,
+// tests/test_gpu_parity.py::test_conv_fusion_matches).
+static bool conv_fusable(const acehip_ctx* c, u32 n_in) {
+  static const bool on = [] { const char* e = getenv("ACEHIP_CONV_FUSION"); return e && *e == '1'; }();
+  return on && c->dc.logN == 16 && c->dc.split_bits <= 30 && n_in <= 12;
+}
+
 // workspace carving (in limbs of N words)
 static u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
 static const KsPlan* get_ks_plan(acehip_ctx* c, u32 level);
@@ -1039,9 +1049,17 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
     launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
   }
   // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
-  launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s, hp.K);
+  const bool conv_in_ntt = conv_fusable(c, hp.K);
+  if (!conv_in_ntt) launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s, hp.K);
   if (c->dc.logN == 16) {
     NttFuse fo;
+    if (conv_in_ntt) {  // the conversion P -> Q rides in the first pass of the NTT
+      fo.conv = plan->d_descs + plan->nd;
+      fo.conv_step = 0;
+      fo.conv_max_in = hp.K;
+      fo.conv_src = pc - QL;
+      fo.conv_src_stride = PK;
+    }
     fo.epi = 2;
     fo.out0 = out0;
     fo.out1 = out1;
@@ -1333,11 +1351,22 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
     HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
     launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
   }
-  // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the load), one launch
-  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
-  // 3. NTT of every digit's complement limbs, one launch (own digit limbs are skipped)
-  launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E,
-             hp.alpha);
+  // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the inverse NTT) and
+  // 3. the NTT of every digit's complement limbs (own digit limbs are skipped): at N = 2^16 one pipeline, the conversion
+  //    is computed by the first NTT pass while it loads its input
+  const u32 n_ext_rows = level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1));
+  if (conv_fusable(c, hp.alpha)) {
+    NttFuse fc;
+    fc.conv = plan->d_descs;
+    fc.conv_step = 1;
+    fc.conv_max_in = hp.alpha;
+    fc.conv_src = coef;
+    fc.conv_src_stride = 0;
+    launch_ntt_fused(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
+  } else {
+    launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
+    launch_ntt(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
+  }
   // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
   launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
   // 5. ModDown of both accumulators together (polynomial.c:928-967)
@@ -1348,9 +1377,17 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   } else {
     launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
   }
-  launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
-  if (fused) {  // the ModDown tail rides in the last NTT pass
+  const bool conv_in_ntt = fused && conv_fusable(c, hp.K);
+  if (!conv_in_ntt) launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
+  if (fused) {  // the ModDown tail rides in the last NTT pass, the conversion P -> Q in the first
     NttFuse fo;
+    if (conv_in_ntt) {
+      fo.conv = plan->d_descs + nd;
+      fo.conv_step = 0;
+      fo.conv_max_in = hp.K;
+      fo.conv_src = acc0;
+      fo.conv_src_stride = E;
+    }
     fo.epi = 2;
     fo.out0 = out0;
     fo.out1 = out1;
@@ -1544,8 +1581,19 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
     HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
     launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
   }
-  launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
-  launch_ntt(c->dc, ext, level, 0, level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1)), false, s, 0, nd, E, hp.alpha);
+  const u32 n_ext_rows = level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1));
+  if (conv_fusable(c, hp.alpha)) {  // the conversions ride in the first pass of the NTT
+    NttFuse fc;
+    fc.conv = plan->d_descs;
+    fc.conv_step = 1;
+    fc.conv_max_in = hp.alpha;
+    fc.conv_src = coef;
+    fc.conv_src_stride = 0;
+    launch_ntt_fused(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
+  } else {
+    launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
+    launch_ntt(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
+  }
   {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
     HwBatchArgs cp;
     u32 n_ops = 0;

@@ -98,6 +98,14 @@ struct NttFuse {
   const int64_t* msg = nullptr;
   size_t msg_stride = 0;          // polynomial z reads msg + z*msg_stride
   const u64* msg_scale = nullptr;
+  // forward, first pass: the input of polynomial z is the fast base conversion (Decompose_modup polynomial.c:1302-1320,
+  // Reduce_rns_base :928-967) of coefficient-domain source limbs, computed on the fly: limb row y of the launch is output j = y
+  // of descriptor conv[z*conv_step] (n_in <= conv_max_in <= 12 sources, no `scale`: pre-factors folded into the inverse NTT
+  // before); sources are read from conv_src + z*conv_src_stride at limb positions src_pos0.. .  Needs split_bits <= 30.
+  const ConvDesc* conv = nullptr;
+  u32 conv_step = 0, conv_max_in = 0;
+  const u64* conv_src = nullptr;
+  size_t conv_src_stride = 0;
   // inverse, last pass: store the centred representative (x > q/2 ? x - q : x, as int64) instead of x, i.e. the
   // `msg` of a following forward transform over other primes (Rescale, ModRaise)
   bool center_out = false;

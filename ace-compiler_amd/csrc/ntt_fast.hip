@@ -219,6 +219,30 @@ __device__ __forceinline__ void load_tw(const ulong2* __restrict__ TW, u32 sbase
   for (int i = 0; i < 8; ++i) t3[i] = ldtw<SMALL>(TW, (8u << sbase) + (prefix << 3) + i);
 }
 
+// The 15 twiddles of stages 0..3 (TW[1..15]) are the same for every lane: read through the constant address space they
+// become scalar loads, live in SGPRs (60 of them instead of 60 VGPRs) and enter the multiply-adds as their one scalar operand.
+// (The tables are written once at context creation, never by a kernel.)
+typedef const __attribute__((address_space(4))) u64* ctw_ptr;
+template <bool SMALL>
+__device__ __forceinline__ void load_tw_uniform(const ulong2* __restrict__ TW, Tw& t0, Tw (&t1)[2], Tw (&t2)[4], Tw (&t3)[8]) {
+#if NTT_EXP & 4
+  load_tw<SMALL>(TW, 0, 0, t0, t1, t2, t3);
+#else
+  ctw_ptr T = (ctw_ptr)(reinterpret_cast<const u64*>(TW));
+  auto ld = [&](u32 i) {
+    const u64 w = T[2 * i], p = T[2 * i + 1];
+    return Tw{w, SMALL ? p >> 1 : p};
+  };
+  t0 = ld(1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) t1[i] = ld(2 + i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t2[i] = ld(4 + i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t3[i] = ld(8 + i);
+#endif
+}
+
 // One limb seen through a buffer descriptor: addresses are descriptor (SGPRs) + one 32-bit per-lane byte offset + a scalar
 // byte offset, so the 16 strided accesses of a lane share ONE address VGPR instead of 16 64-bit pairs (the difference
 // between 4 and 2 waves per SIMD for the forward strided pass).  `base` must be wave-uniform.
@@ -271,8 +295,14 @@ struct StridedArgs {
 // stored in place.  The two prime classes are separate code regions from the first load to the last store (one
 // scalar branch at the top): sharing the loads lets the compiler hoist both paths' twiddles above the branch, which
 // costs half of the occupancy.
-template <bool SMALL, bool FROM_MSG>
-__device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 z, u32 n_bytes) {
+// SRC: where x[] comes from: SRC_MEM the limb itself (in place), SRC_MSG the signed message f.msg reduced mod the limb's prime
+// (encode), SRC_CONV8/12 the fast base conversion of up to 8/12 coefficient-domain source limbs (ModUp / ModDown: the
+// converted limbs are never written in coefficient form; 16 sources would spill registers: those take the separate kernel)
+enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV8 = 8, SRC_CONV12 = 12 };
+template <bool SMALL, int SRC>
+__device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 row, u32 z,
+                                                 u32 n_bytes, u32 split_bits) {
+  constexpr bool FROM_MSG = SRC == SRC_MSG;
   const u64 q = a.q;
   const BfK bk = bf_consts<SMALL>(q);
   u64 x[16];
@@ -291,11 +321,47 @@ __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const Dev
       if (v < 0 && r != 0) r = q - r;
       x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
     }
+  } else if (SRC >= SRC_CONV8) {
+    // x[n] = ( sum_i y_i[n] * hat[i][row] ) mod q: exact 128-bit sum, one reduction (Reduce_rns_base polynomial.c:928-967,
+    // Decompose_modup :1302-1320); the pre-factors (Q_d/q_i)^-1 were folded into the inverse NTT that produced y.  Same
+    // arithmetic as base_conv_batch16_kernel (keyswitch.hip): halves of split_bits <= 30 bits, four carry-free
+    // multiply-add chains per term; the row's constants are wave-uniform (scalar registers).
+    constexpr int NI = SRC >= SRC_CONV8 ? SRC : 1;  // (the branch is dead for the other sources)
+    const ConvDesc& d = f.conv[z * f.conv_step];
+    const u32 n_in = d.n_in, jcol = d.col ? d.col[row] : row;
+    if (d.out_pos[row] != pos) __builtin_trap();  // the launch must enumerate the limbs like the descriptor does
+    const u32 h = split_bits, mask = (1u << h) - 1u;
+    const LimbBuf sbuf = limb_buf(f.conv_src + z * f.conv_src_stride, (d.src_pos0 + n_in) * n_bytes);
+    u32 b0[NI], b1[NI], soff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const u32 ii = min((u32)i, n_in - 1);  // rows past n_in: reload the last source, multiply by zero
+      const u64 b = (u32)i < n_in ? d.hat[(size_t)ii * d.hat_ld + jcol] : 0;
+      b0[i] = (u32)b & mask;
+      b1[i] = (u32)(b >> h);
+      soff[i] = (d.src_pos0 + ii) * n_bytes;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      u64 s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const u64 v = bld(sbuf, (a.hg << 11) + a.col * 8, ((u32)k << 15) + soff[i]);
+        const u32 a0 = (u32)v & mask, a1 = (u32)(v >> h);
+        s00 += (u64)a0 * b0[i];
+        s01 += (u64)a0 * b1[i];
+        s10 += (u64)a1 * b0[i];
+        s11 += (u64)a1 * b1[i];
+      }
+      const unsigned __int128 tot =
+          (unsigned __int128)s00 + (((unsigned __int128)s01 + s10) << h) + ((unsigned __int128)s11 << (2 * h));
+      x[k] = reduce128(U128{(u64)tot, (u64)(tot >> 64)}, q, P.prec128_lo, P.prec128_hi);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, (a.hg << 11) + a.col * 8, (u32)k << 15);  // row 16k+hg, row pitch 2 KiB
   }
-  load_tw<SMALL>(a.TW, 0, 0, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
+  load_tw_uniform<SMALL>(a.TW, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) a.lds[(16 * k + a.hg) * kRowPitch + a.cc] = x[k];
@@ -328,7 +394,7 @@ __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulon
   radix16_inv_0<SMALL>(x, t0, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
-  load_tw<SMALL>(TW, 0, 0, t0, t1, t2, t3);
+  load_tw_uniform<SMALL>(TW, t0, t1, t2, t3);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
@@ -357,14 +423,14 @@ __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulon
   asm volatile("" ::: "memory");
 }
 
-// FROM_MSG (forward only): the input of every limb is the signed message f.msg reduced mod the limb's prime
-template <bool INVERSE, bool FROM_MSG>
+// SRC (forward only): source of the first pass' input, see strided_fwd_body
+template <bool INVERSE, int SRC>
 __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
                                                            u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                            u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[256 * kRowPitch];
 #if NTT_EXP & 8
-  if (!FROM_MSG) return;
+  if (SRC != SRC_MSG) return;
 #endif
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   u32 pos, gi;
@@ -387,8 +453,8 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 
   if (!INVERSE) {
     const StridedArgs a{limb_buf(X, c.N * 8), TW, lds, cc, hg, col, q};
-    if (q <= kSmallPrimeMax) strided_fwd_body<true, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
-    else                     strided_fwd_body<false, FROM_MSG>(a, P, f, pos, blk.z, c.N * 8);
+    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(a, P, f, pos, blk.y, blk.z, c.N * 8, c.split_bits);
+    else                     strided_fwd_body<false, SRC>(a, P, f, pos, blk.y, blk.z, c.N * 8, c.split_bits);
   } else {
     if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, pos, cc, hg, col);
     else                     strided_inv_body<false>(X, TW, lds, P, f, pos, cc, hg, col);
@@ -557,15 +623,17 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
-    if (f.msg) hipLaunchKernelGGL((ntt8_strided_kernel<false, true>), ACEHIP_NTT_ARGS);
-    else       hipLaunchKernelGGL((ntt8_strided_kernel<false, false>), ACEHIP_NTT_ARGS);
+    if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
+    else if (f.conv && f.conv_max_in <= 8)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV8>), ACEHIP_NTT_ARGS);
+    else if (f.conv)               hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV12>), ACEHIP_NTT_ARGS);
+    else                           hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MEM>), ACEHIP_NTT_ARGS);
     if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1>), ACEHIP_NTT_ARGS);
     else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2>), ACEHIP_NTT_ARGS);
     else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), ACEHIP_NTT_ARGS);
   } else {
     if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1>), ACEHIP_NTT_ARGS);
     else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0>), ACEHIP_NTT_ARGS);
-    hipLaunchKernelGGL((ntt8_strided_kernel<true, false>), ACEHIP_NTT_ARGS);
+    hipLaunchKernelGGL((ntt8_strided_kernel<true, SRC_MEM>), ACEHIP_NTT_ARGS);
   }
 #undef ACEHIP_NTT_ARGS
 }

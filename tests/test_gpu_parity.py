@@ -333,3 +333,17 @@ def test_mod_raise(cfg):
     finally:
         rt.close()
         o.close()
+
+
+def test_conv_fusion_matches():
+    """ACEHIP_CONV_FUSION=1 (base conversion computed by the first pass of the following NTT, ntt_fast.hip SRC_CONV*) is an
+    opt-in variant of the N = 2^16 ModUp / ModDown pipelines: it must reproduce the reference-generated golden vectors bit for
+    bit as well.  The switch is read once per process, so the golden tests run again in a child with the variable set."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ACEHIP_CONV_FUSION="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_against_reference_golden and n65536"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
