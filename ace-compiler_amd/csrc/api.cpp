@@ -1468,7 +1468,9 @@ static int ensure_embed_tables(acehip_ctx* c) {
   u32* d_rot = c->up(rot);
   double* d_rou = c->up(rou);
   void *work = nullptr, *msg = nullptr, *err = nullptr;
-  if (!d_rot || !d_rou || hipMalloc(&work, N / 2 * 16 + 16) != hipSuccess || hipMalloc(&msg, N * 8) != hipSuccess ||
+  // scratch for a batch of EMB_BATCH_MAX messages (acehip_encode_batch)
+  if (!d_rot || !d_rou || hipMalloc(&work, EMB_BATCH_MAX * (N / 2 * 16) + 16) != hipSuccess ||
+      hipMalloc(&msg, (size_t)EMB_BATCH_MAX * N * 8) != hipSuccess ||
       hipMalloc(&err, 64) != hipSuccess)
     return fail(ACEHIP_EHIP, "acehip_encode: table allocation failed");
   c->owned.push_back(work);
@@ -1481,6 +1483,56 @@ static int ensure_embed_tables(acehip_ctx* c) {
   c->emb_err = (int*)err;
   c->emb_rou = (cd*)d_rou;
   return 0;
+}
+
+// [L] Delta^(sf_degree-1) mod q_i on the device (ckks_encoder.c:270-285), cached per (Delta, sf_degree)
+static const u64* encode_scale_table(acehip_ctx* c, u64 sfi, u32 sf_degree) {
+  std::lock_guard<std::mutex> g(c->mu);
+  u64*& tab = c->enc_scales[{sfi, sf_degree}];
+  if (!tab) {
+    std::vector<u64> w(c->hp.L);
+    for (u32 i = 0; i < c->hp.L; ++i) {
+      const u64 q = c->hp.primes[i].q;
+      u64 pw = sfi % q;
+      for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+      w[i] = pw;
+    }
+    tab = c->up(w);
+  }
+  return tab;
+}
+
+int acehip_encode_batch(acehip_ctx* c, uint64_t* const* h_q, const void* const* h_vals, uint32_t n_batch, int kind, size_t len,
+                        uint32_t slots, double sf, uint32_t sf_degree, uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  const u32 N = c->hp.N;
+  if (slots == 0) slots = N / 2;
+  if (n_batch == 0 || n_batch > EMB_BATCH_MAX || !h_q || !h_vals || kind < 0 || kind > 2 || slots > N / 2 || (slots & (slots - 1)) ||
+      len > slots || len == 0 || sf_degree < 1 || level == 0 || level > c->hp.L)
+    return fail(ACEHIP_EINVAL, "acehip_encode_batch: bad arguments");
+  for (u32 b = 0; b < n_batch; ++b)
+    if (!h_q[b] || !h_vals[b]) return fail(ACEHIP_EINVAL, "acehip_encode_batch: null pointer in the batch");
+  if (c->dc.logN != 16 || n_batch == 1) {  // no batched form below N = 2^16: one encode after the other
+    for (u32 b = 0; b < n_batch; ++b)
+      if (int e = acehip_encode(c, h_q[b], nullptr, h_vals[b], kind, len, slots, sf, sf_degree, level, 0, s)) return e;
+    return ACEHIP_OK;
+  }
+  if (int e = ensure_embed_tables(c)) return e;
+  hipStream_t st = (hipStream_t)s;
+  EmbBatch eb{};
+  for (u32 b = 0; b < n_batch; ++b) eb.vals[b] = h_vals[b];
+  launch_embed_inv_batch(c->emb_msg, c->emb_work, eb, n_batch, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
+  NttFuse f;
+  f.msg = c->emb_msg;
+  f.msg_stride = N;
+  for (u32 b = 0; b < n_batch; ++b) f.polyz[b] = h_q[b];
+  if (sf_degree > 1) {
+    f.msg_scale = encode_scale_table(c, (u64)sf, sf_degree);
+    if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
+  }
+  launch_ntt_fused(c->dc, h_q[0], level, 0, level, false, st, 0, n_batch, 0, 0, f);
+  stat(ST_ENCODE, n_batch, n_batch * (8ull * N * level + len * (kind == 0 ? 4 : kind == 1 ? 8 : 16)));
+  return post_launch();
 }
 
 int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
@@ -1499,20 +1551,8 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
     NttFuse f;
     f.msg = c->emb_msg;
     if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
-      std::lock_guard<std::mutex> g(c->mu);
-      u64*& tab = c->enc_scales[{sfi, sf_degree}];
-      if (!tab) {
-        std::vector<u64> w(c->hp.L);
-        for (u32 i = 0; i < c->hp.L; ++i) {
-          const u64 q = c->hp.primes[i].q;
-          u64 pw = sfi % q;
-          for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
-          w[i] = pw;
-        }
-        tab = c->up(w);
-        if (!tab) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
-      }
-      f.msg_scale = tab;
+      f.msg_scale = encode_scale_table(c, sfi, sf_degree);
+      if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
     }
     launch_ntt_fused(c->dc, d_q, level, 0, level, false, st, 0, 1, 0, 0, f);
     if (n_p) {

@@ -42,10 +42,14 @@ constexpr u32 EMB_COLS = 4;   // columns per workgroup in the strided pass
 
 // Stages logn .. EMB_LOW+1 on a tile of R = n/256 rows (stride 256) x EMB_COLS columns held in LDS.
 // Reads the message (zero padded), writes the partially transformed complex vector to work[n].
-__global__ __launch_bounds__(256) void embed_inv_high_kernel(cd* __restrict__ work, const void* __restrict__ vals, int kind,
+// blockIdx.y = message of a batch (EmbBatch: same kind / length / slots; work and msg of message b are b*work_stride /
+// b*msg_stride further)
+__global__ __launch_bounds__(256) void embed_inv_high_kernel(cd* __restrict__ work, EmbBatch batch, size_t work_stride, int kind,
                                                              size_t len, u32 logn, u32 log2m, const cd* __restrict__ rou,
                                                              const u32* __restrict__ rot_group) {
   extern __shared__ cd tile[];  // [R][EMB_COLS]
+  const void* __restrict__ vals = batch.vals[blockIdx.y];
+  work += blockIdx.y * work_stride;
   const u32 R = 1u << (logn - EMB_LOW);
   const u32 c0 = blockIdx.x * EMB_COLS;
   const u32 n_elem = R * EMB_COLS;
@@ -76,12 +80,15 @@ __global__ __launch_bounds__(256) void embed_inv_high_kernel(cd* __restrict__ wo
 // the scatter into the coefficient vector: msg[i*gap] = Re, msg[(i+slots)*gap] = Im (ckks_encoder.c:246-268).
 // FROM_INPUT: logn <= EMB_LOW, read the message directly (no strided pass ran).
 template <bool FROM_INPUT>
-__global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict__ msg, const cd* __restrict__ work,
-                                                            const void* __restrict__ vals, int kind, size_t len, u32 logn,
+__global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict__ msg, size_t msg_stride, const cd* __restrict__ work,
+                                                            size_t work_stride, EmbBatch batch, int kind, size_t len, u32 logn,
                                                             u32 log2m, const cd* __restrict__ rou,
                                                             const u32* __restrict__ rot_group, double sf, u32 coef_gap,
                                                             int* __restrict__ err_flag) {
   __shared__ cd blk[1u << EMB_LOW];
+  const void* __restrict__ vals = batch.vals[blockIdx.y];
+  msg += blockIdx.y * msg_stride;
+  work += blockIdx.y * work_stride;
   const u32 lb = logn < EMB_LOW ? logn : EMB_LOW;
   const u32 bsz = 1u << lb;
   const size_t base = (size_t)blockIdx.x << lb;
@@ -113,25 +120,32 @@ __global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict_
   }
 }
 
-// msg[N] (device) <- rounded, scaled inverse embedding of `vals` (len values, zero padded to `slots`)
-void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
-                      const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
+// msg[b][N] (device) <- rounded, scaled inverse embedding of batch.vals[b] (len values each, zero padded to `slots`), b < n_batch;
+// work must hold n_batch * slots complex values
+void launch_embed_inv_batch(int64_t* msg, cd* work, const EmbBatch& batch, u32 n_batch, int kind, size_t len, u32 slots, u32 N,
+                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
   ACEHIP_ABLATE(ABL_EMBED);
   u32 logn = 0, log2m = 1;
   while ((1u << logn) < slots) ++logn;
   while ((1u << log2m) < 2 * N) ++log2m;
   const u32 coef_gap = N / (2 * slots);
-  if (coef_gap > 1) (void)hipMemsetAsync(msg, 0, (size_t)N * sizeof(int64_t), s);
+  if (coef_gap > 1) (void)hipMemsetAsync(msg, 0, (size_t)n_batch * N * sizeof(int64_t), s);
   if (logn > EMB_LOW) {
     const u32 R = 1u << (logn - EMB_LOW);
-    hipLaunchKernelGGL(embed_inv_high_kernel, dim3((1u << EMB_LOW) / EMB_COLS), dim3(256), (size_t)R * EMB_COLS * sizeof(cd), s,
-                       work, vals, kind, len, logn, log2m, rou, rot_group);
-    hipLaunchKernelGGL(embed_inv_low_kernel<false>, dim3(slots >> EMB_LOW), dim3(128), 0, s, msg, work, vals, kind, len, logn,
-                       log2m, rou, rot_group, sf, coef_gap, err_flag);
+    hipLaunchKernelGGL(embed_inv_high_kernel, dim3((1u << EMB_LOW) / EMB_COLS, n_batch), dim3(256), (size_t)R * EMB_COLS * sizeof(cd),
+                       s, work, batch, (size_t)slots, kind, len, logn, log2m, rou, rot_group);
+    hipLaunchKernelGGL(embed_inv_low_kernel<false>, dim3(slots >> EMB_LOW, n_batch), dim3(128), 0, s, msg, (size_t)N, work,
+                       (size_t)slots, batch, kind, len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag);
   } else {
-    hipLaunchKernelGGL(embed_inv_low_kernel<true>, dim3(1), dim3(128), 0, s, msg, work, vals, kind, len, logn, log2m, rou,
-                       rot_group, sf, coef_gap, err_flag);
+    hipLaunchKernelGGL(embed_inv_low_kernel<true>, dim3(1, n_batch), dim3(128), 0, s, msg, (size_t)N, work, (size_t)slots, batch, kind,
+                       len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag);
   }
+}
+void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
+                      const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
+  EmbBatch b{};
+  b.vals[0] = vals;
+  launch_embed_inv_batch(msg, work, b, 1, kind, len, slots, N, rou, rot_group, sf, err_flag, s);
 }
 
 }  // namespace acehip

@@ -95,6 +95,9 @@ enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 // Work fused into the first / last pass of an N = 2^16 NTT (ntt_fast.hip), so that the neighbours of a transform
 // in Rescale / ModDown / ModUp / encode need no launch and no pass over memory of their own.
 struct NttFuse {
+  // polynomial z lives at polyz[z] instead of poly + z*poly_stride when polyz[0] is set (batched encodes into separate
+  // blocks of the caller's pool; at most 8 polynomials)
+  u64* polyz[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // inverse, first pass: read polynomial z from src_z instead of transforming in place (limb layout as `poly`)
   const u64* src0 = nullptr;
   const u64* src1 = nullptr;
@@ -235,6 +238,12 @@ void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hip
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s);
 // embed.hip: rounded, scaled inverse canonical embedding (device FP64, bit-identical to the reference host code)
 struct cd;
+constexpr u32 EMB_BATCH_MAX = 8;
+struct EmbBatch {  // messages of one batched embedding (device pointers), a kernel argument
+  const void* vals[EMB_BATCH_MAX];
+};
+void launch_embed_inv_batch(int64_t* msg, cd* work, const EmbBatch& batch, u32 n_batch, int kind, size_t len, u32 slots, u32 N,
+                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s);
 void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
                       const u32* rot_group, double sf, int* err_flag, hipStream_t s);
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);

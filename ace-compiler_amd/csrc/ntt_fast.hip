@@ -485,7 +485,7 @@ __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ 
                                              u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
-  u64* __restrict__ X = poly + w.z * poly_stride + (size_t)(w.pos - pos_off) * c.N;
+  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(w.pos - pos_off) * c.N;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
   const u32 col = w.tile * 16 + cc;  // N = 2^16 only (launch_ntt_fused): constant row stride, addresses = one base + immediates
@@ -608,7 +608,7 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
   const u32 pos = w.pos;
-  u64* __restrict__ X = poly + w.z * poly_stride + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
+  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const u32 s8 = c.logN - 8;
   const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;

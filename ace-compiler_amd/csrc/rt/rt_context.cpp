@@ -338,6 +338,8 @@ void Acehip_rt_thread_release(void) { thread_release(); }
 // Extension for callers that touch Coeffs() memory themselves (acehip_* / HIP calls on the raw device
 // pointers): hands over everything the shim still holds back and waits for the device.
 void Acehip_rt_sync(void) { sync(); }
+void Acehip_rt_next_input(void) { pt_image_boundary(); }
+size_t Acehip_rt_prefetched_count(void) { return g_ctx ? g_ctx->n_encode_prefetched : 0; }
 
 // ---- key accessors (key_gen.h:28-75) ----
 uint32_t Auto_idx(int32_t rot_idx) { return ensure_rot_key(rot_idx); }

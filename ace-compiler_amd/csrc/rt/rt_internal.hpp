@@ -7,6 +7,7 @@
 // reference also does on the CPU (ckks_encoder.c:199-297, :649-703).
 #pragma once
 #include <complex>
+#include <deque>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -98,7 +99,23 @@ struct Context {
   double t_encode = 0, t_main = 0, t_issue = 0, t_bootstrap = 0;
   size_t n_bootstrap = 0;
   size_t n_encode = 0, n_encode_ahead = 0;       // encodes / encodes launched ahead of the per-limb queue
+  // Weight-plaintext prefetch (rt_io.cpp pt_encode).  An FHE program is data-oblivious: every image makes the same
+  // Pt_from_msg calls in the same order.  The calls of this thread's first image are recorded; from the second image on
+  // the plaintexts of the next calls are encoded together, ahead of their use (acehip_encode_batch: one set of launches
+  // for up to 8 weights), and handed out as the calls arrive.  A call that differs from the record ends the prediction for
+  // the rest of that image.  (The reference prefetches weight plaintexts as well: pt_mgr.c:128-159.)
+  struct PtCall {
+    u32 index, scale, level;
+    size_t len;
+    bool operator==(const PtCall& o) const { return index == o.index && scale == o.scale && level == o.level && len == o.len; }
+  };
+  std::vector<PtCall> pt_trace;
+  bool pt_trace_done = false, pt_predict = false;
+  size_t pt_pos = 0;                             // index into pt_trace of the next expected call
+  std::deque<u64*> pt_ring;                      // encoded blocks for calls pt_pos, pt_pos + 1, ...
+  size_t n_encode_prefetched = 0, n_encode_batches = 0;
 };
+void pt_image_boundary();                        // a new input arrives (Prepare_input): the recorded call sequence restarts
 
 extern thread_local Context* g_ctx;  // this thread's context (its own acehip_ctx, counters, copies of the parameters)
 extern Context* g_primary;           // the context Prepare_context built: owner of the keys every thread uses

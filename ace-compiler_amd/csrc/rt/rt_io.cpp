@@ -155,6 +155,7 @@ void Tm_taken(const char* msg) {
 // ---- rtlib.c:41-87 ----
 void Prepare_input(TENSOR* input, const char* name) {
   io_init();
+  rt::pt_image_boundary();
   const size_t len = TENSOR_SIZE(input);
   std::vector<cplx> v(len);
   for (size_t i = 0; i < len; ++i) v[i] = cplx(input->_vals[i], 0.0);
@@ -393,6 +394,58 @@ static void pt_cache_clear() {
   g_pt_cache.clear();
   g_pt_cache_on = -1;
 }
+// ---- weight-plaintext prefetch (Context::pt_trace) ----
+static int pt_prefetch_batch() {
+  static const int n = [] {
+    const char* e = getenv("ACEHIP_PT_PREFETCH");  // batch size; 0 / 1 = off
+    int v = e ? atoi(e) : 8;
+    return v < 0 ? 0 : (v > 8 ? 8 : v);
+  }();
+  return n;
+}
+static void pt_ring_drop(rt::Context& c) {
+  for (rt::u64* b : c.pt_ring) rt::dfree(b);
+  c.pt_ring.clear();
+}
+}  // extern "C"
+namespace rt {
+void pt_image_boundary() {
+  if (g_ctx == nullptr) return;
+  Context& c = *g_ctx;
+  pt_ring_drop(c);
+  if (!c.pt_trace.empty()) c.pt_trace_done = true;
+  c.pt_predict = c.pt_trace_done && pt_prefetch_batch() > 1;
+  c.pt_pos = 0;
+}
+}  // namespace rt
+extern "C" {
+// encode the plaintexts of the recorded calls pt_pos, pt_pos+1, ... (same length / scale / level) in one batch
+static void pt_ring_fill(rt::Context& c) {
+  const rt::Context::PtCall& h = c.pt_trace[c.pt_pos];
+  rt::u32 n = 1;
+  const rt::u32 cap = (rt::u32)pt_prefetch_batch();
+  while (n < cap && c.pt_pos + n < c.pt_trace.size()) {
+    const rt::Context::PtCall& e = c.pt_trace[c.pt_pos + n];
+    if (e.len != h.len || e.scale != h.scale || e.level != h.level) break;
+    ++n;
+  }
+  rt::u64* q[8];
+  const void* vals[8];
+  for (rt::u32 j = 0; j < n; ++j) {
+    vals[j] = pt_entry_dev(c.pt_trace[c.pt_pos + j].index, h.len);
+    q[j] = rt::dalloc((size_t)h.level * c.N, false);  // the encode writes every limb
+  }
+  // like encode_device: the batch writes only blocks no queued op can name, so it may run ahead of the per-limb queue
+  if (!rt::hw_queue_empty()) {
+    rt::hw_pending_flush();
+    HIPCHK_NOFLUSH(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
+  } else {
+    HIPCHK(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
+  }
+  for (rt::u32 j = 0; j < n; ++j) c.pt_ring.push_back(q[j]);
+  c.n_encode_batches++;
+}
+
 static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
   if (len == 1) {  // plain_eval.c:25-33: a single value is a constant polynomial
     Encode_plain_from_float(plain, pt_entry(index, len), len, scale, level);
@@ -419,7 +472,38 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
       plain->_poly._is_ntt = true;
     }
   } else {
-    rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+    rt::Context& c = rt::ctx();
+    const rt::Context::PtCall call{index, scale, level ? level : c.L, len};
+    if (!c.pt_trace_done) {
+      c.pt_trace.push_back(call);  // first image of this thread: learn the sequence
+      rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+    } else if (c.pt_predict && c.pt_pos < c.pt_trace.size() && c.pt_trace[c.pt_pos] == call && scale >= 1 &&
+               call.level <= c.L && len <= c.N / 2) {
+      if (c.pt_ring.empty()) pt_ring_fill(c);
+      rt::u64* blk = c.pt_ring.front();
+      c.pt_ring.pop_front();
+      c.pt_pos++;
+      // what init_plaintext + poly_alloc + the encode leave behind, with the prefetched block as the data
+      POLYNOMIAL* poly = &plain->_poly;
+      if (poly->_data) rt::poly_free(poly);  // queued readers keep the old block (pool limbo)
+      plain->_scaling_factor = pow(c.sf, (double)scale);
+      plain->_sf_degree = scale;
+      plain->_slots = c.N / 2;
+      poly->_ring_degree = c.N;
+      poly->_num_primes = call.level;
+      poly->_num_primes_p = 0;
+      poly->_num_alloc_primes = call.level;
+      poly->_data = (int64_t*)blk;
+      poly->_is_ntt = true;
+      c.n_encode++;
+      c.n_encode_prefetched++;
+    } else {
+      if (c.pt_predict) {  // the program left the recorded sequence: no prediction for the rest of this image
+        pt_ring_drop(c);
+        c.pt_predict = false;
+      }
+      rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
+    }
   }
   rt::ctx().weight_plain_cnt++;
   rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;

@@ -208,6 +208,12 @@ int acehip_values_to_rns(acehip_ctx* ctx, uint64_t* d_poly, const int64_t* d_val
  * reference's assert) is recorded in a sticky flag: acehip_encode_status() synchronises and reports it. */
 int acehip_encode(acehip_ctx* ctx, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
                   double scaling_factor, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream stream);
+/* The same for n_batch <= 8 messages of equal kind / length / slots / scale / level in one set of launches (embedding
+ * kernels over the batch, one NTT with n_batch polynomials sharing every limb's twiddles): h_q[b] / h_vals[b] are HOST arrays
+ * of device pointers (output q-limbs, message values).  Results are bit-identical to n_batch acehip_encode calls.  This is what
+ * the weight-plaintext prefetch of the rt_ant shim issues (the reference prefetches weight plaintexts too: pt_mgr.c:128-159). */
+int acehip_encode_batch(acehip_ctx* ctx, uint64_t* const* h_q, const void* const* h_vals, uint32_t n_batch, int kind, size_t len,
+                        uint32_t slots, double scaling_factor, uint32_t sf_degree, uint32_t level, acehip_stream stream);
 int acehip_encode_status(acehip_ctx* ctx);
 /* uniformly random residues (Sample_uniform_poly polynomial.c:1349-1371; the generator differs from the
  * reference's BLAKE2 PRNG: key material is random by construction, parity is per operator) */

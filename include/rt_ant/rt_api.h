@@ -14,6 +14,13 @@ void       Acehip_rt_sync(void);
 /* Extension: a thread other than the one that called Prepare_context attaches to that context on its first API
  * call (shared keys; own scratch, pool, queue, HIP stream); before it ends it may give those back. */
 void       Acehip_rt_thread_release(void);
+/* Extension: weight-plaintext prefetch.  The runtime records the Pt_from_msg calls of a thread's first input and, for later
+ * inputs, encodes the plaintexts of upcoming calls in batches ahead of their use (ACEHIP_PT_PREFETCH=<batch>, default 8,
+ * 0 turns it off); a call that differs from the record falls back to a direct encode.  Prepare_input marks the start of an
+ * input; a main() that feeds ciphertexts by other means calls Acehip_rt_next_input() there instead.
+ * Acehip_rt_prefetched_count() = plaintexts this thread received from the prefetcher so far (statistics, tests). */
+void       Acehip_rt_next_input(void);
+size_t     Acehip_rt_prefetched_count(void);
 /* Extension: on-disk containers (the reference has none).  All return 0 or a negative code
  * (-1 cannot open, -2 truncated / wrong magic, -3 written for other CKKS parameters).
  *   "ACEHCT01" ciphertext / plaintext: u32 n_polys, N, level, num_p, is_ntt, slots, sf_degree, 0; f64 scaling_factor;

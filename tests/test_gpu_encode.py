@@ -282,3 +282,78 @@ def test_plaintext_cache_equals_encoding(stub, tmp_path):
     finally:
         os.environ.pop("ACEHIP_PT_CACHE", None)
         stub.Stub_set_data_file(None, 0)
+
+
+@pytest.mark.parametrize("N", [4096, 65536], ids=["n4096_sequential", "n65536_batched"])
+def test_weight_prefetch_equals_encoding(stub, tmp_path, N):
+    """Weight-plaintext prefetch (rt_io.cpp): the Pt_from_msg calls of the first input are recorded, later inputs get their
+    plaintexts from batched encodes issued ahead of the calls (acehip_encode_batch at N = 2^16; one by one below).  What the
+    calls return must equal the direct encodes of the first input bit for bit -- for runs of equal calls, a change of level /
+    scale / length inside the sequence, and an input whose calls leave the recorded order (fallback)."""
+    L, q0, sf, dnum = 4, 60, 50, 2
+    n = N // 4
+    ent = tmp_path / "entries.txt"
+    ent.write_text("".join("%d %d\n" % (i, n if i != 5 else n // 2) for i in range(7)))
+    wfile = str(tmp_path / "w.msg")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_weight_file.py"), "--entries", str(ent), "--out", wfile])
+    stub.Stub_set_data_file.argtypes = [C.c_char_p, C.c_int]
+    stub.Pt_from_msg.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32]
+    stub.Acehip_rt_prefetched_count.restype = C.c_size_t
+    stub.Stub_set_params(N, L - 1, q0, sf, dnum, 192)
+    stub.Stub_set_data_file(wfile.encode(), 0)
+    seq = [(0, n, 1, 4), (1, n, 1, 4), (2, n, 1, 4), (3, n, 1, 4), (4, n, 2, 3), (6, n, 2, 3), (5, n // 2, 1, 4), (0, n, 1, 4),
+           (1, n, 1, 2)]
+    os.environ["ACEHIP_PT_PREFETCH"] = "3"   # batches of 3: runs longer than a batch, and batches cut short by a change
+    try:
+        stub.Prepare_context()
+        first = {}
+        for image in range(4):
+            stub.Acehip_rt_next_input()
+            calls = seq if image < 3 else [seq[1], seq[0]] + seq[2:]   # the last input swaps two calls: prediction ends
+            held = []
+            for k, (idx, ln, deg, level) in enumerate(calls):
+                pt = C.create_string_buffer(stub.Stub_sizeof_plaintext())
+                stub.Pt_from_msg(pt, idx, ln, deg, level)
+                held.append(pt)
+                if len(held) > 2:   # plaintexts stay alive for a while, as in a convolution's tap loop
+                    stub.Free_plain(held.pop(0))
+                got = _download(stub, pt, N)
+                key = (idx, ln, deg, level)
+                if image == 0:
+                    first.setdefault(key, got)
+                assert np.array_equal(got, first[key]), (image, k, key)
+            for pt in held:
+                stub.Free_plain(pt)
+            want = 0 if image == 0 else len(seq) * min(image, 2)
+            assert stub.Acehip_rt_prefetched_count() == want, (image, stub.Acehip_rt_prefetched_count(), want)
+        stub.Finalize_context()
+    finally:
+        os.environ.pop("ACEHIP_PT_PREFETCH", None)
+        stub.Stub_set_data_file(None, 0)
+
+
+def test_encode_batch_abi_matches_single_encodes():
+    """acehip_encode_batch (embedding kernels over the batch, one NTT over separate output blocks) against acehip_encode, one
+    message at a time: bit-identical q-limbs, scale degree 1 and 2."""
+    import ace_compiler_amd as A
+
+    N, L = 65536, 4
+    rt = A.AceHip(N, L, 60, 50, 2)
+    try:
+        rng = np.random.default_rng(5)
+        B, ln = 5, 12000
+        msgs = [(rng.standard_normal(ln) * 0.1).astype(np.float32) for _ in range(B)]
+        for deg, level in ((1, 4), (2, 3)):
+            singles = [rt.encode(m, level, sf_degree=deg)[0] for m in msgs]
+            dvals = [rt.to_device(m) for m in msgs]
+            outs = [rt.buf(level * N) for _ in range(B)]
+            hq = (C.c_void_p * B)(*[o.ptr for o in outs])
+            hv = (C.c_void_p * B)(*[d.ptr for d in dvals])
+            rt.check(rt.lib.acehip_encode_batch(rt.h, hq, hv, B, 0, ln, 0, float(2.0 ** rt.sf_bits), deg, level, None))
+            rt.check(rt.lib.acehip_encode_status(rt.h))
+            for b in range(B):
+                assert np.array_equal(outs[b].download((level, N)), singles[b]), (deg, b)
+            for d in dvals + outs:
+                d.free()
+    finally:
+        rt.close()
