@@ -173,6 +173,10 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   ctx->p_gi = ctx->up(pgi);
   ctx->q_gi = ctx->up(qgi);
   ctx->q_pos = ctx->q_gi;
+  {  // ACEHIP_NTT_NARROW = largest launch (limb rows) that takes the narrow small-launch passes (0: never)
+    const char* e = getenv("ACEHIP_NTT_NARROW");
+    ctx->dc.ntt_narrow_max_rows = e ? (u32)strtoul(e, nullptr, 0) : 16u;
+  }
   if (hp.logN == 16) {  // arrival counters of the one-launch transforms (ntt_fast.hip ntt16_one_kernel)
     // ACEHIP_NTT_ONE_LAUNCH = largest number of limb rows of a launch that takes the one-launch path.  Default 0 (never):
     // measured on MI355X the in-kernel hand-off (write-through 8-byte stores, sc1 loads, waiting for the slowest of 16

@@ -30,6 +30,8 @@ struct DevCtx {
   u32* sync_ring = nullptr;
   u32 sync_size = 0, one_launch_max_limbs = 0;
   u32* sync_cursor = nullptr;
+  // N = 2^16 transforms of at most this many limb rows (limbs x polynomials) run as narrow passes (ntt_fast.hip ntt4_*)
+  u32 ntt_narrow_max_rows = 0;
 };
 
 // prime (global index) of the limb at position pos of a polynomial extended at `level`

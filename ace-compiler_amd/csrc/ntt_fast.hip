@@ -669,6 +669,335 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// NARROW passes for small launches: 1024-coefficient tiles, 4 coefficients per lane, four radix-4 rounds per pass.
+// Most transforms of the workload cover 1..30 limbs (a Rescale's last limb, the P-limbs of a ModDown, low levels): with
+// 4096-coefficient tiles that is 16..500 workgroups of one wave per SIMD, each wave running 128 butterflies one after the
+// other at a lone wave's issue rate (a v_mad_u64_u32 every 9 cycles, profiles/r02v): ~9.5 us per pass whatever the size.
+// The same work cut into 4x as many workgroups of 16 butterflies per wave finishes in about half the time and fills 4x as
+// many CUs.  Same butterflies, same twiddle tables, same lazy ranges as the wide passes: results are bit-identical.
+//   STRIDED tile: 256 rows x 4 adjacent columns (a 32-byte segment per row); thread t = 4*g + c; rounds hold rows
+//       g + 64k | 64a + j + 16k | 16a' + j' + 4k | 4g + k   (k = 0..3), exchanged through LDS (row pitch 5: conflict-free)
+//   CONTIG tile: 4 blocks of 256 contiguous coefficients, ONE WAVE PER BLOCK (lane l): rounds hold rho =
+//       l + 64k | 64(l>>4) + (l&15) + 16k | 16(l>>2) + (l&3) + 4k | 4l + k; the exchanges stay inside the wave (its own
+//       LDS region, no workgroup barrier)
+// Every round is the same radix-4 step on 4 registers: stage A pairs (0,2),(1,3) with twiddle tA, stage B pairs (0,1) with
+// tB0 and (2,3) with tB1, where tA = TW[2^s + p], tB_i = TW[2^(s+1) + 2p + i] for the round's first stage s and the index p of
+// the lane's butterfly group at that stage.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kNarrowPitch = 5;  // strided narrow tile: 256 rows x 4 columns, row pitch 5 words
+
+struct Tw3 {
+  Tw a, b0, b1;
+};
+// scalar (wave-uniform p: constant address space) or per-lane twiddles of one round
+template <bool SMALL, bool UNIFORM>
+__device__ __forceinline__ Tw3 load_tw3(const ulong2* __restrict__ TW, u32 s, u32 p) {
+#if NTT_EXP & 4
+  return Tw3{ldtw<SMALL>(TW, 1), ldtw<SMALL>(TW, 2), ldtw<SMALL>(TW, 3)};
+#else
+  const u32 ia = (1u << s) + p, ib = (2u << s) + 2 * p;
+  if (UNIFORM) {
+    ctw_ptr T = (ctw_ptr)(reinterpret_cast<const u64*>(TW));
+    auto ld = [&](u32 i) {
+      const u64 w = T[2 * i], pp = T[2 * i + 1];
+      return Tw{w, SMALL ? pp >> 1 : pp};
+    };
+    return Tw3{ld(ia), ld(ib), ld(ib + 1)};
+  }
+  return Tw3{ldtw<SMALL>(TW, ia), ldtw<SMALL>(TW, ib), ldtw<SMALL>(TW, ib + 1)};
+#endif
+}
+template <bool SMALL>
+__device__ __forceinline__ void radix4_fwd(u64 (&x)[4], const Tw3& t, const BfK& k) {
+  bf_fwd<SMALL>(x[0], x[2], t.a, k);
+  bf_fwd<SMALL>(x[1], x[3], t.a, k);
+  bf_fwd<SMALL>(x[0], x[1], t.b0, k);
+  bf_fwd<SMALL>(x[2], x[3], t.b1, k);
+}
+// inverse: stage B first, then stage A (skipped when the caller folds it: the very last stage carries N^-1)
+template <bool SMALL, bool WITH_A>
+__device__ __forceinline__ void radix4_inv(u64 (&x)[4], const Tw3& t, const BfK& k) {
+  bf_inv<SMALL>(x[0], x[1], t.b0, k);
+  bf_inv<SMALL>(x[2], x[3], t.b1, k);
+  if (WITH_A) {
+    bf_inv<SMALL>(x[0], x[2], t.a, k);
+    bf_inv<SMALL>(x[1], x[3], t.a, k);
+  }
+}
+
+// ---- strided narrow pass (stages 0..7).  lds: 256 * kNarrowPitch words.
+template <bool SMALL, bool INVERSE, int SRC>
+__device__ __forceinline__ void strided4_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
+                                              const NttFuse& f, u32 pos, u32 z, u32 tile, u64 q, u32 n_words) {
+  const BfK bk = bf_consts<SMALL>(q);
+  const u32 t = threadIdx.x, c = t & 3, g = t >> 2;
+  const u32 col = tile * 4 + c;
+  // the round layouts: row of register k
+  const u32 a2 = __builtin_amdgcn_readfirstlane(t >> 6), j2 = (t >> 2) & 15;  // R2: 64*a2 + j2 + 16k (a2 is wave-uniform)
+  const u32 a3 = t >> 4, j3 = (t >> 2) & 3;                                    // R3: 16*a3 + j3 + 4k
+  u64 x[4];
+  asm volatile("" ::: "memory");
+  // every round's twiddles are requested up front, next to the data: four dependent fetches would cost four memory latencies
+  const Tw3 t1 = load_tw3<SMALL, true>(TW, 0, 0), t2 = load_tw3<SMALL, true>(TW, 2, a2), t3 = load_tw3<SMALL, false>(TW, 4, a3),
+            t4 = load_tw3<SMALL, false>(TW, 6, g);
+  if (!INVERSE) {
+    if (SRC == SRC_MSG) {  // Encode_impl ckks_encoder.c:262-285, as in strided_fwd_body
+      const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
+      const int64_t* __restrict__ M = f.msg + z * f.msg_stride;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t v = M[(size_t)(g + 64 * k) * 256 + col];
+        const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+        u64 r = mag;
+        if (__any(mag >= q)) r = mag < q ? mag : reduce128(U128{mag, 0}, q, P.prec128_lo, P.prec128_hi);
+        if (v < 0 && r != 0) r = q - r;
+        x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = ntld(&X[(size_t)(g + 64 * k) * 256 + col]);
+    }
+    radix4_fwd<SMALL>(x, t1, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(g + 64 * k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(64 * a2 + j2 + 16 * k) * kNarrowPitch + c];
+    radix4_fwd<SMALL>(x, t2, bk);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(64 * a2 + j2 + 16 * k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(16 * a3 + j3 + 4 * k) * kNarrowPitch + c];
+    radix4_fwd<SMALL>(x, t3, bk);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(16 * a3 + j3 + 4 * k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(4 * g + k) * kNarrowPitch + c];
+    radix4_fwd<SMALL>(x, t4, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ntst(&X[(size_t)(4 * g + k) * 256 + col], x[k]);  // lazy: < 41q SMALL, < 8q otherwise
+  } else {
+    // input lazy [0,lim) from the contiguous pass; stages 7,6 | 5,4 | 3,2 | 1 and stage 0 with N^-1 (or the caller's scale)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = ntld(&X[(size_t)(4 * g + k) * 256 + col]);
+    radix4_inv<SMALL, true>(x, t4, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(4 * g + k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(16 * a3 + j3 + 4 * k) * kNarrowPitch + c];
+    radix4_inv<SMALL, true>(x, t3, bk);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(16 * a3 + j3 + 4 * k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(64 * a2 + j2 + 16 * k) * kNarrowPitch + c];
+    radix4_inv<SMALL, true>(x, t2, bk);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(64 * a2 + j2 + 16 * k) * kNarrowPitch + c] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lds[(g + 64 * k) * kNarrowPitch + c];
+    radix4_inv<SMALL, false>(x, t1, bk);  // stage 1; stage 0 below
+    Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+    if (f.inv_scale) {
+      const u64* sc = f.inv_scale + 4 * (size_t)pos;
+      tn = Tw{sc[0], sc[1]};
+      tw = Tw{sc[2], sc[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u64 s = x[k] + x[k + 2];
+      const u64 d = x[k] + bk.lim - x[k + 2];
+      const u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);  // exact quotient: [0,2q)
+      x[k] = a >= q ? a - q : a;
+      x[k + 2] = b >= q ? b - q : b;
+    }
+    if (f.center_out) {
+      const u64 half = q >> 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = x[k] > half ? x[k] - q : x[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ntst(&X[(size_t)(g + 64 * k) * 256 + col], x[k]);
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <bool INVERSE, int SRC>
+__global__ __launch_bounds__(256) void ntt4_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
+                                                        u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
+  __shared__ u64 lds[256 * kNarrowPitch];
+  // the 4 tiles that share the 128-byte lines of a row (tile = 4*line + r) get block ids congruent mod 8: one XCD's L2
+  const u32 b = blockIdx.x, xl = b & 7u, m = b >> 3;
+  const u32 tile = 4 * (xl + 8 * ((m >> 2) & 1u)) + (m & 3u), rowi = m >> 3;
+  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0};
+  w.y = __builtin_amdgcn_readfirstlane(w.y);
+  w.z = __builtin_amdgcn_readfirstlane(w.z);
+  if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
+  const DevPrime& P = c.primes[w.gi];
+  const u64 q = uniform64(P.q);
+  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(w.pos - pos_off) * c.N;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  if (q <= kSmallPrimeMax) strided4_body<true, INVERSE, SRC>(X, TW, lds, P, f, w.pos, w.z, w.tile, q, c.N);
+  else                     strided4_body<false, INVERSE, SRC>(X, TW, lds, P, f, w.pos, w.z, w.tile, q, c.N);
+}
+
+// ---- contiguous narrow pass (stages 8..15): one wave per 256-coefficient block, `wl` = the wave's 256-word LDS region
+// (+ 8 words of padding between the regions)
+template <bool SMALL, bool INVERSE, int FUSE>
+__device__ __forceinline__ void contig4_body(u64* __restrict__ Xb, const u64* __restrict__ Sb, const ulong2* __restrict__ TW, u64* wl,
+                                             const DevPrime& P, const NttFuse& f, u32 pos, u32 z, u32 o, u64 q, size_t tail_off) {
+  const BfK bk = bf_consts<SMALL>(q);
+  const u32 l = threadIdx.x & 63;
+  const u32 c2 = l >> 4, j2 = l & 15, c3 = l >> 2, j3 = l & 3;
+  u64 x[4];
+  asm volatile("" ::: "memory");
+  // every round's twiddles are requested up front, next to the data
+  const Tw3 t1 = load_tw3<SMALL, true>(TW, 8, o), t2 = load_tw3<SMALL, false>(TW, 10, (o << 2) + c2),
+            t3 = load_tw3<SMALL, false>(TW, 12, (o << 4) + c3), t4 = load_tw3<SMALL, false>(TW, 14, (o << 6) + l);
+  if (!INVERSE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = ntld(&Xb[l + 64 * k]);
+    radix4_fwd<SMALL>(x, t1, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[l + 64 * k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[64 * c2 + j2 + 16 * k];
+    radix4_fwd<SMALL>(x, t2, bk);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[64 * c2 + j2 + 16 * k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[16 * c3 + j3 + 4 * k];
+    radix4_fwd<SMALL>(x, t3, bk);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[16 * c3 + j3 + 4 * k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[4 * l + k];
+    radix4_fwd<SMALL>(x, t4, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = canon_fwd<SMALL>(x[k], q, P.prec128_hi);
+    // the lane holds 4 contiguous coefficients: 32 bytes, two 16-byte accesses (Rescale / ModDown tails as in contig_pass)
+    const u64* __restrict__ xin = FUSE ? (z ? f.x1 : f.x0) + tail_off + 4 * l : nullptr;
+    u64* __restrict__ dst = FUSE ? (z ? f.out1 : f.out0) + tail_off + 4 * l : Xb + 4 * l;
+    const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ulong2 v{x[2 * h], x[2 * h + 1]};
+      if (FUSE == 1) {
+        const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + 2 * h);
+        v.x = add_mod(mul_shoup(xv.x, tw_w, tw_p, q), v.x, q);
+        v.y = add_mod(mul_shoup(xv.y, tw_w, tw_p, q), v.y, q);
+      } else if (FUSE == 2) {
+        const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + 2 * h);
+        v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
+        v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
+      }
+      *reinterpret_cast<ulong2*>(dst + 2 * h) = v;
+    }
+  } else {
+    {  // 4 contiguous coefficients per lane from Sb (out of place when FUSE)
+      const ulong2 v0 = *reinterpret_cast<const ulong2*>(Sb + 4 * l), v1 = *reinterpret_cast<const ulong2*>(Sb + 4 * l + 2);
+      x[0] = v0.x;
+      x[1] = v0.y;
+      x[2] = v1.x;
+      x[3] = v1.y;
+    }
+    radix4_inv<SMALL, true>(x, t4, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[4 * l + k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[16 * c3 + j3 + 4 * k];
+    radix4_inv<SMALL, true>(x, t3, bk);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[16 * c3 + j3 + 4 * k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[64 * c2 + j2 + 16 * k];
+    radix4_inv<SMALL, true>(x, t2, bk);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[64 * c2 + j2 + 16 * k] = x[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wl[l + 64 * k];
+    radix4_inv<SMALL, true>(x, t1, bk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ntst(&Xb[l + 64 * k], x[k]);  // lazy [0,lim): the strided pass follows
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <bool INVERSE, int FUSE>
+__global__ __launch_bounds__(256) void ntt4_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
+                                                       u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
+  __shared__ u64 lds[4 * 264];
+  const u32 b = blockIdx.x, tile = b & 63u, rowi = b >> 6;
+  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0};
+  w.y = __builtin_amdgcn_readfirstlane(w.y);
+  w.z = __builtin_amdgcn_readfirstlane(w.z);
+  if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
+  const DevPrime& P = c.primes[w.gi];
+  const u64 q = uniform64(P.q);
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 o = w.tile * 4 + wave;  // 256-coefficient block of the limb
+  const size_t limb_off = (size_t)(w.pos - pos_off) * c.N + (size_t)o * 256;
+  u64* __restrict__ Xb = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + limb_off;
+  const u64* __restrict__ Sb = (INVERSE && FUSE) ? (w.z ? f.src1 : f.src0) + limb_off : Xb;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const size_t tail_off = (size_t)w.pos * c.N + (size_t)o * 256;
+  u64* wl = lds + wave * 264;
+  if (q <= kSmallPrimeMax) contig4_body<true, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, w.pos, w.z, o, q, tail_off);
+  else                     contig4_body<false, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, w.pos, w.z, o, q, tail_off);
+}
+
+// small launches take the narrow passes: at most c.ntt_narrow_max_rows limb rows (limbs x polynomials)
+static bool launch_ntt_narrow(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                              u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
+  if (n_limbs * n_polys > c.ntt_narrow_max_rows || f.conv != nullptr) return false;
+  dim3 block(256), grid(64 * n_limbs * n_polys);
+#define ACEHIP_N4_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
+  if (!inverse) {
+    if (f.msg) hipLaunchKernelGGL((ntt4_strided_kernel<false, SRC_MSG>), ACEHIP_N4_ARGS);
+    else       hipLaunchKernelGGL((ntt4_strided_kernel<false, SRC_MEM>), ACEHIP_N4_ARGS);
+    if (f.epi == 1)      hipLaunchKernelGGL((ntt4_contig_kernel<false, 1>), ACEHIP_N4_ARGS);
+    else if (f.epi == 2) hipLaunchKernelGGL((ntt4_contig_kernel<false, 2>), ACEHIP_N4_ARGS);
+    else                 hipLaunchKernelGGL((ntt4_contig_kernel<false, 0>), ACEHIP_N4_ARGS);
+  } else {
+    if (f.src0) hipLaunchKernelGGL((ntt4_contig_kernel<true, 1>), ACEHIP_N4_ARGS);
+    else        hipLaunchKernelGGL((ntt4_contig_kernel<true, 0>), ACEHIP_N4_ARGS);
+    hipLaunchKernelGGL((ntt4_strided_kernel<true, SRC_MEM>), ACEHIP_N4_ARGS);
+  }
+#undef ACEHIP_N4_ARGS
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Both passes of an N = 2^16 transform in ONE launch.  The 16 workgroups of a limb each run first-pass tile t, publish it,
 // wait until all 16 first-pass tiles of THEIR limb are published and then run second-pass tile t of the same limb: one
 // launch, one fetch of the kernel arguments and prime constants, no kernel boundary (and no second launch floor) between
@@ -769,6 +1098,7 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   ACEHIP_ABLATE(ABL_NTT);
   if (n_limbs == 0) return;
   if (launch_ntt_one(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
+  if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {

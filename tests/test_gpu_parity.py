@@ -362,3 +362,21 @@ def test_one_launch_ntt_matches():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("rows", ["0", "100000"], ids=["wide_only", "narrow_always"])
+def test_ntt_tile_width_variants_match(rows):
+    """N = 2^16 transforms run as narrow passes (1024-coefficient tiles, ntt_fast.hip ntt4_*) up to ACEHIP_NTT_NARROW limb rows
+    and as wide passes (4096-coefficient tiles) above: both must reproduce the reference-generated golden vectors and the
+    fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ACEHIP_NTT_NARROW=rows)
+    tests = [os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_encode.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + tests + ["-k",
+                        "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536 or "
+                        "(test_encode_matches_reference and n65536) or test_encode_batch_abi or (test_weight_prefetch and n65536)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
