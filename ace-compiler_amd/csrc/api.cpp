@@ -88,7 +88,6 @@ struct acehip_ctx {
   int64_t* emb_msg = nullptr;
   int* emb_err = nullptr;
   std::map<std::pair<u64, u32>, u64*> enc_scales;  // (Delta, sf_degree) -> [L] Delta^(sf_degree-1) mod q_i
-  u32 sync_cursor = 0;  // host cursor into dc.sync_ring (one-launch transforms; one stream per context at a time)
 
   template <typename T>
   T* up(const std::vector<T>& v) {
@@ -176,23 +175,6 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   {  // ACEHIP_NTT_NARROW = largest launch (limb rows) that takes the narrow small-launch passes (0: never)
     const char* e = getenv("ACEHIP_NTT_NARROW");
     ctx->dc.ntt_narrow_max_rows = e ? (u32)strtoul(e, nullptr, 0) : 16u;
-  }
-  if (hp.logN == 16) {  // arrival counters of the one-launch transforms (ntt_fast.hip ntt16_one_kernel)
-    // ACEHIP_NTT_ONE_LAUNCH = largest number of limb rows of a launch that takes the one-launch path.  Default 0 (never):
-    // measured on MI355X the in-kernel hand-off (write-through 8-byte stores, sc1 loads, waiting for the slowest of 16
-    // siblings) costs MORE than the kernel boundary it removes -- C3 key-switch 0.300 ms vs 0.251 ms, 1024-limb batch
-    // 0.667 ms vs 0.548 ms -- so the two-launch form stays the product path; the variant is kept bit-exact under test.
-    const char* e = getenv("ACEHIP_NTT_ONE_LAUNCH");
-    const u32 max_limbs = e ? (u32)strtoul(e, nullptr, 0) : 0u;
-    constexpr u32 kRing = 1u << 16;
-    u32* ring = nullptr;
-    if (max_limbs != 0 && hipMalloc(&ring, kRing * sizeof(u32)) == hipSuccess && hipMemset(ring, 0, kRing * sizeof(u32)) == hipSuccess) {
-      ctx->owned.push_back(ring);
-      ctx->dc.sync_ring = ring;
-      ctx->dc.sync_size = kRing;
-      ctx->dc.one_launch_max_limbs = max_limbs;
-      ctx->dc.sync_cursor = &ctx->sync_cursor;
-    }
   }
   // workspace of the batched key-switch: coef (L) + ext[dnum] + two accumulators (L+K each) + tmp (2L)
   ctx->ws_words = ((size_t)hp.L * 3 + (size_t)(hp.dnum + 2) * T) * hp.N;

@@ -25,11 +25,6 @@ struct DevCtx {
   const ulong2* tw_inv;    // [L+K][N] {rou_inv[bitrev], Shoup companion}
   u32 N, logN, L, K;
   u32 split_bits;  // ceil(max prime bits / 2): base conversion multiplies in halves of this width (keyswitch.hip)
-  // one-launch N = 2^16 transforms (ntt_fast.hip ntt16_one_kernel): ring of per-limb arrival counters in HBM, its size, the
-  // HOST cursor into it (owned by the context that launches: one stream per context) and the largest launch that takes the path
-  u32* sync_ring = nullptr;
-  u32 sync_size = 0, one_launch_max_limbs = 0;
-  u32* sync_cursor = nullptr;
   // N = 2^16 transforms of at most this many limb rows (limbs x polynomials) run as narrow passes (ntt_fast.hip ntt4_*)
   u32 ntt_narrow_max_rows = 0;
 };

@@ -278,18 +278,6 @@ template <class T> __device__ __forceinline__ void ntst(T* p, T v) {
   *p = v;
 #endif
 }
-// MID: the access touches the INTERMEDIATE of a transform whose two passes run in one launch (ntt16_one_kernel): another
-// workgroup -- possibly on another XCD, whose L2 is not coherent with this one -- produced / will consume the data within
-// the same kernel, so stores write through (sc1) and loads bypass the CU's L1 (sc1), the forms of MI355X_MICROARCH.md
-// "Workgroup dispatch, XCD placement & inter-workgroup visibility" (relaxed agent-scope atomics lower to exactly those)
-template <int MID> __device__ __forceinline__ u64 mid_ld(const u64* p) {
-  if (MID) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return ntld(p);
-}
-template <int MID> __device__ __forceinline__ void mid_st(u64* p, u64 v) {
-  if (MID) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else ntst(p, v);
-}
 __device__ __forceinline__ u64 bld(const LimbBuf& b, u32 voff, u32 soff) {
 #if NTT_EXP & 2
   return (u64)voff * 0x9E3779B97F4A7C15ull + soff;
@@ -297,7 +285,6 @@ __device__ __forceinline__ u64 bld(const LimbBuf& b, u32 voff, u32 soff) {
   const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, NTT_NT_LD);
   return ((u64)v.y << 32) | v.x;
 }
-template <int MID>
 __device__ __forceinline__ void bst(const LimbBuf& b, u32 voff, u32 soff, u64 v) {
 #if NTT_EXP & 2
   if (v != 0x123456789ull) return;
@@ -305,7 +292,7 @@ __device__ __forceinline__ void bst(const LimbBuf& b, u32 voff, u32 soff, u64 v)
   u32x2_t w;
   w.x = (u32)v;
   w.y = (u32)(v >> 32);
-  __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff, soff, MID ? 16 /* sc1 */ : NTT_NT_ST);
+  __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff, soff, NTT_NT_ST);
 }
 
 constexpr u32 kRowPitch = 17;        // strided tile: 256 rows x 16 cols, row pitch 17 words
@@ -334,7 +321,7 @@ struct StridedArgs {
 // (encode), SRC_CONV8/12 the fast base conversion of up to 8/12 coefficient-domain source limbs (ModUp / ModDown: the
 // converted limbs are never written in coefficient form; 16 sources would spill registers: those take the separate kernel)
 enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV8 = 8, SRC_CONV12 = 12 };
-template <bool SMALL, int SRC, int MID>
+template <bool SMALL, int SRC>
 __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 row, u32 z,
                                                  u32 n_bytes, u32 split_bits) {
   constexpr bool FROM_MSG = SRC == SRC_MSG;
@@ -407,13 +394,13 @@ __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const Dev
   for (int k = 0; k < 16; ++k) x[k] = a.lds[(16 * a.hg + k) * kRowPitch + a.cc];
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) bst<MID>(a.buf, (a.hg << 15) + a.col * 8, (u32)k << 11, x[k]);  // row 16hg+k
+  for (int k = 0; k < 16; ++k) bst(a.buf, (a.hg << 15) + a.col * 8, (u32)k << 11, x[k]);  // row 16hg+k
   asm volatile("" ::: "memory");  // and its stores above the join
 }
 
 // inverse: round B first (stages 7..4 on rows 16h+g'; input lazy [0,lim) from the contiguous pass), then round A (stages
 // 3..1 and stage 0 with N^-1 -- or the caller's scale -- folded in); canonical (or centred) output
-template <bool SMALL, int MID>
+template <bool SMALL>
 __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
                                                  const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
   constexpr u32 log_s = 8;
@@ -423,7 +410,7 @@ __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulon
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
 #pragma unroll
-  for (int k = 0; k < 16; ++k) x[k] = mid_ld<MID>(&X[((size_t)(16 * hg + k) << log_s) + col]);
+  for (int k = 0; k < 16; ++k) x[k] = ntld(&X[((size_t)(16 * hg + k) << log_s) + col]);
   load_tw<SMALL>(TW, 4, hg, t0, t1, t2, t3);
   radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
   radix16_inv_0<SMALL>(x, t0, bk);
@@ -479,8 +466,7 @@ __device__ __forceinline__ bool ntt_resolve(NttWg& w, const DevCtx& c, const Ntt
 }
 
 // STRIDED pass of one workgroup.  SRC (forward only): source of the first pass' input, see strided_fwd_body.
-// MID: the forward result / the inverse input is the intermediate of a one-launch transform (mid_ld / mid_st)
-template <bool INVERSE, int SRC, int MID>
+template <bool INVERSE, int SRC>
 __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
                                              u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
@@ -491,11 +477,11 @@ __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ 
   const u32 col = w.tile * 16 + cc;  // N = 2^16 only (launch_ntt_fused): constant row stride, addresses = one base + immediates
   if (!INVERSE) {
     const StridedArgs a{limb_buf(X, c.N * 8), TW, lds, cc, hg, col, q};
-    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC, MID>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
-    else                     strided_fwd_body<false, SRC, MID>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
+    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
+    else                     strided_fwd_body<false, SRC>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
   } else {
-    if (q <= kSmallPrimeMax) strided_inv_body<true, MID>(X, TW, lds, P, f, w.pos, cc, hg, col);
-    else                     strided_inv_body<false, MID>(X, TW, lds, P, f, w.pos, cc, hg, col);
+    if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, w.pos, cc, hg, col);
+    else                     strided_inv_body<false>(X, TW, lds, P, f, w.pos, cc, hg, col);
   }
 }
 
@@ -510,7 +496,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   NttWg w{blk.tile, blk.y, blk.z, 0, 0};
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
-  strided_pass<INVERSE, SRC, 0>(c, poly, poly_stride, pos_off, f, lds, w);
+  strided_pass<INVERSE, SRC>(c, poly, poly_stride, pos_off, f, lds, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,7 +510,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 // ------------------------------------------------------------------------------------------------
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
 // rho = 16*lo4+k on return
-template <bool SMALL, int MID>
+template <bool SMALL>
 __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, u32 s8, u32 o,
                                                 u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
   const BfK bk = bf_consts<SMALL>(q);
@@ -534,7 +520,7 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
 #if NTT_EXP & 2
   for (int k = 0; k < 16; ++k) x[k] = (u64)(b * 256 + 16 * k + lo4) * 0x9E3779B97F4A7C15ull + o;
 #else
-  for (int k = 0; k < 16; ++k) x[k] = mid_ld<MID>(&X[b * 256 + 16 * k + lo4]);
+  for (int k = 0; k < 16; ++k) x[k] = ntld(&X[b * 256 + 16 * k + lo4]);
 #endif
   load_tw<SMALL>(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
@@ -552,7 +538,7 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
 
 // inverse rounds: the tile is read from S (coalesced 16-byte loads through LDS), round B first (stages s8+7..s8+4 on the 16
 // contiguous rho = 16h + g'), then round A (stages s8+3..s8 on rho = 16k + g); lazy [0,lim) output unless CANON_OUT
-template <bool SMALL, bool CANON_OUT, int MID>
+template <bool SMALL, bool CANON_OUT>
 __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW, u64* lds,
                                                 u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
   const BfK bk = bf_consts<SMALL>(q);
@@ -593,7 +579,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
       v = v >= 2 * q ? v - 2 * q : v;
       v = v >= q ? v - q : v;
     }
-    mid_st<MID>(&X[b * 256 + 16 * k + lo4], v);
+    ntst(&X[b * 256 + 16 * k + lo4], v);
   }
   asm volatile("" ::: "memory");
 }
@@ -601,8 +587,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
 // CONTIG pass of one workgroup.
 // FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
 // f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
-// MID: the forward input / the inverse result is the intermediate of a one-launch transform
-template <bool INVERSE, bool CANON_OUT, int FUSE, int MID>
+template <bool INVERSE, bool CANON_OUT, int FUSE>
 __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
                                             u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
@@ -616,8 +601,8 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
 
   if (!INVERSE) {
     u64 x[16];
-    if (q <= kSmallPrimeMax) contig_fwd_body<true, MID>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
-    else                     contig_fwd_body<false, MID>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    if (q <= kSmallPrimeMax) contig_fwd_body<true>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    else                     contig_fwd_body<false>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
@@ -652,8 +637,8 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   } else {
     const u64* __restrict__ S =
         FUSE ? (w.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
-    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, MID>(X, S, TW, lds, s8, o, b, lo4, q);
-    else                     contig_inv_body<false, CANON_OUT, MID>(X, S, TW, lds, s8, o, b, lo4, q);
+    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
+    else                     contig_inv_body<false, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
   }
 }
 
@@ -665,7 +650,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   NttWg w{blk.tile, blk.y, blk.z, 0, 0};
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
-  contig_pass<INVERSE, CANON_OUT, FUSE, 0>(c, poly, poly_stride, pos_off, f, lds, w);
+  contig_pass<INVERSE, CANON_OUT, FUSE>(c, poly, poly_stride, pos_off, f, lds, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,63 +982,6 @@ static bool launch_ntt_narrow(const DevCtx& c, u64* poly, u32 level, u32 pos0, u
   return true;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Both passes of an N = 2^16 transform in ONE launch.  The 16 workgroups of a limb each run first-pass tile t, publish it,
-// wait until all 16 first-pass tiles of THEIR limb are published and then run second-pass tile t of the same limb: one
-// launch, one fetch of the kernel arguments and prime constants, no kernel boundary (and no second launch floor) between
-// the passes.  Most transforms of the workload cover 1..100 limbs, where those fixed costs are half of the time.
-//
-// Hand-off (MI355X_MICROARCH.md "inter-workgroup visibility"): intermediate stores are write-through (sc1), every storing
-// wave drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane adds 1 to the limb's counter (agent-scope
-// atomic); the consumer polls the counter with sc1 loads from one lane, meets at a barrier and reads the intermediate with
-// sc1 loads (L1 bypassed; a 128-byte line of the intermediate was touched before by its producing workgroup only, so no
-// other L2 can hold a stale copy of it).  Nothing here depends on where workgroups run.
-// Progress: a workgroup waits only for workgroups of its own 16-group.  Block ids are laid out so that the group's members
-// are consecutive in dispatch order on one XCD (ids congruent mod 8, ntt_one_block): under the in-order dispatch of a grid
-// the members become resident together; at most one group per launch and XCD can be partially resident (<= 15 waiting
-// workgroups), far fewer than an XCD's workgroup slots even with every hardware queue running such a launch, so a free slot
-// for the missing members always appears.  The poll is bounded all the same: a workgroup that waits for ~1 s traps instead
-// of hanging the device.
-// Counters: one u32 per limb of the launch, taken from a ring that is zeroed when it wraps (launch_ntt_fused).
-// ------------------------------------------------------------------------------------------------
-// block -> (tile, limb row y, polynomial z): the 8 XCD lanes carry limb rows y = 8*yq + lane, every row's 16 tiles are
-// consecutive on its lane, polynomials z of the same row (same prime: same twiddles) follow each other on the same lane
-__device__ __forceinline__ NttBlk ntt_one_block(u32 n_polys) {
-  const u32 b = blockIdx.x, lane = b & 7u, r = b >> 3, tile = r & 15u, s = r >> 4;
-  const u32 z = s % n_polys, yq = s / n_polys;
-  return NttBlk{tile, (u32)__builtin_amdgcn_readfirstlane(yq * 8 + lane), (u32)__builtin_amdgcn_readfirstlane(z)};
-}
-constexpr u32 kNttOneTiles = 16;
-
-template <bool INVERSE, int SRC, int FUSE>
-__global__ __launch_bounds__(256, 4) void ntt16_one_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
-                                                        u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
-                                                        u32 n_limbs, u32 n_polys, u32* __restrict__ counters) {
-  __shared__ u64 lds[16 * kBlkPitch];  // = 256 * kRowPitch words: both passes use the same 34 KiB
-  static_assert(16 * kBlkPitch == 256 * kRowPitch, "the two passes share one LDS tile");
-  const NttBlk blk = ntt_one_block(n_polys);
-  if (blk.y >= n_limbs) return;  // grid padding (limb rows are dealt in eights)
-  NttWg w{blk.tile, blk.y, blk.z, 0, 0};
-  if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;  // the whole 16-group of a missing row leaves
-  u32* ctr = counters + (blk.z * n_limbs + blk.y);
-  if (!INVERSE) strided_pass<false, SRC, 1>(c, poly, poly_stride, pos_off, f, lds, w);
-  else          contig_pass<true, false, FUSE, 1>(c, poly, poly_stride, pos_off, f, lds, w);
-  // publish: every wave's intermediate stores have left (write-through), then one arrival per workgroup
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kNttOneTiles) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 24)) __builtin_trap();  // ~1 s: never observed; a trap is reported, a hang is not
-    }
-  }
-  __syncthreads();
-  if (!INVERSE) contig_pass<false, true, FUSE, 1>(c, poly, poly_stride, pos_off, f, lds, w);
-  else          strided_pass<true, SRC_MEM, 1>(c, poly, poly_stride, pos_off, f, lds, w);
-}
-
 // logN >= 16 uses both fast passes when logN == 16; the contig pass alone serves the last 8 stages of
 // any logN >= 13 (the generic LDS kernel does the leading logN-8 stages).
 void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
@@ -1061,43 +989,10 @@ void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limb
   launch_ntt_fused(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, NttFuse{});
 }
 
-// one launch for both passes when the context has a counter ring and the (source, epilogue) combination is instantiated
-static bool launch_ntt_one(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
-                           u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
-  if (c.sync_ring == nullptr || c.sync_cursor == nullptr || f.gi_tab != nullptr || f.conv != nullptr) return false;
-  const u32 need = n_limbs * n_polys;
-  if (need > c.sync_size || n_limbs > c.one_launch_max_limbs) return false;
-  if (!inverse && f.msg && f.epi == 2) return false;  // not instantiated (no caller)
-  if (*c.sync_cursor + need > c.sync_size) {  // wrap: every earlier launch of this stream is ordered before the memset
-    if (hipMemsetAsync(c.sync_ring, 0, (size_t)c.sync_size * sizeof(u32), s) != hipSuccess) return false;
-    *c.sync_cursor = 0;
-  }
-  u32* ctr = c.sync_ring + *c.sync_cursor;
-  *c.sync_cursor += need;
-  dim3 block(256), grid(((n_limbs + 7) / 8) * 8 * 16 * n_polys);
-#define ACEHIP_ONE_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys, ctr
-  if (!inverse) {
-    if (f.msg) {
-      if (f.epi == 1) hipLaunchKernelGGL((ntt16_one_kernel<false, SRC_MSG, 1>), ACEHIP_ONE_ARGS);
-      else            hipLaunchKernelGGL((ntt16_one_kernel<false, SRC_MSG, 0>), ACEHIP_ONE_ARGS);
-    } else {
-      if (f.epi == 1)      hipLaunchKernelGGL((ntt16_one_kernel<false, SRC_MEM, 1>), ACEHIP_ONE_ARGS);
-      else if (f.epi == 2) hipLaunchKernelGGL((ntt16_one_kernel<false, SRC_MEM, 2>), ACEHIP_ONE_ARGS);
-      else                 hipLaunchKernelGGL((ntt16_one_kernel<false, SRC_MEM, 0>), ACEHIP_ONE_ARGS);
-    }
-  } else {
-    if (f.src0) hipLaunchKernelGGL((ntt16_one_kernel<true, SRC_MEM, 1>), ACEHIP_ONE_ARGS);
-    else        hipLaunchKernelGGL((ntt16_one_kernel<true, SRC_MEM, 0>), ACEHIP_ONE_ARGS);
-  }
-#undef ACEHIP_ONE_ARGS
-  return true;
-}
-
 void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                       u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
   ACEHIP_ABLATE(ABL_NTT);
   if (n_limbs == 0) return;
-  if (launch_ntt_one(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys

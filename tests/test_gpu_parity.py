@@ -349,21 +349,6 @@ def test_conv_fusion_matches():
     assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
 
 
-def test_one_launch_ntt_matches():
-    """ACEHIP_NTT_ONE_LAUNCH=n (both passes of an N = 2^16 transform in one launch with an in-kernel hand-off between the
-    workgroups of a limb, ntt_fast.hip ntt16_one_kernel) is an opt-in variant, slower than two launches on MI355X: it must
-    still reproduce the reference-generated golden vectors and the fused-neighbour paths bit for bit."""
-    import subprocess
-    import sys
-
-    env = dict(os.environ, ACEHIP_NTT_ONE_LAUNCH="64")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536"], env=env, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
-
-
 @pytest.mark.parametrize("rows", ["0", "100000"], ids=["wide_only", "narrow_always"])
 def test_ntt_tile_width_variants_match(rows):
     """N = 2^16 transforms run as narrow passes (1024-coefficient tiles, ntt_fast.hip ntt4_*) up to ACEHIP_NTT_NARROW limb rows
