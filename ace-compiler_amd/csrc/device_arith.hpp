@@ -75,9 +75,10 @@ __device__ __forceinline__ void mac128(U128& acc, u64 a, u64 b) {
   acc.hi = (u64)(v >> 64);
 }
 
-// (hi:lo) mod q with mu = floor(2^128/q) = (mh:ml); same quotient estimate as the reference's
-// Mod_barrett_128 (fhe_utils.h:241-280); the estimate is at most 2 below the true quotient.
-__device__ __forceinline__ u64 reduce128(U128 v, u64 q, u64 ml, u64 mh) {
+// (hi:lo) mod q with mu = floor(2^128/q) = (mh:ml), canonical result (the reference reduces the same sums with
+// Mod_barrett_128, fhe_utils.h:241-280; any exact reduction gives the same residue).
+// Generic form: the reference's quotient estimate, at most 2 below the true quotient.
+__device__ __forceinline__ u64 reduce128_generic(U128 v, u64 q, u64 ml, u64 mh) {
   // qhat = floor( (v.hi:v.lo) * (mh:ml) / 2^128 ) up to the dropped low partial product
   const unsigned __int128 mid = (unsigned __int128)v.lo * mh + mulhi64(v.lo, ml);  // < 2^128
   const unsigned __int128 m2 = (unsigned __int128)v.hi * ml + (u64)mid;            // carries into bit 64
@@ -85,6 +86,29 @@ __device__ __forceinline__ u64 reduce128(U128 v, u64 q, u64 ml, u64 mh) {
   u64 r = v.lo - qhat * q;
   while (r >= q) r -= q;
   return r;
+}
+// Primes above 2^32 (every prime of a real parameter set) have mh < 2^32, and the base-conversion / BSGS kernels spend
+// more instructions in this reduction than in their multiply-adds (profiles/r02y: base_conv_batch16_kernel issues VALU
+// instructions 88 % of the time), so the quotient is assembled from the three partial products that matter:
+//   floor(v*mu/2^128) = v1*mh + floor((v1*ml + v0*mh + floor(v0*ml/2^64)) / 2^64)
+//                     = lo64(v1*mh) + hi64(v1*ml) + hi64(v0*mh) + c,  c in {0,1,2}   (mod 2^64; the true quotient may exceed 64
+// bits, only its low word enters r), i.e. at most 2 + 2 below the true quotient: r = v0 - qhat*q lies in [0,5q) (q < 2^61,
+// host_params) and three conditional subtractions make it canonical -- no 128-bit adds, no data-dependent loop.
+__device__ __forceinline__ u64 reduce128(U128 v, u64 q, u64 ml, u64 mh) {
+  if (mh >> 32) return reduce128_generic(v, q, ml, mh);  // wave-uniform: a property of the prime
+  const u32 m = (u32)mh;
+  const u32 v0l = (u32)v.lo, v0h = (u32)(v.lo >> 32), v1l = (u32)v.hi, v1h = (u32)(v.hi >> 32);
+  u64 A = (u64)v1l * m;                          // lo64(v1 * mh)
+  A += (u64)(u32)((u64)v1h * m) << 32;
+  const u64 B = mulhi64(v.hi, ml);               // hi64(v1 * ml)
+  const u64 t1 = (u64)v0l * m;                   // hi64(v0 * mh) = (v0h*m + hi32(v0l*m)) >> 32
+  const u64 t2 = (u64)v0h * m + (t1 >> 32);
+  const u64 qhat = A + B + (t2 >> 32);
+  u64 r = v.lo - qhat * q;
+  const u64 q4 = 4 * q, q2 = 2 * q;
+  r = r >= q4 ? r - q4 : r;
+  r = r >= q2 ? r - q2 : r;
+  return r >= q ? r - q : r;
 }
 
 // Switch_modulus (fhe_utils.h:349-375): centred lift of v in [0,old_q) to [0,new_q)
