@@ -80,6 +80,7 @@ SYMBOLS = [
     ("acehip_mul_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_add_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_modup_digits", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    ("acehip_modup_digits_to", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_inner_product", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),

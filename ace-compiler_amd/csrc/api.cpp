@@ -1605,16 +1605,23 @@ int acehip_add_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint
   launch_add_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
-// Switch_key_precompute (polynomial.c:1224-1239, 1337-1343): every digit of d_in raised to level+K limbs
-int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32_t level, acehip_stream s_) {
+// Switch_key_precompute (polynomial.c:1224-1239, 1337-1343): every digit of d_in raised to level+K limbs.
+// h_ext[d] = output polynomial of digit d (separate blocks: the rt_ant shim hands them to the caller's polynomials without a copy)
+static int modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t* in, uint32_t level, acehip_stream s_) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_modup_digits: bad level");
   const HostParams& hp = c->hp;
   hipStream_t s = (hipStream_t)s_;
   const KsPlan* plan = get_ks_plan(c, level);
   if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
-  const size_t N = hp.N, E = (size_t)(level + hp.K) * N;
+  const size_t N = hp.N;
   const u32 nd = plan->nd;
+  if (nd > 8) return fail(ACEHIP_EINVAL, "acehip_modup_digits: more than 8 digits");
+  PtrTab8 outz;
+  for (u32 d = 0; d < nd; ++d) {
+    if (!h_ext[d]) return fail(ACEHIP_EINVAL, "acehip_modup_digits: null output");
+    outz.p[d] = h_ext[d];
+  }
   u64* coef = c->ws;
   if (c->dc.logN == 16) {
     NttFuse fi;
@@ -1633,10 +1640,21 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
     fc.conv_max_in = hp.alpha;
     fc.conv_src = coef;
     fc.conv_src_stride = 0;
-    launch_ntt_fused(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
+    for (u32 d = 0; d < nd; ++d) fc.polyz[d] = outz.p[d];
+    launch_ntt_fused(c->dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fc);
   } else {
-    launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
-    launch_ntt(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
+    launch_base_conv_batch(c->dc, outz.p[0], 0, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, outz);
+    if (c->dc.logN == 16) {
+      NttFuse fz;
+      for (u32 d = 0; d < nd; ++d) fz.polyz[d] = outz.p[d];
+      launch_ntt_fused(c->dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fz);
+    } else {
+      for (u32 d = 0; d < nd; ++d) {  // the generic passes address polynomials by stride: one digit at a time
+        const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
+        if (start) launch_ntt(c->dc, outz.p[d], level, 0, start, false, s);
+        launch_ntt(c->dc, outz.p[d], level, start + n2, level + hp.K - (start + n2), false, s);
+      }
+    }
   }
   {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
     HwBatchArgs cp;
@@ -1644,13 +1662,26 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
     for (u32 pos = 0; pos < level; ++pos) {
       if (n_ops == HW_BATCH_MAX) return fail(ACEHIP_EINVAL, "acehip_modup_digits: too many limbs");
       cp.seg_start[n_ops] = (uint16_t)n_ops;
-      cp.op[n_ops++] = HwBatchOp{ext + (pos / hp.alpha) * E + (size_t)pos * N, in + (size_t)pos * N, nullptr, HW_OP_COPY, 0};
+      cp.op[n_ops++] = HwBatchOp{outz.p[pos / hp.alpha] + (size_t)pos * N, in + (size_t)pos * N, nullptr, HW_OP_COPY, 0};
     }
     cp.seg_start[n_ops] = (uint16_t)n_ops;
     launch_hw_batch_ew(c->dc, cp, n_ops, s);
   }
   stat(ST_MODUP, nd, 8ull * N * (level + (u64)nd * (level + hp.K)));
   return post_launch();
+}
+int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32_t level, acehip_stream s) {
+  if (!c || level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_modup_digits: bad level");
+  const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
+  uint64_t* tab[8];
+  const u32 nd = c->hp.num_decomp(level);
+  if (nd > 8) return fail(ACEHIP_EINVAL, "acehip_modup_digits: more than 8 digits");
+  for (u32 d = 0; d < nd; ++d) tab[d] = ext + d * E;
+  return modup_digits_to(c, tab, in, level, s);
+}
+int acehip_modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t* in, uint32_t level, acehip_stream s) {
+  if (!c || !h_ext) return fail(ACEHIP_EINVAL, "acehip_modup_digits_to: null argument");
+  return modup_digits_to(c, h_ext, in, level, s);
 }
 // Fast_switch_key_ext (ckks_evaluator.c:418-460): acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K limbs, no ModDown
 int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, const uint64_t* key, const uint64_t* ext, uint32_t level, acehip_stream s) {

@@ -155,9 +155,13 @@ void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, 
                       u32 n_in, u32 n_out, u32 hat_ld, hipStream_t s);
 // batched form: problem z = blockIdx.z uses descs[z*desc_step], reads in + z*in_stride (coefficient domain
 // limbs at positions src_pos0..), writes out + z*out_stride
+struct PtrTab8 {  // up to 8 per-problem output polynomials as a kernel argument; p[0] == nullptr: out + z*out_stride instead
+  u64* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
                             const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s,
-                            u32 max_n_in = 0);  // max_n_in: largest n_in of the problems when known (selects the <= 16 kernel)
+                            u32 max_n_in = 0,  // max_n_in: largest n_in of the problems when known (selects the <= 16 kernel)
+                            const PtrTab8& outz = PtrTab8{});
 // fused key inner product over all digits (generated code inc:7011-7036 for every part):
 //   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,

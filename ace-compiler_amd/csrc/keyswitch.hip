@@ -20,7 +20,7 @@ constexpr int kConvMaxIn = 64;  // source limbs of one conversion (digit size al
 // staged in LDS, already split (every lane reads the same address: a broadcast).
 __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                               const u64* __restrict__ in, size_t in_stride,
-                                                              const ConvDesc* __restrict__ descs, u32 desc_step) {
+                                                              const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
   __shared__ uint2 s_hat[kConvMaxIn * kGroup];  // this row's constants, already split: {low half, high half}
   const ConvDesc d = descs[blockIdx.z * desc_step];
   const u32 j0 = blockIdx.y * kGroup;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
   const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + n;
-  u64* dst = out + blockIdx.z * out_stride + n;
+  u64* dst = (outz.p[0] ? outz.p[blockIdx.z] : out + blockIdx.z * out_stride) + n;
   const u32 chunk = h <= 30 ? 16u : (h == 31 ? 4u : 1u);  // terms whose partial products fit 64-bit sums
   unsigned __int128 tot[kGroup];
   u64 s00[kGroup], s01[kGroup], s10[kGroup], s11[kGroup];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
 // running total (<= 128 VGPRs: 4 workgroups per CU), and the per-output reduction constants come from LDS.
 __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                                    const u64* __restrict__ in, size_t in_stride,
-                                                                   const ConvDesc* __restrict__ descs, u32 desc_step) {
+                                                                   const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
   constexpr u32 kIn = 16;
   __shared__ uint2 s_hat[kIn * kGroup];
   __shared__ u64 s_q[kGroup], s_ml[kGroup], s_mh[kGroup];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
       s11[g] += (u64)a1 * b.y;
     }
   }
-  u64* dst = out + blockIdx.z * out_stride + n;
+  u64* dst = (outz.p[0] ? outz.p[blockIdx.z] : out + blockIdx.z * out_stride) + n;
 #pragma unroll
   for (int g = 0; g < kGroup; ++g) {
     if (j0 + g < d.n_out) {
@@ -141,14 +141,15 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
 }
 
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
-                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s, u32 max_n_in) {
+                            const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s, u32 max_n_in,
+                            const PtrTab8& outz) {
   ACEHIP_ABLATE(ABL_CONV);
   if (n_problems == 0 || max_n_out == 0) return;
   dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems), block(256);
   if (max_n_in != 0 && max_n_in <= 16 && c.split_bits <= 30)
-    hipLaunchKernelGGL(base_conv_batch16_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
+    hipLaunchKernelGGL(base_conv_batch16_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
   else
-    hipLaunchKernelGGL(base_conv_batch_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step);
+    hipLaunchKernelGGL(base_conv_batch_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
 }
 
 // acc{0,1}[pos][n] = sum_d key{0,1}[d][gi][n] * e_d[pos][n];  key layout [nd][2][L+K][N]

@@ -237,6 +237,9 @@ int acehip_add_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, co
  * Fast_switch_key_ext (ckks_evaluator.c:418-460): d_acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K
  *   limbs, no ModDown. */
 int acehip_modup_digits(acehip_ctx* ctx, uint64_t* d_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
+/* The same with one output block per digit: h_ext is a HOST array of acehip_num_decomp(ctx, level) device pointers, each to
+ * (level + K) limbs.  (The rt_ant shim swaps these blocks into the caller's polynomials instead of copying.) */
+int acehip_modup_digits_to(acehip_ctx* ctx, uint64_t* const* h_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext, uint32_t level, acehip_stream stream);
 /* Baby-step giant-step inner products of Rotate_iteration (ckks_bootstrap_context.c:1326-1341: Mul_plaintext +
  * Add_ciphertext over one giant step, for every baby step): d_out{0,1}[i] = sum_{j<g} d_in{0,1}[j] (*) pt[i*g + j],
