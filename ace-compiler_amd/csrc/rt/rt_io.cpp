@@ -397,7 +397,10 @@ static void pt_cache_clear() {
 // ---- weight-plaintext prefetch (Context::pt_trace) ----
 static int pt_prefetch_batch() {
   static const int n = [] {
-    const char* e = getenv("ACEHIP_PT_PREFETCH");  // batch size; 0 / 1 = off
+    // batch size; 0 / 1 = off.  The reference's own knob for its weight-plaintext prefetch (PT_PREFETCH_COUNT, rt_env.h:27,
+    // pt_mgr.c:42-46: entries read ahead) is honoured when ours is not set
+    const char* e = getenv("ACEHIP_PT_PREFETCH");
+    if (e == nullptr) e = getenv("PT_PREFETCH_COUNT");
     int v = e ? atoi(e) : 8;
     return v < 0 ? 0 : (v > 8 ? 8 : v);
   }();
