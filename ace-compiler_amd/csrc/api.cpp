@@ -172,6 +172,18 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   ctx->p_gi = ctx->up(pgi);
   ctx->q_gi = ctx->up(qgi);
   ctx->q_pos = ctx->q_gi;
+  if (hp.logN == 16) {  // companion-only twiddle tables (ntt_fast.hip Tp15): 8-byte twiddle stream in the contiguous passes
+    // ACEHIP_NTT_TW8_POLYS = largest number of polynomials per launch that uses them (0: never).  Measured: ResNet-20 1.68 ->
+    // 1.73 images/s, C3 key-switch 0.248 -> 0.237 ms, 1024-limb batch 0.555 -> 0.537 ms with every launch on the 8-byte stream
+    const char* e = getenv("ACEHIP_NTT_TW8_POLYS");
+    const u32 maxp = e ? (u32)strtoul(e, nullptr, 0) : 65535u;
+    if (maxp) {
+      ctx->dc.twp_fwd = ctx->up(hp.rou_prec);
+      ctx->dc.twp_inv = ctx->up(hp.rou_inv_prec);
+      ctx->dc.tw8_max_polys = (ctx->dc.twp_fwd && ctx->dc.twp_inv) ? maxp : 0;
+      if (!ctx->dc.tw8_max_polys) ctx->dc.twp_fwd = ctx->dc.twp_inv = nullptr;
+    }
+  }
   {  // ACEHIP_NTT_NARROW = largest launch (limb rows) that takes the narrow small-launch passes (0: never)
     const char* e = getenv("ACEHIP_NTT_NARROW");
     ctx->dc.ntt_narrow_max_rows = e ? (u32)strtoul(e, nullptr, 0) : 16u;

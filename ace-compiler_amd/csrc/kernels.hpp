@@ -27,6 +27,11 @@ struct DevCtx {
   u32 split_bits;  // ceil(max prime bits / 2): base conversion multiplies in halves of this width (keyswitch.hip)
   // N = 2^16 transforms of at most this many limb rows (limbs x polynomials) run as narrow passes (ntt_fast.hip ntt4_*)
   u32 ntt_narrow_max_rows = 0;
+  // companion-only twiddle tables [L+K][N] (8 bytes per entry; ntt_fast.hip Tp15) and the largest number of polynomials
+  // per launch for which the contiguous passes read them instead of the 16-byte tables
+  const u64* twp_fwd = nullptr;
+  const u64* twp_inv = nullptr;
+  u32 tw8_max_polys = 0;
 };
 
 // prime (global index) of the limb at position pos of a polynomial extended at `level`

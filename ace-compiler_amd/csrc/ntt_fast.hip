@@ -220,6 +220,72 @@ __device__ __forceinline__ void load_tw(const ulong2* __restrict__ TW, u32 sbase
   for (int i = 0; i < 8; ++i) t3[i] = ldtw<SMALL>(TW, (8u << sbase) + (prefix << 3) + i);
 }
 
+// Companion-only twiddles (TW8: 8 bytes per entry instead of 16).  p = floor(w*2^64/q) determines w: p*q = w*2^64 - r with
+// 0 < r < q, so w = mulhi64(p, q) + 1 exactly.  In the small launches of the workload the passes wait for memory (VALU issue in
+// 30 % of the cycles, profiles/r02z) and the 16-byte twiddle stream of the last four stages is as large as the data of the
+// pass; loading p alone halves it for 4 multiply-adds per twiddle.  The twiddle is derived right before its butterflies, so
+// only the companions (30 registers instead of 60) stay live.  Used when few polynomials share a limb's twiddles.
+struct Tp15 {
+  u64 p0, p1[2], p2[4], p3[8];
+};
+__device__ __forceinline__ void load_tp(const u64* __restrict__ TP, u32 sbase, u32 prefix, Tp15& t) {
+  t.p0 = TP[(1u << sbase) + prefix];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) t.p1[i] = TP[(2u << sbase) + (prefix << 1) + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t.p2[i] = TP[(4u << sbase) + (prefix << 2) + i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t.p3[i] = TP[(8u << sbase) + (prefix << 3) + i];
+}
+template <bool SMALL>
+__device__ __forceinline__ Tw tw_of(u64 p, u64 q) {
+  return Tw{mulhi64(p, q) + 1, SMALL ? p >> 1 : p};
+}
+template <bool SMALL>
+__device__ __forceinline__ void radix16_fwd_p(u64 (&x)[16], const Tp15& t, const BfK& k) {
+  {
+    const Tw w = tw_of<SMALL>(t.p0, k.q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bf_fwd<SMALL>(x[i], x[i + 8], w, k);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const Tw w = tw_of<SMALL>(t.p1[g], k.q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf_fwd<SMALL>(x[8 * g + i], x[8 * g + i + 4], w, k);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const Tw w = tw_of<SMALL>(t.p2[g], k.q);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bf_fwd<SMALL>(x[4 * g + i], x[4 * g + i + 2], w, k);
+  }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bf_fwd<SMALL>(x[2 * g], x[2 * g + 1], tw_of<SMALL>(t.p3[g], k.q), k);
+}
+template <bool SMALL>
+__device__ __forceinline__ void radix16_inv_p(u64 (&x)[16], const Tp15& t, const BfK& k) {  // stages 3..0
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bf_inv<SMALL>(x[2 * g], x[2 * g + 1], tw_of<SMALL>(t.p3[g], k.q), k);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const Tw w = tw_of<SMALL>(t.p2[g], k.q);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bf_inv<SMALL>(x[4 * g + i], x[4 * g + i + 2], w, k);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const Tw w = tw_of<SMALL>(t.p1[g], k.q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf_inv<SMALL>(x[8 * g + i], x[8 * g + i + 4], w, k);
+  }
+  {
+    const Tw w = tw_of<SMALL>(t.p0, k.q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bf_inv<SMALL>(x[i], x[i + 8], w, k);
+  }
+}
+
 // The 15 twiddles of stages 0..3 (TW[1..15]) are the same for every lane: read through the constant address space they
 // become scalar loads, live in SGPRs (60 of them instead of 60 VGPRs) and enter the multiply-adds as their one scalar operand.
 // (The tables are written once at context creation, never by a kernel.)
@@ -510,9 +576,9 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 // ------------------------------------------------------------------------------------------------
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
 // rho = 16*lo4+k on return
-template <bool SMALL>
-__device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, u32 s8, u32 o,
-                                                u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
+template <bool SMALL, bool TW8>
+__device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, const u64* __restrict__ TP,
+                                                u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
   const BfK bk = bf_consts<SMALL>(q);
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
@@ -526,21 +592,24 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
-  load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  Tp15 tp;
+  if (TW8) load_tp(TP, s8 + 4, 16 * o + lo4, tp);
+  else     load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
   __syncthreads();
   // round B: stages s8+4..s8+7 on rho = 16h + g'
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-  radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
+  if (TW8) radix16_fwd_p<SMALL>(x, tp, bk);
+  else     radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = canon_fwd<SMALL>(x[k], q, mu);
 }
 
 // inverse rounds: the tile is read from S (coalesced 16-byte loads through LDS), round B first (stages s8+7..s8+4 on the 16
 // contiguous rho = 16h + g'), then round A (stages s8+3..s8 on rho = 16k + g); lazy [0,lim) output unless CANON_OUT
-template <bool SMALL, bool CANON_OUT>
-__device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW, u64* lds,
-                                                u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
+template <bool SMALL, bool CANON_OUT, bool TW8>
+__device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW,
+                                                const u64* __restrict__ TP, u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
   const BfK bk = bf_consts<SMALL>(q);
   const u32 tid = threadIdx.x;
   u64 x[16];
@@ -556,12 +625,18 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
     lds[bb * kBlkPitch + cpad(rho)] = v.x;
     lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
   }
-  load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  Tp15 tp;
+  if (TW8) load_tp(TP, s8 + 4, 16 * o + lo4, tp);
+  else     load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
-  radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
-  radix16_inv_0<SMALL>(x, t0, bk);
+  if (TW8) {
+    radix16_inv_p<SMALL>(x, tp, bk);
+  } else {
+    radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+    radix16_inv_0<SMALL>(x, t0, bk);
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
@@ -587,7 +662,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
 // CONTIG pass of one workgroup.
 // FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
 // f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
-template <bool INVERSE, bool CANON_OUT, int FUSE>
+template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8>
 __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
                                             u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
@@ -595,14 +670,15 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   const u32 pos = w.pos;
   u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const u64* __restrict__ TP = TW8 ? (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N : nullptr;
   const u32 s8 = c.logN - 8;
   const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
   const u32 o = w.tile * 16 + b;
 
   if (!INVERSE) {
     u64 x[16];
-    if (q <= kSmallPrimeMax) contig_fwd_body<true>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
-    else                     contig_fwd_body<false>(X, TW, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    if (q <= kSmallPrimeMax) contig_fwd_body<true, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    else                     contig_fwd_body<false, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
@@ -637,12 +713,12 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   } else {
     const u64* __restrict__ S =
         FUSE ? (w.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
-    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
-    else                     contig_inv_body<false, CANON_OUT>(X, S, TW, lds, s8, o, b, lo4, q);
+    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
+    else                     contig_inv_body<false, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
   }
 }
 
-template <bool INVERSE, bool CANON_OUT, int FUSE>
+template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8 = false>
 __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                           u32 n_limbs, u32 n_polys) {
@@ -650,7 +726,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
   const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
   NttWg w{blk.tile, blk.y, blk.z, 0, 0};
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
-  contig_pass<INVERSE, CANON_OUT, FUSE>(c, poly, poly_stride, pos_off, f, lds, w);
+  contig_pass<INVERSE, CANON_OUT, FUSE, TW8>(c, poly, poly_stride, pos_off, f, lds, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -995,18 +1071,30 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   if (n_limbs == 0) return;
   if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
+  const bool tw8 = c.twp_fwd != nullptr && n_polys <= c.tw8_max_polys;  // few polynomials share the twiddles: 8-byte stream
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
     else if (f.conv && f.conv_max_in <= 8)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV8>), ACEHIP_NTT_ARGS);
     else if (f.conv)               hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV12>), ACEHIP_NTT_ARGS);
     else                           hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MEM>), ACEHIP_NTT_ARGS);
-    if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1>), ACEHIP_NTT_ARGS);
-    else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2>), ACEHIP_NTT_ARGS);
-    else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), ACEHIP_NTT_ARGS);
+    if (tw8) {
+      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, true>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, true>), ACEHIP_NTT_ARGS);
+      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, true>), ACEHIP_NTT_ARGS);
+    } else {
+      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2>), ACEHIP_NTT_ARGS);
+      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), ACEHIP_NTT_ARGS);
+    }
   } else {
-    if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1>), ACEHIP_NTT_ARGS);
-    else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0>), ACEHIP_NTT_ARGS);
+    if (tw8) {
+      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, true>), ACEHIP_NTT_ARGS);
+      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, true>), ACEHIP_NTT_ARGS);
+    } else {
+      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1>), ACEHIP_NTT_ARGS);
+      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0>), ACEHIP_NTT_ARGS);
+    }
     hipLaunchKernelGGL((ntt8_strided_kernel<true, SRC_MEM>), ACEHIP_NTT_ARGS);
   }
 #undef ACEHIP_NTT_ARGS

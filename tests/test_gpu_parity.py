@@ -349,15 +349,16 @@ def test_conv_fusion_matches():
     assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
 
 
-@pytest.mark.parametrize("rows", ["0", "100000"], ids=["wide_only", "narrow_always"])
-def test_ntt_tile_width_variants_match(rows):
+@pytest.mark.parametrize("rows,tw8", [("0", "65535"), ("100000", "65535"), ("0", "0")], ids=["wide_only", "narrow_always", "wide_16byte_twiddles"])
+def test_ntt_tile_width_variants_match(rows, tw8):
     """N = 2^16 transforms run as narrow passes (1024-coefficient tiles, ntt_fast.hip ntt4_*) up to ACEHIP_NTT_NARROW limb rows
     and as wide passes (4096-coefficient tiles) above: both must reproduce the reference-generated golden vectors and the
-    fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced."""
+    fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced -- and once with
+    the contiguous passes on the 16-byte twiddle tables (ACEHIP_NTT_TW8_POLYS=0) instead of the companion-only stream."""
     import subprocess
     import sys
 
-    env = dict(os.environ, ACEHIP_NTT_NARROW=rows)
+    env = dict(os.environ, ACEHIP_NTT_NARROW=rows, ACEHIP_NTT_TW8_POLYS=tw8)
     tests = [os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_encode.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + tests + ["-k",
                         "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536 or "
