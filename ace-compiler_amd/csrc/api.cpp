@@ -75,6 +75,7 @@ struct acehip_ctx {
   std::mutex mu;
   std::map<std::pair<u32, u32>, DevModUp> modup;
   std::map<u32, u32*> auto_tabs;
+  std::map<const void*, u32> auto_tab_k;   // device table -> automorphism index (hw_run_rotate: the kernel computes the index map)
   std::map<u32, KsPlan> ks_plans;
   // workspace (one per context; launches of one context are expected on one stream at a time)
   u64* ws = nullptr;
@@ -286,6 +287,7 @@ const uint32_t* acehip_auto_order(acehip_ctx* c, uint32_t k) {
     return nullptr;
   }
   c->auto_tabs[k] = d;
+  c->auto_tab_k[d] = k;
   return d;
 }
 
@@ -962,7 +964,15 @@ void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t
       n_ops = 0;
       first = k;
     }
-    args.op[n_ops++] = HwBatchOp{ops[k].res, ops[k].a, (const u64*)ops[k].b, ops[k].op, ops[k].prime_gi};
+    // a table this context built is a known automorphism k: the kernel computes perm[i] = rev(((2 rev(i) + 1) k mod 2N) / 2)
+    // itself instead of loading 4 bytes per coefficient (gi carries k; 0 = load the caller's table)
+    u32 auto_k = 0;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      auto it = c->auto_tab_k.find(ops[k].b);
+      if (it != c->auto_tab_k.end()) auto_k = it->second;
+    }
+    args.op[n_ops++] = HwBatchOp{ops[k].res, ops[k].a, (const u64*)ops[k].b, ops[k].op, auto_k};
   }
   emit_rotate(c, args, n_ops, st);
 }

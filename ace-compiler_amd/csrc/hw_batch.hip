@@ -118,12 +118,23 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
 }
 
 // independent gathers r[j] = a[perm[j]] (the host guarantees no result aliases any source of the launch)
+// op.gi != 0: the table op.b is the automorphism X -> X^k of this context (k = op.gi), whose index map in the NTT (bit-reversed)
+// order is perm[i] = rev(((2 rev(i) + 1) k mod 2N) >> 1) (host_params.cpp automorphism_order_ntt): computed here, 4 bytes per
+// coefficient less to load.  op.gi == 0: a caller-supplied permutation, loaded.
 template <int CAP>
 __global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgsT<CAP> args) {
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= N) return;
   const HwBatchOp op = args.op[blockIdx.y];
-  const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const u32*>(op.b) + i);
+  uint2 p;
+  if (op.gi != 0) {  // uniform for the workgroup
+    const u32 sh = __builtin_clz(N) + 1;  // 32 - log2(N)
+    const u32 j0 = __brev(i) >> sh, j1 = __brev(i + 1) >> sh;
+    p.x = __brev((((2 * j0 + 1) * op.gi) & (2 * N - 1)) >> 1) >> sh;
+    p.y = __brev((((2 * j1 + 1) * op.gi) & (2 * N - 1)) >> 1) >> sh;
+  } else {
+    p = *reinterpret_cast<const uint2*>(reinterpret_cast<const u32*>(op.b) + i);
+  }
   ulong2 v;
   v.x = op.a[p.x];
   v.y = op.a[p.y];
