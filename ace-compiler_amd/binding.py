@@ -61,6 +61,8 @@ SYMBOLS = [
     ("acehip_hw_rotate", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_batch", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_hw_batch_plan", C.c_long, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _u64]),
+    ("acehip_hw_batch_discard", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    ("acehip_hw_batch_plan_discard", C.c_long, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _u64]),
     ("acehip_stats", C.c_int, [_vp, C.c_int, C.c_int]),
     ("acehip_stat_name", C.c_char_p, [C.c_int]),
     ("acehip_decomp_modup", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
@@ -125,6 +127,14 @@ def load_library(path=None):
 class HwOp(C.Structure):
     """acehip_hw_op of include/acehip.h"""
     _fields_ = [("op", C.c_uint32), ("prime_gi", C.c_uint32), ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p)]
+
+
+class HwRange(C.Structure):
+    """acehip_hw_range of include/acehip.h"""
+    _fields_ = [("ptr", C.c_void_p), ("words", C.c_size_t)]
+
+
+HW_NOSTORE = 0x80000000
 
 
 HW_ADD, HW_MUL, HW_ROTATE, HW_COPY, HW_ZERO, HW_SUB, HW_MULADD, HW_MULC, HW_ADDC = range(9)
@@ -323,6 +333,12 @@ class AceHip:
         """ops: iterable of (op, prime_gi, res_ptr, a_ptr, b_ptr) device addresses -> acehip_hw_batch"""
         arr = (HwOp * len(ops))(*[HwOp(o, g, r, a or None, b or None) for o, g, r, a, b in ops])
         self.check(self.lib.acehip_hw_batch(self.h, arr, len(ops), None))
+
+    def hw_batch_discard(self, ops, dead):
+        """acehip_hw_batch_discard: dead = iterable of (device address, words) the caller does not need afterwards"""
+        arr = (HwOp * len(ops))(*[HwOp(o, g, r, a or None, b or None) for o, g, r, a, b in ops])
+        rg = (HwRange * max(1, len(dead)))(*[HwRange(p, w) for p, w in dead])
+        self.check(self.lib.acehip_hw_batch_discard(self.h, arr, len(ops), rg, len(dead), None))
 
     def key_switch(self, a, key, level):
         da, dk = self.to_device(a), self.to_device(key)

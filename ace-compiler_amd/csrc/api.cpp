@@ -550,7 +550,8 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
   std::vector<Slot> table;
   std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b, cur, last_pure;
   std::vector<u64> node_ptr;  // address of every node (limb)
-  std::vector<char> written, dead, state;
+  std::vector<char> written, dead, state, need, nostore;
+  std::vector<u32> pos;  // place of every live op in the emission order
   std::vector<u32> kind, readers;  // effective op kind after fusion; reads of every node
 };
 thread_local HwScratch g_hw;
@@ -656,31 +657,65 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg) {
       for (u32 k = args.seg_start[sgm]; k < args.seg_start[sgm + 1]; ++k) {
         const HwBatchOp& o = args.op[k];
         char buf[96];
-        const bool has_b = o.kind == HW_OP_ADD || o.kind == HW_OP_SUB || o.kind == HW_OP_MUL || o.kind == HW_OP_MULADD;
-        if (o.kind == HW_OP_ZERO) snprintf(buf, sizeof buf, " L%d=0", name(o.res));
-        else if (has_b) snprintf(buf, sizeof buf, " L%d=%s(L%d,L%d)q%u", name(o.res), kn[o.kind], name(o.a), name(o.b), o.gi);
-        else snprintf(buf, sizeof buf, " L%d=%s(L%d)q%u", name(o.res), kn[o.kind], name(o.a), o.gi);
+        const u32 kind = o.kind & HW_OP_KIND_MASK;
+        const bool has_b = kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD;
+        if (kind == HW_OP_ZERO) snprintf(buf, sizeof buf, " L%d=0", name(o.res));
+        else if (has_b) snprintf(buf, sizeof buf, " L%d=%s(L%d,L%d)q%u", name(o.res), kn[kind], name(o.a), name(o.b), o.gi);
+        else snprintf(buf, sizeof buf, " L%d=%s(L%d)q%u", name(o.res), kn[kind], name(o.a), o.gi);
         out += buf;
+        if (o.kind & HW_OP_NOSTORE) out += "~";
       }
       out += "\n";
     }
     fputs(out.c_str(), stderr);
+  }
+  // what becomes of executed zero fills: the first later elementwise op that touches the limb (single-threaded runs only)
+  static const bool zero_fate = getenv("ACEHIP_HW_ZERO_FATE") != nullptr;
+  static std::unordered_map<const u64*, int> zeroed;
+  static u64 fate_read[9], fate_over[9], fate_rezero;
+  if (zero_fate) {
+    static const bool reg = [] {
+      atexit([] {
+        static const char* const kn[9] = {"add", "mul", "rot", "copy", "zero", "sub", "muladd", "mulc", "addc"};
+        for (int k = 0; k < 9; ++k)
+          if (fate_read[k] || fate_over[k])
+            fprintf(stderr, "[zero fate] first touched by %-7s: read %llu  overwritten %llu\n", kn[k], (unsigned long long)fate_read[k],
+                    (unsigned long long)fate_over[k]);
+        fprintf(stderr, "[zero fate] zeroed again %llu, never touched by an elementwise op %zu\n", (unsigned long long)fate_rezero, zeroed.size());
+      });
+      return true;
+    }();
+    (void)reg;
+    for (u32 k = 0; k < args.seg_start[n_seg]; ++k) {
+      const HwBatchOp& o = args.op[k];
+      const u32 kind = o.kind & HW_OP_KIND_MASK;
+      const bool has_b = kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD;
+      bool rd = false;
+      if (kind != HW_OP_ZERO && zeroed.erase(o.a)) rd = true;
+      if (has_b && zeroed.erase(o.b)) rd = true;
+      if (kind == HW_OP_MULADD && zeroed.erase(o.res)) rd = true;
+      if (rd) fate_read[kind]++;
+      if (kind == HW_OP_ZERO) {
+        if (!zeroed.emplace(o.res, 1).second) fate_rezero++;
+      } else if (zeroed.erase(o.res)) fate_over[kind]++;
+    }
   }
   for (u32 sgm = 0; sgm < n_seg; ++sgm) {
     const u64* prev = nullptr;
     const u32 beg = args.seg_start[sgm], end = args.seg_start[sgm + 1];
     for (u32 k = beg; k < end; ++k) {
       const HwBatchOp& o = args.op[k];
+      const u32 kind = o.kind & HW_OP_KIND_MASK;
       u64 loads = 0;
-      if (o.kind != HW_OP_ZERO) {
+      if (kind != HW_OP_ZERO) {
         loads += o.a != prev;
-        if (o.kind == HW_OP_ADD || o.kind == HW_OP_SUB || o.kind == HW_OP_MUL || o.kind == HW_OP_MULADD) loads += o.b != prev;
-        if (o.kind == HW_OP_MULADD) loads += o.res != prev;
+        if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) loads += o.b != prev;
+        if (kind == HW_OP_MULADD) loads += o.res != prev;
       }
-      const bool keep = k + 1 < end && args.op[k + 1].res == o.res;
-      g_hw_traffic[o.kind][0] += 1;
-      g_hw_traffic[o.kind][1] += loads;
-      g_hw_traffic[o.kind][2] += !keep;
+      const bool keep = (o.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == o.res);
+      g_hw_traffic[kind][0] += 1;
+      g_hw_traffic[kind][1] += loads;
+      g_hw_traffic[kind][2] += !keep;
       prev = o.res;
     }
   }
@@ -759,15 +794,41 @@ static u64* hw_scratch(acehip_ctx* c, size_t limbs) {
 }
 constexpr size_t kHwScratchMaxLimbs = 2048;
 
+// Memory the caller does not need after the batch (acehip_hw_batch_discard): sorted, disjoint [start, end) byte ranges,
+// minus the limbs a later run of the same batch still reads (`keep`).
+struct HwDead {
+  const std::pair<u64, u64>* range;
+  size_t n_range;
+  const u64* keep;
+  size_t n_keep;
+  bool in_range(u64 ptr, u64 span) const {
+    size_t lo = 0, hi = n_range;
+    while (lo < hi) {  // last range that starts at or below ptr
+      const size_t mid = (lo + hi) / 2;
+      if (range[mid].first <= ptr) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo > 0 && ptr + span <= range[lo - 1].second;
+  }
+  bool limb_is_dead(u64 ptr, u64 span) const {
+    if (!in_range(ptr, span)) return false;
+    for (size_t i = 0; i < n_keep; ++i)
+      if (keep[i] == ptr) return false;
+    return true;
+  }
+};
+
 // Elementwise run ops[0, m).  The list is executed as if one by one, but:
-//  * a zero fill / copy whose limb is completely rewritten later in the list before anything reads it is dropped
-//    (Alloc_poly and Init_ciph_* zero-fill every result that the next Hw_* loop overwrites);
+//  * an op whose result is completely rewritten later in the list before anything reads it is dropped (Alloc_poly and
+//    Init_ciph_* zero-fill every result that the next Hw_* loop overwrites), and so is one whose result lies in memory
+//    the caller has given up (`dead`: temporaries freed while the list was queued) and is read by nothing that follows;
+//  * a result that only the next op of its chain reads, and that nobody needs afterwards, is not stored (HW_OP_NOSTORE);
 //  * a limb that is purely overwritten several times (generated code funnels every limb of a key inner product
 //    through ONE scratch limb: resnet20_cifar10_pre.onnx.inc:7011-7036) gets a private scratch limb for each
 //    version but the last, which removes the false write-after-read / write-after-write dependencies;
 //  * ops are then grouped into chains = connected components over limbs that some op writes, program order
 //    kept inside a chain, and each chain segment runs in one blockIdx.y of hw_batch_ew_kernel.
-void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st) {
+void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st, const HwDead* dead_mem) {
   HwScratch& h = g_hw;
   const u64 span = (u64)c->hp.N * 8;
   size_t cap = 64;
@@ -801,13 +862,16 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
   };
   // backwards: dead stores, and the last pure overwrite of every limb (the version that stays in place)
   h.dead.assign(m, 0);
-  h.state.assign(n_base, 0);  // 1 = overwritten by a later op with no read in between
+  h.state.assign(n_base, 0);  // 1 = overwritten by a later op (or given up by the caller) with no read in between
+  if (dead_mem)
+    for (u32 i = 0; i < n_base; ++i) h.state[i] = dead_mem->limb_is_dead(h.node_ptr[i], span);
+  h.need.assign(h.state.begin(), h.state.end());  // kept for the store analysis below: 1 = not needed after the list
   h.last_pure.assign(n_base, UINT32_MAX);
   size_t live = m;
   bool rename_useful = false;
   for (size_t k = m; k-- > 0;) {
     const u32 op = ops[k].op, nr = h.n_res[k];
-    if ((op == ACEHIP_HW_ZERO || op == ACEHIP_HW_COPY) && h.state[nr]) {
+    if (h.state[nr]) {
       h.dead[k] = 1;
       --live;
       continue;
@@ -924,6 +988,37 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
   for (size_t k = 0; k < m; ++k)
     if (!h.dead[k]) h.ord[h.cnt[h.comp_of_node[uf_find(h.parent, h.n_res[k])]]++] = (u32)k;
   // after the scatter cnt[j] = end offset of chain j
+  // Which results have to reach memory: walking the list backwards, need[x] = the version of limb x that is current here is
+  // loaded by a later op (an operand is taken from registers only when the op right before its reader, in the same
+  // chain and launch, produced it: hw_batch_ew_kernel) or outlives the list.
+  h.pos.resize(m);
+  for (size_t t = 0; t < live; ++t) h.pos[h.ord[t]] = (u32)t;
+  {
+    const size_t nb0 = h.need.size();  // base limbs: needed afterwards unless the caller gave them up; scratch versions: never
+    for (size_t i = 0; i < nb0; ++i) h.need[i] = !h.need[i];
+    h.need.resize(n_nodes, 0);
+  }
+  h.nostore.assign(m, 0);
+  {
+    std::vector<u32>& chain_of = h.cur;  // reused: chain of every emission place
+    chain_of.resize(live);
+    u32 ch = 0;
+    for (size_t t = 0; t < live; ++t) {
+      while (t >= h.cnt[ch]) ++ch;
+      chain_of[t] = ch;
+    }
+    for (size_t k = m; k-- > 0;) {
+      if (h.dead[k]) continue;
+      const u32 kind = h.kind[k], nr = h.n_res[k], t = h.pos[k];
+      h.nostore[k] = !h.need[nr];
+      h.need[nr] = 0;
+      const bool fwd = t > 0 && t % HW_BATCH_MAX != 0 && chain_of[t - 1] == chain_of[t];
+      const u32 prev_res = fwd ? h.n_res[h.ord[t - 1]] : UINT32_MAX;
+      if (hw_has_a(kind) && h.n_a[k] != prev_res) h.need[h.n_a[k]] = 1;
+      if (hw_has_b(kind) && h.n_b[k] != prev_res) h.need[h.n_b[k]] = 1;
+      if (kind == ACEHIP_HW_MULADD && nr != prev_res) h.need[nr] = 1;
+    }
+  }
   HwBatchArgs args;
   u32 n_ops = 0, n_seg = 0, chain = 0, prev_chain = UINT32_MAX;
   args.seg_start[0] = 0;
@@ -942,7 +1037,8 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st)
     const acehip_hw_op& o = ops[k];
     const u32 kind = h.kind[k];
     args.op[n_ops++] = HwBatchOp{(u64*)h.node_ptr[h.n_res[k]], hw_has_a(kind) ? (const u64*)h.node_ptr[h.n_a[k]] : nullptr,
-                                 hw_has_b(kind) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b, kind, o.prime_gi};
+                                 hw_has_b(kind) ? (const u64*)h.node_ptr[h.n_b[k]] : (const u64*)o.b,
+                                 kind | (h.nostore[k] ? HW_OP_NOSTORE : 0u), o.prime_gi};
   }
   args.seg_start[++n_seg] = (uint16_t)n_ops;
   emit_ew(c, args, n_seg, st);
@@ -978,9 +1074,11 @@ void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t
 }
 }  // namespace
 
-static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st) {
+static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st, const acehip_hw_range* dead = nullptr,
+                        size_t n_dead = 0) {
   if (n == 0) return ACEHIP_OK;
   if (!ops) return fail(ACEHIP_EINVAL, "acehip_hw_batch: null op list");
+  if (n_dead && !dead) return fail(ACEHIP_EINVAL, "acehip_hw_batch_discard: null range list");
   const u32 T = c->hp.L + c->hp.K;
   const u64 span = (u64)c->hp.N * 8;
   // limbs moved per op (24N per add/mul, 16N per rotate; copy 16N, zero 8N, muladd 32N, scalar forms 16N)
@@ -999,14 +1097,54 @@ static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStr
     if (o.op == ACEHIP_HW_ROTATE && limbs_overlap(o.res, o.a, span))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: in-place rotation is not supported");
   }
-  size_t i = 0;
-  while (i < n) {
+  // the list runs as alternating rotation / elementwise runs.  Memory the caller gave up is dead for a run only where no
+  // later run reads it: walking the runs backwards, keep[0, run.n_keep) = the given-up limbs that runs after it read
+  static thread_local std::vector<std::pair<u64, u64>> ranges;
+  static thread_local std::vector<u64> keep;
+  struct Run {
+    size_t i, j, n_keep;
+  };
+  static thread_local std::vector<Run> runs;
+  runs.clear();
+  for (size_t i = 0; i < n;) {
     size_t j = i;
     const bool rot = ops[i].op == ACEHIP_HW_ROTATE;
     while (j < n && (ops[j].op == ACEHIP_HW_ROTATE) == rot) ++j;
-    if (rot) hw_run_rotate(c, ops + i, j - i, st);
-    else hw_run_ew(c, ops + i, j - i, st);
+    runs.push_back(Run{i, j, 0});
     i = j;
+  }
+  HwDead dm{nullptr, 0, nullptr, 0};
+  if (n_dead) {
+    ranges.clear();
+    for (size_t r = 0; r < n_dead; ++r)
+      if (dead[r].ptr && dead[r].words) ranges.emplace_back((u64)dead[r].ptr, (u64)dead[r].ptr + (u64)dead[r].words * 8);
+    std::sort(ranges.begin(), ranges.end());
+    for (size_t r = 1; r < ranges.size(); ++r)
+      if (ranges[r].first < ranges[r - 1].second) return fail(ACEHIP_EINVAL, "acehip_hw_batch_discard: overlapping ranges");
+    dm.range = ranges.data();
+    dm.n_range = ranges.size();
+    keep.clear();
+    for (size_t r = runs.size(); r-- > 0;) {
+      runs[r].n_keep = keep.size();
+      if (r == 0) break;
+      for (size_t k = runs[r].i; k < runs[r].j; ++k) {
+        const acehip_hw_op& o = ops[k];
+        if (hw_has_a(o.op) && dm.in_range((u64)o.a, span)) keep.push_back((u64)o.a);
+        if (hw_has_b(o.op) && dm.in_range((u64)o.b, span)) keep.push_back((u64)o.b);
+        if (o.op == ACEHIP_HW_MULADD && dm.in_range((u64)o.res, span)) keep.push_back((u64)o.res);
+      }
+    }
+  }
+  for (const Run& r : runs) {
+    if (ops[r.i].op == ACEHIP_HW_ROTATE) {
+      hw_run_rotate(c, ops + r.i, r.j - r.i, st);
+      continue;
+    }
+    // (a long keep list would make the per-limb lookup slow: such a run is analysed without the caller's hint)
+    const bool hint = dm.n_range && r.n_keep <= 256;
+    dm.keep = keep.data();
+    dm.n_keep = r.n_keep;
+    hw_run_ew(c, ops + r.i, r.j - r.i, st, hint ? &dm : nullptr);
   }
   if (!g_plan) {
     stat(ST_EW, n - n_rot, (alg_words - 2 * n_rot) * span);
@@ -1025,13 +1163,25 @@ int acehip_hw_batch(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_str
   return post_launch();
 }
 
+int acehip_hw_batch_discard(acehip_ctx* c, const acehip_hw_op* ops, size_t n, const acehip_hw_range* dead, size_t n_dead, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  (void)hipSetDevice(c->device);
+  if (int e = hw_batch_run(c, ops, n, (hipStream_t)s, dead, n_dead)) return e;
+  return post_launch();
+}
+
 long acehip_hw_batch_plan(acehip_ctx* c, const acehip_hw_op* ops, size_t n, acehip_hw_op* out_ops, uint32_t* out_launch,
                           uint32_t* out_segment, size_t cap, uint64_t scratch_base) {
+  return acehip_hw_batch_plan_discard(c, ops, n, nullptr, 0, out_ops, out_launch, out_segment, cap, scratch_base);
+}
+
+long acehip_hw_batch_plan_discard(acehip_ctx* c, const acehip_hw_op* ops, size_t n, const acehip_hw_range* dead, size_t n_dead,
+                                  acehip_hw_op* out_ops, uint32_t* out_launch, uint32_t* out_segment, size_t cap, uint64_t scratch_base) {
   if (!c) return fail(ACEHIP_EINVAL, "null context");
   if ((cap && (!out_ops || !out_launch || !out_segment)) || !scratch_base) return fail(ACEHIP_EINVAL, "acehip_hw_batch_plan: bad output arguments");
   HwPlanSink sink{out_ops, out_launch, out_segment, cap, 0, 0, scratch_base};
   g_plan = &sink;
-  const int e = hw_batch_run(c, ops, n, nullptr);
+  const int e = hw_batch_run(c, ops, n, nullptr, dead, n_dead);
   g_plan = nullptr;
   if (e) return e;
   return (long)sink.n;

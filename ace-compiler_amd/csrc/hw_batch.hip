@@ -13,8 +13,9 @@ namespace acehip {
 // Every lane owns ACEHIP_HW_LANES (2 or 4) consecutive coefficients of all limbs of its segment: read-after-write between ops of a chain goes
 // through the lane itself.  The previous result stays in registers: an operand that is the previous op's result
 // limb is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
-// (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run always stores, so
-// every later reader -- in this segment, another launch or the host -- finds the final value in memory).
+// (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run stores, so every
+// later reader -- in this segment, another launch or the host -- finds the final value in memory), nor when the host
+// analysis found that only the next op of the segment reads it (HW_OP_NOSTORE: temporaries of blocks the caller has freed).
 // Measured on ResNet-20 (1 stream s/image | 4 streams images/s): 2 lanes 1.466 | 1.324, 4 lanes 1.460 | 1.316, with the
 // per-prime constants staged in LDS (ACEHIP_HW_STAGE=1) 1.42 | 1.29-1.31: the defaults are the best throughput.
 #ifndef ACEHIP_HW_LANES
@@ -72,26 +73,27 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   V4 vprev{{0, 0}, {0, 0}};
   for (u32 k = beg; k < end; ++k) {
     const HwBatchOp op = args.op[k];
-    const bool keep_in_regs = k + 1 < end && args.op[k + 1].res == op.res;
+    const u32 kind = op.kind & HW_OP_KIND_MASK;
+    const bool keep_in_regs = (op.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == op.res);
     V4 vr;
-    if (op.kind == HW_OP_ZERO) {
+    if (kind == HW_OP_ZERO) {
       vr = V4{{0, 0}, {0, 0}};
     } else {
       const V4 va = op.a == prev_res ? vprev : ld4(op.a + i);
-      if (op.kind == HW_OP_COPY) {
+      if (kind == HW_OP_COPY) {
         vr = va;
       } else {
         const bool staged = ACEHIP_HW_STAGE && op.gi < kMaxPrimes;  // larger prime sets read the rest from memory
         const u64 q = staged ? s_q[op.gi] : c.primes[op.gi].q, mu = staged ? s_mu[op.gi] : c.primes[op.gi].barrett_mu;
         const u32 nb = staged ? s_nb[op.gi] : c.primes[op.gi].nbits;
         V4 vb;
-        if (op.kind == HW_OP_MULC || op.kind == HW_OP_ADDC) {  // the second operand is an immediate
+        if (kind == HW_OP_MULC || kind == HW_OP_ADDC) {  // the second operand is an immediate
           const u64 imm = (u64)(uintptr_t)op.b;
           vb = V4{{imm, imm}, {imm, imm}};
         } else {
           vb = op.b == prev_res ? vprev : ld4(op.b + i);
         }
-        switch (op.kind) {
+        switch (kind) {
           case HW_OP_ADD:
           case HW_OP_ADDC:
             vr = map2(va, vb, [q](u64 x, u64 y) { return add_mod(x, y, q); });

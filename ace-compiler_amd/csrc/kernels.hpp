@@ -226,7 +226,9 @@ struct LimbConsts {
 constexpr u32 HW_BATCH_MAX = 112;
 enum : u32 {
   HW_OP_ADD = 0, HW_OP_MUL = 1, HW_OP_ROTATE = 2, HW_OP_COPY = 3, HW_OP_ZERO = 4,
-  HW_OP_SUB = 5, HW_OP_MULADD = 6, HW_OP_MULC = 7, HW_OP_ADDC = 8
+  HW_OP_SUB = 5, HW_OP_MULADD = 6, HW_OP_MULC = 7, HW_OP_ADDC = 8,
+  // ORed into HwBatchOp::kind: the result is read by the next op of the segment only (or by nobody): it stays in registers
+  HW_OP_NOSTORE = 0x80000000u, HW_OP_KIND_MASK = 0xffu
 };
 struct HwBatchOp {
   u64* res;

@@ -219,7 +219,14 @@ void queue_submit() {
           break;
         }
   }
-  const int rc = acehip_hw_batch(ctx().hip, g_hwq.data(), g_hwq.size(), nullptr);
+  // blocks the program freed while these ops were queued (pool_limbo) are named by nothing but the queue: what the ops
+  // leave in them is never read, which the library uses to skip stores and whole ops (ACEHIP_HW_DISCARD=0: plain list)
+  static const bool discard = getenv("ACEHIP_HW_DISCARD") == nullptr || atoi(getenv("ACEHIP_HW_DISCARD")) != 0;
+  static thread_local std::vector<acehip_hw_range> dead;
+  dead.clear();
+  if (discard)
+    for (const auto& b : pool_limbo) dead.push_back(acehip_hw_range{b.first, b.second});
+  const int rc = acehip_hw_batch_discard(ctx().hip, g_hwq.data(), g_hwq.size(), dead.data(), dead.size(), nullptr);
   g_hwq.clear();
   RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());
   limbo_release();

@@ -148,6 +148,23 @@ int acehip_hw_batch(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, aceh
  * in which case only the first `cap` were written) or a negative error.  tests/test_hw_batch_plan.py replays plans. */
 long acehip_hw_batch_plan(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, acehip_hw_op* out_ops, uint32_t* out_launch,
                           uint32_t* out_segment, size_t cap, uint64_t scratch_base);
+/* acehip_hw_batch for a caller that has given up some of the memory the ops name: the reference's generated code frees its
+ * temporaries (Free_poly_data, e.g. resnet20_cifar10_pre.onnx.inc:1464-1471) right after the loops that use them, so by
+ * the time a queued list is handed over many result limbs belong to freed blocks.  dead[0..n_dead) are disjoint ranges of
+ * device memory (words of 8 bytes) whose contents after the call are UNSPECIFIED: every limb outside them ends up exactly
+ * as after acehip_hw_batch; ops that only feed limbs inside are skipped, and results consumed only by the next op of their
+ * chain are not written to memory.  In a plan such an op carries ACEHIP_HW_NOSTORE in `op`: its result is visible to the
+ * next op of the same segment only. */
+typedef struct acehip_hw_range {
+  const uint64_t* ptr;
+  size_t          words;
+} acehip_hw_range;
+#define ACEHIP_HW_NOSTORE 0x80000000u
+int acehip_hw_batch_discard(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, const acehip_hw_range* dead, size_t n_dead,
+                            acehip_stream stream);
+long acehip_hw_batch_plan_discard(acehip_ctx* ctx, const acehip_hw_op* ops, size_t n_ops, const acehip_hw_range* dead, size_t n_dead,
+                                  acehip_hw_op* out_ops, uint32_t* out_launch, uint32_t* out_segment, size_t cap,
+                                  uint64_t scratch_base);
 
 /* ---- RNS basis operations (NTT-domain in, NTT-domain out) ----
  * Decomp_modup (src/poly/poly_eval.c:28 -> Decompose_modup polynomial.c:1241-1335): digit `digit` of
