@@ -552,6 +552,8 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
   std::vector<u64> node_ptr;  // address of every node (limb)
   std::vector<char> written, dead, state, need, nostore;
   std::vector<u32> pos;  // place of every live op in the emission order
+  std::vector<acehip_hw_op> sops;  // the list with ops on known-zero operands simplified
+  std::vector<char> zero;
   std::vector<u32> kind, readers;  // effective op kind after fusion; reads of every node
 };
 thread_local HwScratch g_hw;
@@ -856,6 +858,56 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
     h.n_b[k] = nb;
   }
   const u32 n_base = (u32)h.parent.size();
+  // forwards: operands that a zero fill of this list has just cleared.  0 + x = x, 0 * x = 0, 0 + a*b = a*b on residues:
+  // the op becomes a copy / fill / plain product, the fill loses its reader and usually dies in the backward pass below
+  // (an accumulator is zero-filled by Init_ciph_* and meets its first addend much later: lazy fills of the runtime)
+  {
+    bool any_zero = false;
+    for (size_t k = 0; k < m && !any_zero; ++k) any_zero = ops[k].op == ACEHIP_HW_ZERO;
+    if (any_zero) {
+      h.sops.assign(ops, ops + m);
+      h.zero.assign(n_base, 0);
+      for (size_t k = 0; k < m; ++k) {
+        acehip_hw_op& o = h.sops[k];
+        const u32 nr = h.n_res[k];
+        const bool za = hw_has_a(o.op) && h.zero[h.n_a[k]], zb = hw_has_b(o.op) && h.zero[h.n_b[k]];
+        auto to_copy_of = [&](const u64* src, u32 node) {  // res = src (left alone when that would be res = res)
+          if (node == nr) return;
+          o.op = ACEHIP_HW_COPY;
+          o.a = src;
+          o.b = nullptr;
+          h.n_a[k] = node;
+        };
+        switch (o.op) {
+          case ACEHIP_HW_COPY:
+            if (za) o.op = ACEHIP_HW_ZERO;
+            break;
+          case ACEHIP_HW_ADD:
+            if (za && zb) o.op = ACEHIP_HW_ZERO;
+            else if (za) to_copy_of((const u64*)o.b, h.n_b[k]);
+            else if (zb) to_copy_of(o.a, h.n_a[k]);
+            break;
+          case ACEHIP_HW_SUB:
+            if (za && zb) o.op = ACEHIP_HW_ZERO;
+            else if (zb) to_copy_of(o.a, h.n_a[k]);
+            break;
+          case ACEHIP_HW_MUL:
+            if (za || zb) o.op = ACEHIP_HW_ZERO;
+            break;
+          case ACEHIP_HW_MULC:
+            if (za) o.op = ACEHIP_HW_ZERO;
+            break;
+          case ACEHIP_HW_MULADD:
+            if (!za && !zb && h.zero[nr]) o.op = ACEHIP_HW_MUL;
+            break;
+          default:
+            break;
+        }
+        h.zero[nr] = o.op == ACEHIP_HW_ZERO;
+      }
+      ops = h.sops.data();
+    }
+  }
   auto pure_overwrite = [&](size_t k) {  // writes its result limb without reading it
     const u32 op = ops[k].op, nr = h.n_res[k];
     return op != ACEHIP_HW_MULADD && !(hw_has_a(op) && h.n_a[k] == nr) && !(hw_has_b(op) && h.n_b[k] == nr);
@@ -945,6 +997,15 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
       if (h.dead[k]) continue;
       const size_t p = prev;
       prev = k;
+      if (p != SIZE_MAX && ops[k].op == ACEHIP_HW_COPY && h.n_a[k] == h.n_res[p] && h.n_res[p] >= n_base && h.readers[h.n_res[p]] == 1 &&
+          h.n_res[k] != h.n_res[p]) {
+        // res = copy of a private version that only this copy reads: the producer writes res itself
+        h.n_res[p] = h.n_res[k];
+        h.dead[k] = 1;
+        --live;
+        prev = p;
+        continue;
+      }
       if (p == SIZE_MAX || ops[k].op != ACEHIP_HW_ADD || ops[p].op != ACEHIP_HW_MUL) continue;
       const u32 t = h.n_res[p], acc = h.n_res[k];
       if (t < n_base || h.readers[t] != 1 || ops[p].prime_gi != ops[k].prime_gi) continue;

@@ -97,10 +97,11 @@ const void* stage_to_device(const void* src, size_t bytes) {
   }
   const int k = r.next;
   r.next = (k + 1) % StageRing::SLOTS;
-  HIPCHK(acehip_event_sync(r.ev[k]));  // the copy that last read this pinned slot has finished
+  // (the staging ring is no polynomial memory: these three touch no limb)
+  HIPCHK_T(acehip_event_sync(r.ev[k]));  // the copy that last read this pinned slot has finished
   memcpy(r.host + (size_t)k * r.slot_bytes, src, bytes);
-  HIPCHK(acehip_memcpy_h2d_async(r.dev + (size_t)k * r.slot_bytes, r.host + (size_t)k * r.slot_bytes, bytes, nullptr));
-  HIPCHK(acehip_event_record(r.ev[k], nullptr));
+  HIPCHK_T(acehip_memcpy_h2d_async(r.dev + (size_t)k * r.slot_bytes, r.host + (size_t)k * r.slot_bytes, bytes, nullptr));
+  HIPCHK_T(acehip_event_record(r.ev[k], nullptr));
   return r.dev + (size_t)k * r.slot_bytes;
 }
 void stage_release() {
@@ -147,8 +148,9 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
     HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
                                  level, p_cnt, nullptr));
   } else {
-    HIPCHK(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level,
-                         p_cnt, nullptr));
+    HIPCHK_T(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level, p_cnt,
+                           nullptr),
+             {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N});  // (d_vals: staging ring / weights)
   }
   poly->_is_ntt = true;
   if (c.profile) c.t_encode += wall_s() - t0;

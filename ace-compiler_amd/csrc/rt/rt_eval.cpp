@@ -153,7 +153,7 @@ void mul(Ct& r, Ct& a, Ct& b) {
   q_ew(ACEHIP_HW_MUL, o1, a0, b1, l, 0, l);
   q_ew(ACEHIP_HW_MULADD, o1, a1, b0, l, 0, l);
   q_ew(ACEHIP_HW_MUL, c2, a1, b1, l, 0, l);
-  HIPCHK(acehip_key_switch(c.hip, k0, k1, c2, c.relin.data, l, nullptr));
+  HIPCHK_T(acehip_key_switch(c.hip, k0, k1, c2, c.relin.data, l, nullptr), {k0, (size_t)l * c.N}, {k1, (size_t)l * c.N}, {c2, (size_t)l * c.N});
   q_ew(ACEHIP_HW_ADD, o0, o0, k0, l, 0, l);
   q_ew(ACEHIP_HW_ADD, o1, o1, k1, l, 0, l);
   dfree(c2);
@@ -169,8 +169,10 @@ void rescale(Ct& r, Ct& a) {
   RT_ASSERT(a.np() == 0, "rescale: extended operand");
   Ct out;
   init(out, l - 1, 0, a.c._scaling_factor / c.sf, a.c._sf_degree - 1, a.c._slots, false);
-  HIPCHK(acehip_rescale2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&a.c._c0_poly),
-                         q_limbs(&a.c._c1_poly), l, nullptr));
+  HIPCHK_T(acehip_rescale2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&a.c._c0_poly), q_limbs(&a.c._c1_poly), l,
+                           nullptr),
+           {q_limbs(&out.c._c0_poly), (size_t)(l - 1) * c.N}, {q_limbs(&out.c._c1_poly), (size_t)(l - 1) * c.N},
+           {q_limbs(&a.c._c0_poly), (size_t)l * c.N}, {q_limbs(&a.c._c1_poly), (size_t)l * c.N});
   r.take(out);
 }
 
@@ -221,7 +223,8 @@ static void switch_and_permute(Ct& r, Ct& a, u32 auto_idx) {
   init(out, l, 0, a.c._scaling_factor, a.c._sf_degree, a.c._slots);
   u64* k0 = dalloc((size_t)l * c.N, false);
   u64* k1 = dalloc((size_t)l * c.N, false);
-  HIPCHK(acehip_key_switch(c.hip, k0, k1, q_limbs(&a.c._c1_poly), key->data, l, nullptr));
+  HIPCHK_T(acehip_key_switch(c.hip, k0, k1, q_limbs(&a.c._c1_poly), key->data, l, nullptr), {k0, (size_t)l * c.N}, {k1, (size_t)l * c.N},
+           {q_limbs(&a.c._c1_poly), (size_t)l * c.N});
   q_ew(ACEHIP_HW_ADD, k0, k0, q_limbs(&a.c._c0_poly), l, 0, l);
   const uint32_t* perm = acehip_auto_order(c.hip, auto_idx);
   RT_ASSERT(perm, "automorphism table: %s", acehip_last_error());
@@ -307,7 +310,8 @@ CIPHER Relin(CIPHER res, CIPHER3 ct3) {
   const u32 l = (u32)ct3->_c0_poly._num_primes;
   u64* k0 = dalloc((size_t)l * c.N, false);
   u64* k1 = dalloc((size_t)l * c.N, false);
-  HIPCHK(acehip_key_switch(c.hip, k0, k1, q_limbs(&ct3->_c2_poly), c.relin.data, l, nullptr));
+  HIPCHK_T(acehip_key_switch(c.hip, k0, k1, q_limbs(&ct3->_c2_poly), c.relin.data, l, nullptr), {k0, (size_t)l * c.N}, {k1, (size_t)l * c.N},
+           {q_limbs(&ct3->_c2_poly), (size_t)l * c.N});
   q_ew(ACEHIP_HW_ADD, q_limbs(&out._c0_poly), k0, q_limbs(&ct3->_c0_poly), l, 0, l);
   q_ew(ACEHIP_HW_ADD, q_limbs(&out._c1_poly), k1, q_limbs(&ct3->_c1_poly), l, 0, l);
   dfree(k0);

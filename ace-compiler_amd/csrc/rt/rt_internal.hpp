@@ -35,10 +35,34 @@
   } while (0)
 // Every device call of the shim goes through HIPCHK, which first hands over the per-limb Hw_* calls
 // that are still queued (rt_poly.cpp hw_queue): the device sees all work in program order.
-namespace rt { void hw_flush(); void hw_flush_site(const char* file, int line); }
+namespace rt {
+void hw_flush();
+void hw_flush_site(const char* file, int line);
+// memory a direct launch reads or writes (words of 8 bytes)
+struct Touch {
+  const void* p;
+  size_t words;
+};
+void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n);
+}  // namespace rt
 #define HIPCHK(expr)                                                                       \
   do {                                                                                     \
     rt::hw_flush_site(__FILE__, __LINE__);                                                                        \
+    int rc_ = (expr);                                                                      \
+    if (rc_ < 0) {                                                                         \
+      fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
+      abort();                                                                             \
+    }                                                                                      \
+  } while (0)
+
+// HIPCHK for a launch whose device operands are ALL listed ({pointer, words}, ...; library-internal workspaces and
+// tables need not be): zero fills of other memory that nothing queued has consumed yet may then stay deferred across
+// the launch (rt_poly.cpp "lazy zero fills") instead of being written out now and read back by their first consumer.
+// Leaving an operand out makes the launch see stale memory -- when in doubt use HIPCHK, which defers nothing.
+#define HIPCHK_T(expr, ...)                                                                  \
+  do {                                                                                     \
+    const rt::Touch touch_[] = {{nullptr, 0}, __VA_ARGS__};                                \
+    rt::hw_flush_touching(__FILE__, __LINE__, touch_, sizeof touch_ / sizeof touch_[0]);   \
     int rc_ = (expr);                                                                      \
     if (rc_ < 0) {                                                                         \
       fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \

@@ -372,7 +372,7 @@ static const float* pt_entry_dev(uint32_t index, size_t len) {
   if (it != g_pt.synth_dev.end()) g_pt.synth_old.push_back(it->second.first);  // another image stream may still read it: freed at Pt_mgr_fini
   float* d = (float*)acehip_malloc(len * sizeof(float));
   RT_ASSERT(d, "weight upload: %s", acehip_last_error());
-  HIPCHK(acehip_memcpy_h2d(d, host, len * sizeof(float), nullptr));
+  HIPCHK_T(acehip_memcpy_h2d(d, host, len * sizeof(float), nullptr));  // a fresh allocation outside the pool
   g_pt.synth_dev[index] = {d, len};
   return d;
 }
@@ -443,7 +443,8 @@ static void pt_ring_fill(rt::Context& c) {
     rt::hw_pending_flush();
     HIPCHK_NOFLUSH(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
   } else {
-    HIPCHK(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
+    // (fresh blocks: no fill of them can be waiting; the weights are not limbs)
+    HIPCHK_T(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
   }
   for (rt::u32 j = 0; j < n; ++j) c.pt_ring.push_back(q[j]);
   c.n_encode_batches++;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <ctime>
+#include <set>
 
 #include "rt_internal.hpp"
 
@@ -100,6 +101,19 @@ struct HwqStats {
   size_t res_limbs = 0, res_limbs_freed = 0;  // distinct result limbs per flush; those whose block was already freed
 };
 thread_local HwqStats g_hwq_stats;
+// ---- lazy zero fills ----
+// Generated code zero-fills a result (Init_ciph_*, Alloc_poly) long before the first per-limb op accumulates into it:
+// a rotation with its key-switch lies in between, whose direct launches hand the queue over.  Issued there, the fill is
+// written to memory and read back by its first consumer (200 k limbs = 100 GB of stores and as much again in loads per
+// ResNet-20 image).  Instead, a fill that nothing queued behind it touches is taken out of the queue when the launch
+// that forces the hand-over declares its operands (HIPCHK_T) and does not touch the limb; the limb waits here and the
+// fill is put back right in front of the first queued op that names it -- where the batch kernel keeps it in registers
+// (hw_batch_ew_kernel) -- or is issued as soon as an undeclared launch (HIPCHK) or one that touches it comes up.
+thread_local std::set<const u64*> g_lazy;
+struct LazyStats {
+  size_t deferred = 0, met_consumer = 0, materialised = 0, dropped = 0;
+};
+thread_local LazyStats g_lazy_stats;
 }
 void hw_stats_print() {
   const HwqStats& s = g_hwq_stats;
@@ -108,6 +122,9 @@ void hw_stats_print() {
          s.flushes, s.ops, s.by_kind[0], s.by_kind[1], s.by_kind[2], s.by_kind[3], s.by_kind[4], s.by_kind[5], s.by_kind[6],
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
   printf("[ACEHIP] hw queue: %zu distinct result limbs, %zu of them in blocks freed before the flush\n", s.res_limbs, s.res_limbs_freed);
+  const LazyStats& z = g_lazy_stats;
+  printf("[ACEHIP] lazy zero fills: %zu limbs deferred; %zu met their first consumer in the queue, %zu issued for a launch, %zu dropped (block freed or rewritten)\n",
+         z.deferred, z.met_consumer, z.materialised, z.dropped);
 }
 // ---- pairing of Mod_down / Rescale calls, speculative ModUp of all digits ----
 // Generated code handles the two polynomials of a ciphertext with two consecutive calls (Mod_down(c0); Mod_down(c1),
@@ -135,7 +152,7 @@ struct ModupCache {
   bool valid = false;
 };
 thread_local ModupCache g_muc;
-void queue_submit();
+void queue_submit(const Touch* touch = nullptr, size_t n_touch = 0, bool defer = false);
 void cancel_fills(const u64* out, size_t n_limbs);
 // The held-back op was called after everything that is queued now (a later hw_queue() would have issued it first): hand
 // the queue over, then launch it.  Its output is rewritten completely, so zero fills still queued for it are dead.
@@ -144,7 +161,10 @@ void pending_flush() {
   const PendingPair p = g_pend;
   g_pend.kind = 0;
   cancel_fills(p.out, p.kind == 1 ? p.level : p.level - 1);
-  queue_submit();
+  const size_t N = ctx().N;
+  const Touch touch[2] = {{p.out, (size_t)(p.kind == 1 ? p.level : p.level - 1) * N},
+                          {p.in, (size_t)(p.kind == 1 ? p.level + ctx().K : p.level) * N}};
+  queue_submit(touch, 2, true);
   const int rc = p.kind == 1 ? acehip_mod_down(ctx().hip, p.out, p.in, p.level, nullptr)
                              : acehip_rescale(ctx().hip, p.out, p.in, p.level, nullptr);
   RT_ASSERT(rc >= 0, "deferred %s failed: %s", p.kind == 1 ? "Mod_down" : "Rescale", acehip_last_error());
@@ -160,7 +180,9 @@ namespace {
 // Generated code initialises a result (Init_ciph_*: zero fill on reuse, polynomial.h:331-348) and then has Mod_down /
 // Rescale / ... rewrite it completely; the fill sits in the queue when the direct kernel is about to be launched.
 // Drops queued ZERO / COPY ops on limbs [out, out + n_limbs) that no later queued op reads.
+void cancel_lazy(const u64* out, size_t n_limbs);
 void cancel_fills(const u64* out, size_t n_limbs) {
+  cancel_lazy(out, n_limbs);
   if (g_hwq.empty() || n_limbs == 0) return;
   const size_t N = ctx().N;
   const u64* end = out + n_limbs * N;
@@ -191,7 +213,148 @@ void cancel_fills(const u64* out, size_t n_limbs) {
     g_hwq.resize(w);
   }
 }
-void queue_submit() {
+// a deferred fill of a limb in [out, out + n_limbs) that no queued op reads is dead as well
+void cancel_lazy(const u64* out, size_t n_limbs) {
+  if (g_lazy.empty() || n_limbs == 0) return;
+  const u64* end = out + n_limbs * ctx().N;
+  for (auto it = g_lazy.lower_bound(out); it != g_lazy.end() && *it < end;) {
+    bool read = false;
+    for (const acehip_hw_op& o : g_hwq) {
+      read |= o.op != ACEHIP_HW_ZERO && o.a == *it;
+      read |= (o.op == ACEHIP_HW_ADD || o.op == ACEHIP_HW_SUB || o.op == ACEHIP_HW_MUL || o.op == ACEHIP_HW_MULADD) && o.b == (const void*)*it;
+      read |= o.op == ACEHIP_HW_MULADD && o.res == *it;
+    }
+    if (read) {
+      ++it;
+    } else {
+      it = g_lazy.erase(it);
+      g_lazy_stats.dropped++;
+    }
+  }
+}
+inline bool touches(const Touch* touch, size_t n_touch, const u64* limb, size_t N) {
+  for (size_t i = 0; i < n_touch; ++i)
+    if (touch[i].p && limb + N > (const u64*)touch[i].p && limb < (const u64*)touch[i].p + touch[i].words) return true;
+  return false;
+}
+inline bool in_limbo(const u64* limb) {
+  for (const auto& b : pool_limbo)
+    if (limb >= b.first && limb < b.first + b.second) return true;
+  return false;
+}
+// small pointer set for one pass over the queue (open addressing, cleared per use)
+struct PtrSet {
+  std::vector<const void*> slot;
+  size_t mask = 0;
+  void reset(size_t n) {
+    size_t cap = 64;
+    while (cap < 2 * n) cap <<= 1;
+    slot.assign(cap, nullptr);
+    mask = cap - 1;
+  }
+  bool insert(const void* p) {  // true: new
+    for (size_t i = ((uintptr_t)p * 0x9E3779B97F4A7C15ull) >> 24;; ++i) {
+      const void*& s = slot[i & mask];
+      if (s == p) return false;
+      if (s == nullptr) {
+        s = p;
+        return true;
+      }
+    }
+  }
+  bool has(const void* p) const {
+    for (size_t i = ((uintptr_t)p * 0x9E3779B97F4A7C15ull) >> 24;; ++i) {
+      const void* s = slot[i & mask];
+      if (s == p) return true;
+      if (s == nullptr) return false;
+    }
+  }
+};
+inline bool op_has_b(u32 op) { return op == ACEHIP_HW_ADD || op == ACEHIP_HW_SUB || op == ACEHIP_HW_MUL || op == ACEHIP_HW_MULADD; }
+// touch: what the direct launch that follows reads or writes; defer = the list is complete (HIPCHK_T)
+void lazy_meet_queue(const Touch* touch, size_t n_touch, bool defer) {
+  const size_t N = ctx().N;
+  // 1. deferred fills go back in front of the first queued op that names their limb
+  if (!g_lazy.empty() && !g_hwq.empty()) {
+    static thread_local std::vector<acehip_hw_op> out;
+    out.clear();
+    bool any = false;
+    size_t k = 0;
+    for (; k < g_hwq.size() && !g_lazy.empty(); ++k) {
+      const acehip_hw_op& o = g_hwq[k];
+      const void* named[3] = {o.res, o.op != ACEHIP_HW_ZERO ? o.a : nullptr, op_has_b(o.op) ? o.b : nullptr};
+      for (const void* p : named) {
+        if (!p) continue;
+        const u64* lo = (const u64*)p - (N - 1);
+        for (auto it = g_lazy.lower_bound(lo); it != g_lazy.end() && *it < (const u64*)p + N;) {
+          // (an op that rewrites exactly this limb without reading it makes the deferred fill redundant; put in front of
+          // a rotation the fill would also cut the list into more runs)
+          const bool rewritten = o.res == *it && o.op != ACEHIP_HW_MULADD && (o.op == ACEHIP_HW_ZERO || o.a != *it) &&
+                                 !(op_has_b(o.op) && o.b == (const void*)*it);
+          if (!rewritten) out.push_back(acehip_hw_op{ACEHIP_HW_ZERO, 0, const_cast<u64*>(*it), nullptr, nullptr});
+          it = g_lazy.erase(it);
+          g_lazy_stats.met_consumer++;
+          any = true;
+        }
+      }
+      out.push_back(o);
+    }
+    if (any) {
+      out.insert(out.end(), g_hwq.begin() + k, g_hwq.end());
+      g_hwq.swap(out);
+    }
+  }
+  // 2. the others: dead with their block, due now (the launch touches them / declares nothing), or kept waiting
+  for (auto it = g_lazy.begin(); it != g_lazy.end();) {
+    if (in_limbo(*it)) {
+      g_lazy_stats.dropped++;
+    } else if (!defer || touches(touch, n_touch, *it, N)) {
+      g_hwq.push_back(acehip_hw_op{ACEHIP_HW_ZERO, 0, const_cast<u64*>(*it), nullptr, nullptr});
+      g_lazy_stats.materialised++;
+    } else {
+      ++it;
+      continue;
+    }
+    it = g_lazy.erase(it);
+  }
+  if (!defer) return;
+  // 3. queued fills that nothing behind them names, and that the launch does not touch, start waiting
+  size_t zeros = 0;
+  for (const acehip_hw_op& o : g_hwq) zeros += o.op == ACEHIP_HW_ZERO;
+  if (zeros == 0) return;
+  static thread_local PtrSet later;
+  later.reset(3 * g_hwq.size());
+  bool any = false;
+  for (size_t k = g_hwq.size(); k-- > 0 && zeros > 0;) {
+    acehip_hw_op& o = g_hwq[k];
+    if (o.op == ACEHIP_HW_ZERO) {
+      --zeros;
+      if (!later.has(o.res) && !touches(touch, n_touch, o.res, N)) {
+        if (in_limbo(o.res)) {
+          g_lazy_stats.dropped++;
+        } else {
+          g_lazy.insert(o.res);
+          g_lazy_stats.deferred++;
+        }
+        o.res = nullptr;  // taken out
+        any = true;
+        continue;
+      }
+    }
+    later.insert(o.res);
+    if (o.op != ACEHIP_HW_ZERO) later.insert(o.a);
+    if (op_has_b(o.op)) later.insert(o.b);
+  }
+  if (any) {
+    size_t w = 0;
+    for (size_t k = 0; k < g_hwq.size(); ++k)
+      if (g_hwq[k].res != nullptr) g_hwq[w++] = g_hwq[k];
+    g_hwq.resize(w);
+  }
+}
+void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
+  static const bool lazy_on = getenv("ACEHIP_LAZY_ZERO") == nullptr || atoi(getenv("ACEHIP_LAZY_ZERO")) != 0;
+  lazy_meet_queue(touch, n_touch, defer && lazy_on);
   if (g_hwq.empty()) {
     limbo_release();
     return;
@@ -237,17 +400,27 @@ void hw_flush() {
   g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
   queue_submit();
 }
+static void note_site(const char* file, int line);
+void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n) {
+  note_site(file, line);
+  pending_flush();
+  g_muc.valid = false;
+  queue_submit(touch, n, true);
+}
 void hw_cancel_fills(const u64* out, size_t n_limbs) { cancel_fills(out, n_limbs); }
 // ACEHIP_PROFILE: which call sites hand over how many queued limb-ops (finds what cuts accumulation chains short)
 namespace {
 thread_local std::map<std::pair<std::string, int>, std::pair<size_t, size_t>> g_flush_sites;
 }
-void hw_flush_site(const char* file, int line) {
+static void note_site(const char* file, int line) {
   if (g_ctx != nullptr && g_ctx->profile && !g_hwq.empty()) {
     auto& e = g_flush_sites[{file, line}];
     e.first++;
     e.second += g_hwq.size();
   }
+}
+void hw_flush_site(const char* file, int line) {
+  note_site(file, line);
   hw_flush();
 }
 void hw_flush_sites_print() {
@@ -336,8 +509,15 @@ void dfree(u64* p) {
   RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
   if (g_muc.valid && g_muc.src >= p && g_muc.src < p + it->second) g_muc.valid = false;
   pool_live_bytes -= it->second * sizeof(u64);
-  if (g_hwq.empty()) pool_free[it->second].push_back(p);
-  else pool_limbo.emplace_back(p, it->second);  // queued ops may still name it
+  if (g_hwq.empty()) {
+    pool_free[it->second].push_back(p);
+    for (auto z = g_lazy.lower_bound(p); z != g_lazy.end() && *z < p + it->second;) {  // fills nobody waits for any more
+      z = g_lazy.erase(z);
+      g_lazy_stats.dropped++;
+    }
+  } else {
+    pool_limbo.emplace_back(p, it->second);  // queued ops may still name it (and deferred fills of it: queue_submit)
+  }
   pool_live.erase(it);
 }
 
@@ -355,6 +535,7 @@ void thread_release() {
 
 void pool_release_all() {
   std::lock_guard<std::mutex> lk(pool_mu);
+  g_lazy.clear();
   g_muc = ModupCache{};
   for (auto& kv : pool_free)
     for (u64* p : kv.second) acehip_free(p);
@@ -584,7 +765,11 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
       g_muc.n_blk = nd;
       g_muc.blk_words = E;
     }
-    HIPCHK(acehip_modup_digits_to(c.hip, g_muc.blk, src, level, nullptr));  // every digit in one go
+    // every digit in one go; operands: the nd cache blocks (rewritten completely) and the source's q-limbs
+    for (u32 d = 0; d < nd; ++d) cancel_fills(g_muc.blk[d], level + c.K);
+    HIPCHK_T(acehip_modup_digits_to(c.hip, g_muc.blk, src, level, nullptr), {src, (size_t)level * c.N}, {g_muc.blk[0], E},
+             {g_muc.blk[1], nd > 1 ? E : 0}, {g_muc.blk[2], nd > 2 ? E : 0}, {g_muc.blk[3], nd > 3 ? E : 0}, {g_muc.blk[4], nd > 4 ? E : 0},
+             {g_muc.blk[5], nd > 5 ? E : 0}, {g_muc.blk[6], nd > 6 ? E : 0}, {g_muc.blk[7], nd > 7 ? E : 0});
     g_muc.src = src;
     g_muc.level = level;
     g_muc.valid = true;
@@ -621,7 +806,8 @@ POLY Mod_down(POLY res, POLY poly) {
     g_pend.kind = 0;
     cancel_fills(p.out, level);
     cancel_fills(out, level);
-    HIPCHK(acehip_mod_down2(c.hip, p.out, out, p.in, in, level, nullptr));
+    HIPCHK_T(acehip_mod_down2(c.hip, p.out, out, p.in, in, level, nullptr), {p.out, (size_t)level * c.N}, {out, (size_t)level * c.N},
+             {p.in, (size_t)(level + c.K) * c.N}, {in, (size_t)(level + c.K) * c.N});
   } else {
     pending_flush();  // an unpaired predecessor; this call is held back (the queue is handed over when it is issued)
     g_muc.valid = false;
@@ -652,7 +838,8 @@ POLY Rescale(POLY res, POLY poly) {
       g_pend.kind = 0;
       cancel_fills(p.out, level - 1);
       cancel_fills(out, level - 1);
-      HIPCHK(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr));
+      HIPCHK_T(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr), {p.out, (size_t)(level - 1) * c.N},
+               {out, (size_t)(level - 1) * c.N}, {p.in, (size_t)level * c.N}, {in, (size_t)level * c.N});
     } else {
       pending_flush();
       g_muc.valid = false;

@@ -154,26 +154,30 @@ def test_random_programs_replay_to_the_sequential_result(rt, seed):
 
 def test_generated_key_inner_product_is_split_into_independent_chains(rt):
     """resnet20_cifar10_pre.onnx.inc:7011-7036: every product goes through ONE scratch limb; after renaming there must be
-    (at least) one chain per limb and component instead of a single serial chain, and the dead zero fills must be gone"""
+    (at least) one chain per limb and component instead of a single serial chain.  Two digits: the first product of every
+    accumulator meets the zero fill (0 + a*b = a*b: written straight into the accumulator, the fill dies), the second
+    becomes a multiply-add; no product reaches memory except the ones the caller can see in its scratch limb"""
     T = rt.L + rt.K
     at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
     tmp = at(9, 0)
     prog = [(B.HW_ZERO, 0, at(4, g), 0, 0) for g in range(T)] + [(B.HW_ZERO, 0, at(5, g), 0, 0) for g in range(T)]
-    for g in range(T):
-        prog += [(B.HW_MUL, g, tmp, at(2, g), at(0, g)), (B.HW_ADD, g, at(4, g), at(4, g), tmp),
-                 (B.HW_MUL, g, tmp, at(3, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
+    for digit in range(2):
+        for g in range(T):
+            prog += [(B.HW_MUL, g, tmp, at(2 + 4 * digit, g), at(0, g)), (B.HW_ADD, g, at(4, g), at(4, g), tmp),
+                     (B.HW_MUL, g, tmp, at(3 + 4 * digit, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
     plan = _check(rt, prog, 10 * T, 5)
+    kinds = [p[0] & 0xFF for p in plan]
     assert len({(la, sg) for *_, la, sg in plan}) >= 2 * T - 1      # independent chains
-    # every product but the first and the last would go to a private limb and is consumed by exactly one add:
-    # those pairs become one multiply-add each and the product never reaches memory
-    assert sum(1 for p in plan if p[2] >= SCRATCH) == 0
-    assert sum(1 for p in plan if p[0] == B.HW_MULADD) == 2 * T - 2
-    assert sum(1 for p in plan if p[0] & 0xFF == B.HW_MUL) == 2 and sum(1 for p in plan if p[0] == B.HW_ADD) == 2
-    # the first product stays in the caller's scratch limb, which a later product overwrites: the add right behind it takes
-    # it from registers and it is not stored; the last one is what the caller finds in the scratch limb afterwards
-    assert sorted(p[0] for p in plan if p[0] & 0xFF == B.HW_MUL) == [B.HW_MUL, B.HW_MUL | B.HW_NOSTORE]
-    # the zero fills are needed here (the accumulators are read), none may be dropped
-    assert sum(1 for p in plan if p[0] & 0xFF == B.HW_ZERO) == 2 * T
+    assert sum(1 for p in plan if p[2] >= SCRATCH) == 0             # no private version is ever written
+    assert B.HW_ZERO not in kinds                                   # every fill met its first addend
+    # digit 0: 2T products, all but the very first (which stays in the caller's scratch limb: product + copy) written into
+    # their accumulator directly; digit 1: 2T multiply-adds but the very last (product in the scratch limb + add)
+    assert kinds.count(B.HW_MUL) == 2 * T + 1 and kinds.count(B.HW_MULADD) == 2 * T - 1
+    assert kinds.count(B.HW_COPY) == 1 and kinds.count(B.HW_ADD) == 1
+    # the first product is overwritten later and read by the op right behind it only: not stored; the last one is what
+    # the caller finds in its scratch limb afterwards
+    in_tmp = [p[0] for p in plan if p[2] == tmp]
+    assert sorted(in_tmp) == [B.HW_MUL, B.HW_MUL | B.HW_NOSTORE]
 
 
 def test_dead_zero_fills_and_copies_are_dropped(rt):
@@ -209,6 +213,26 @@ def test_random_programs_with_given_up_memory(rt, seed):
     plan = _check(rt, prog, n_limbs, seed, dead)
     plain = _plan(rt, prog)
     assert len(plan) <= len(plain)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_zero_heavy_programs(rt, seed):
+    """a quarter of the ops are zero fills, few limbs: ops on just-cleared operands are rewritten (0 + x -> copy, 0 * x -> fill,
+    0 + a*b -> product) and the rewritten list must still replay to the sequential result, with and without given-up limbs"""
+    rng = random.Random(77000 + seed)
+    T = rt.L + rt.K
+    n_limbs = rng.choice([2, 3]) * T
+    prog = []
+    for _ in range(rng.choice([30, 120, 500])):
+        g = rng.randrange(T)
+        r, a, b = (BASE + rng.choice(range(g, n_limbs, T)) * SPAN for _ in range(3))
+        op = rng.choice([B.HW_ADD, B.HW_ADD, B.HW_MUL, B.HW_COPY, B.HW_ZERO, B.HW_ZERO, B.HW_ZERO, B.HW_SUB, B.HW_MULADD,
+                         B.HW_MULADD, B.HW_MULC, B.HW_ADDC])
+        if op in (B.HW_MULC, B.HW_ADDC):
+            b = rng.randrange(rt.primes[g])
+        prog.append((op, g, r, a, b))
+    _check(rt, prog, n_limbs, seed)
+    _check(rt, prog, n_limbs, seed, [(BASE + i * SPAN, N) for i in range(n_limbs) if rng.random() < 0.3])
 
 
 def dead_ends_at(dead, addr):
