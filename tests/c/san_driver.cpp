@@ -45,6 +45,14 @@ static void plan_random(acehip_ctx* c, uint32_t N, uint32_t limbs, unsigned seed
     std::vector<uint32_t> launch(cap), seg(cap);
     const long n = acehip_hw_batch_plan(c, prog.data(), n_ops, out.data(), launch.data(), seg.data(), cap, 0x7F0000000000ull);
     CHECK(n >= 0 && (size_t)n <= cap);
+    // the same list with some of its limbs given up (acehip_hw_batch_discard): never more ops than without the hint
+    std::vector<acehip_hw_range> dead;
+    for (uint64_t l = 0; l < 24; l += 1 + rng() % 4) dead.push_back(acehip_hw_range{(const uint64_t*)(base + l * span), (size_t)N * (1 + rng() % 2)});
+    for (size_t i = 1; i < dead.size(); ++i)
+      if (dead[i - 1].ptr + dead[i - 1].words > dead[i].ptr) dead[i - 1].words = N;  // keep them disjoint
+    const long nd = acehip_hw_batch_plan_discard(c, prog.data(), n_ops, dead.data(), dead.size(), out.data(), launch.data(), seg.data(), cap,
+                                                 0x7F0000000000ull);
+    CHECK(nd >= 0 && nd <= n);
   }
 }
 
