@@ -48,6 +48,30 @@ def test_own_program_config_c1(tmp_path):
     assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_deferred_zero_fills_are_never_seen_late(tmp_path):
+    """tests/c/lazy_fills.c: accumulators filled before a key-switch, a zero ciphertext as the input of a key-switch, a
+    zero-filled ciphertext freed while its fill waits (block reuse), per-limb adds on a zero-filled polynomial -- correct
+    against the clear computation, and bit-identical slot by slot with the deferral switched off (same ACEHIP_SEED)."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "lazy_fills")
+    inc = os.path.join(ROOT, "include")
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c", "lazy_fills.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe]
+    subprocess.check_call(cmd)
+    outs = {}
+    for lazy, discard in (("1", "1"), ("0", "1"), ("0", "0")):
+        env = dict(os.environ, ACEHIP_SEED="12345", ACEHIP_LAZY_ZERO=lazy, ACEHIP_HW_DISCARD=discard)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[(lazy, discard)] = [ln for ln in r.stdout.splitlines() if ln.startswith("slot ")]
+        assert len(outs[(lazy, discard)]) == 61
+    assert outs[("1", "1")] == outs[("0", "1")] == outs[("0", "0")]
+
+
 def test_resnet20_logits_match_reference_cpu_run(tmp_path):
     """BASELINE configs[3] end to end: the UNCHANGED ACE-generated ResNet-20 source (resnet20_cifar10_pre.onnx.inc,
     linked against our library by `make -C workloads models`) on the synthetic weight file of tools/make_weight_file.py
