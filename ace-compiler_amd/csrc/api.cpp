@@ -1196,6 +1196,35 @@ static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStr
       }
     }
   }
+  if (hw_traffic_on() && getenv("ACEHIP_HW_ROT_FATE")) {  // diagnostic: who reads the result of a queued rotation
+    static std::atomic<u64> cnt[6];  // rotations; result given up; readers in this list: 0, 1, 2+; source rewritten later in the list
+    static const bool reg = [] {
+      atexit([] {
+        fprintf(stderr, "[rot fate] rotations %llu, result in given-up memory %llu; read in the same list by 0 / 1 / 2+ ops: %llu / %llu / %llu; source written later in the list %llu\n",
+                (unsigned long long)cnt[0], (unsigned long long)cnt[1], (unsigned long long)cnt[2], (unsigned long long)cnt[3],
+                (unsigned long long)cnt[4], (unsigned long long)cnt[5]);
+      });
+      return true;
+    }();
+    (void)reg;
+    for (size_t k = 0; k < n; ++k) {
+      if (ops[k].op != ACEHIP_HW_ROTATE) continue;
+      cnt[0]++;
+      cnt[1] += dm.n_range && dm.in_range((u64)ops[k].res, span);
+      u32 readers = 0;
+      bool src_written = false;
+      for (size_t j = k + 1; j < n; ++j) {
+        const acehip_hw_op& o = ops[j];
+        readers += hw_has_a(o.op) && o.a == ops[k].res;
+        readers += hw_has_b(o.op) && o.b == (const void*)ops[k].res;
+        readers += o.op == ACEHIP_HW_MULADD && o.res == ops[k].res;
+        src_written |= o.res == ops[k].a;
+        if (o.res == ops[k].res && o.op != ACEHIP_HW_MULADD) break;
+      }
+      cnt[2 + std::min(readers, 2u)]++;
+      cnt[5] += src_written;
+    }
+  }
   for (const Run& r : runs) {
     if (ops[r.i].op == ACEHIP_HW_ROTATE) {
       hw_run_rotate(c, ops + r.i, r.j - r.i, st);
