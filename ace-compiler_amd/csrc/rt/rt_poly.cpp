@@ -115,6 +115,7 @@ struct LazyStats {
 };
 thread_local LazyStats g_lazy_stats;
 }
+static void muc_stats_print();
 void hw_stats_print() {
   const HwqStats& s = g_hwq_stats;
   printf("[ACEHIP] hw queue: %zu flushes, %zu limb-ops (add %zu mul %zu rot %zu copy %zu zero %zu sub %zu muladd %zu mulc %zu addc %zu); "
@@ -122,6 +123,7 @@ void hw_stats_print() {
          s.flushes, s.ops, s.by_kind[0], s.by_kind[1], s.by_kind[2], s.by_kind[3], s.by_kind[4], s.by_kind[5], s.by_kind[6],
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
   printf("[ACEHIP] hw queue: %zu distinct result limbs, %zu of them in blocks freed before the flush\n", s.res_limbs, s.res_limbs_freed);
+  muc_stats_print();
   const LazyStats& z = g_lazy_stats;
   printf("[ACEHIP] lazy zero fills: %zu limbs deferred; %zu met their first consumer in the queue, %zu issued for a launch, %zu dropped (block freed or rewritten)\n",
          z.deferred, z.met_consumer, z.materialised, z.dropped);
@@ -142,16 +144,50 @@ struct PendingPair {
 thread_local PendingPair g_pend;
 struct ModupCache {
   const u64* src = nullptr;  // q-limbs of the polynomial the digits were raised from
-  u32 level = 0, next_part = 0;
+  u32 level = 0;
   // one pool block of (level+K)*N words per digit: a digit is handed to the caller's polynomial by SWAPPING blocks (the
   // caller's old block becomes the cache's), so Decomp_modup moves no data (it used to copy level+K limbs per digit:
-  // 176 k limb copies = 6 % of the memory traffic of a ResNet-20 image)
+  // 176 k limb copies = 6 % of the memory traffic of a ResNet-20 image).
+  // The digits outlive the rotation they were raised for: generated code rotates the same ciphertext by several steps in
+  // a row (the taps of a convolution), each Rotate() raising the digits of the same c1 again -- 19 % of the all-digit
+  // ModUps of a ResNet-20 image.  `ok` says that the blocks still hold the digits of (src, level) as it is NOW: every write
+  // the runtime can make to the source or to a digit block clears it -- queued per-limb ops (hw_queue), freed blocks
+  // (dfree), the operands of declared launches (HIPCHK_T; all taken as written) and any undeclared launch (HIPCHK).
+  // holds[s] = the digit block s contains (-1: nothing of value); `lent` = the block handed out last, which comes back
+  // untouched either with the next Decomp_modup into the same polynomial or when the caller frees it (dfree adopts it
+  // and releases a valueless block instead).
   u64* blk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int holds[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   u32 n_blk = 0;
   size_t blk_words = 0;
-  bool valid = false;
+  bool ok = false;
+  u64* lent = nullptr;
+  int lent_digit = -1;
+  size_t n_raise = 0, n_reuse = 0;  // all-digit ModUps launched / Rotate()s served from digits raised earlier
+  void forget() {
+    ok = false;
+    lent = nullptr;
+    for (int& h : holds) h = -1;
+  }
+  // [p, p + words) may have been written
+  void written(const u64* p, size_t words) {
+    if (!ok || p == nullptr || words == 0) return;
+    const u64* e = p + words;
+    if (e > src && p < src + (size_t)level * g_ctx->N) {
+      forget();
+      return;
+    }
+    if (lent && e > lent && p < lent + blk_words) lent = nullptr;
+    for (u32 s = 0; s < n_blk; ++s)
+      if (holds[s] >= 0 && e > blk[s] && p < blk[s] + blk_words) holds[s] = -1;
+  }
 };
 thread_local ModupCache g_muc;
+}  // namespace
+static void muc_stats_print() {
+  printf("[ACEHIP] all-digit ModUp: %zu launched, %zu more rotations served from digits raised before\n", g_muc.n_raise, g_muc.n_reuse);
+}
+namespace {
 void queue_submit(const Touch* touch = nullptr, size_t n_touch = 0, bool defer = false);
 void cancel_fills(const u64* out, size_t n_limbs);
 // The held-back op was called after everything that is queued now (a later hw_queue() would have issued it first): hand
@@ -162,6 +198,7 @@ void pending_flush() {
   g_pend.kind = 0;
   cancel_fills(p.out, p.kind == 1 ? p.level : p.level - 1);
   const size_t N = ctx().N;
+  g_muc.written(p.out, (size_t)(p.kind == 1 ? p.level : p.level - 1) * N);
   const Touch touch[2] = {{p.out, (size_t)(p.kind == 1 ? p.level : p.level - 1) * N},
                           {p.in, (size_t)(p.kind == 1 ? p.level + ctx().K : p.level) * N}};
   queue_submit(touch, 2, true);
@@ -396,15 +433,15 @@ void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
 }
 }  // namespace
 void hw_flush() {
-  pending_flush();      // it was called before everything queued since (there is nothing: see hw_queue) and after the rest
-  g_muc.valid = false;  // some other device work follows: the speculated digits may go stale
+  pending_flush();  // it was called before everything queued since (there is nothing: see hw_queue) and after the rest
+  g_muc.forget();   // some other device work follows, operands unknown: the raised digits may go stale
   queue_submit();
 }
 static void note_site(const char* file, int line);
 void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n) {
   note_site(file, line);
   pending_flush();
-  g_muc.valid = false;
+  for (size_t i = 0; i < n; ++i) g_muc.written((const u64*)touch[i].p, touch[i].words);  // (any operand may be an output)
   queue_submit(touch, n, true);
 }
 void hw_cancel_fills(const u64* out, size_t n_limbs) { cancel_fills(out, n_limbs); }
@@ -435,7 +472,7 @@ void hw_pending_flush() { pending_flush(); }
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs) {
   const size_t N = ctx().N;
   pending_flush();
-  if (g_muc.valid && res + n_limbs * N > g_muc.src && res < g_muc.src + (size_t)g_muc.level * N) g_muc.valid = false;
+  g_muc.written(res, n_limbs * N);
   for (size_t l = 0; l < n_limbs; ++l)
     g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
                                  b ? (const void*)((const u64*)b + l * N) : nullptr});
@@ -503,11 +540,21 @@ static size_t pool_block_words(u64* p) {
 
 void dfree(u64* p) {
   if (!p) return;
+  if (p == g_muc.lent) {  // the caller is done with the digit it was handed last: keep it, release a valueless block instead
+    g_muc.lent = nullptr;
+    if (g_muc.ok)
+      for (u32 s = 0; s < g_muc.n_blk; ++s)
+        if (g_muc.holds[s] < 0) {
+          std::swap(p, g_muc.blk[s]);
+          g_muc.holds[s] = g_muc.lent_digit;
+          break;
+        }
+  }
   std::lock_guard<std::mutex> lk(pool_mu);
   auto it = pool_live.find(p);
   if (it == pool_live.end() && shared_free(p)) return;
   RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
-  if (g_muc.valid && g_muc.src >= p && g_muc.src < p + it->second) g_muc.valid = false;
+  if (g_muc.ok && g_muc.src >= p && g_muc.src < p + it->second) g_muc.forget();
   pool_live_bytes -= it->second * sizeof(u64);
   if (g_hwq.empty()) {
     pool_free[it->second].push_back(p);
@@ -751,44 +798,60 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
   RT_ASSERT(q_part_idx < nd, "Decomp_modup: part index out of range");
   const size_t E = (size_t)(level + c.K) * c.N;
   const u64* src = q_limbs(poly);
-  const bool hit = q_part_idx > 0 && g_muc.valid && g_muc.src == src && g_muc.level == level && g_muc.next_part == q_part_idx;
-  if (!hit) {
+  ModupCache& m = g_muc;
+  auto slot_of = [&](int digit) {
+    for (u32 s = 0; s < m.n_blk; ++s)
+      if (m.holds[s] == digit) return (int)s;
+    return -1;
+  };
+  // ACEHIP_MODUP_REUSE=0: raise the digits again for every Rotate() (digit 0 always misses), as the reference does
+  static const bool reuse = getenv("ACEHIP_MODUP_REUSE") == nullptr || atoi(getenv("ACEHIP_MODUP_REUSE")) != 0;
+  int slot = m.ok && m.src == src && m.level == level && m.blk_words == E && (reuse || q_part_idx != 0) ? slot_of((int)q_part_idx) : -1;
+  if (slot < 0) {
     if (q_part_idx != 0 || nd > 8) {  // a digit asked for out of sequence
       HIPCHK(acehip_decomp_modup(c.hip, q_limbs(res), src, level, q_part_idx, nullptr));
       res->_is_ntt = true;
       return res;
     }
-    if (g_muc.blk_words != E || g_muc.n_blk != nd) {
-      for (u32 d = 0; d < g_muc.n_blk; ++d)
-        if (g_muc.blk[d]) dfree(g_muc.blk[d]);
-      for (u32 d = 0; d < 8; ++d) g_muc.blk[d] = d < nd ? dalloc(E, false) : nullptr;
-      g_muc.n_blk = nd;
-      g_muc.blk_words = E;
+    m.forget();
+    if (m.blk_words != E || m.n_blk != nd) {
+      for (u32 d = 0; d < m.n_blk; ++d)
+        if (m.blk[d]) dfree(m.blk[d]);
+      for (u32 d = 0; d < 8; ++d) m.blk[d] = d < nd ? dalloc(E, false) : nullptr;
+      m.n_blk = nd;
+      m.blk_words = E;
     }
     // every digit in one go; operands: the nd cache blocks (rewritten completely) and the source's q-limbs
-    for (u32 d = 0; d < nd; ++d) cancel_fills(g_muc.blk[d], level + c.K);
-    HIPCHK_T(acehip_modup_digits_to(c.hip, g_muc.blk, src, level, nullptr), {src, (size_t)level * c.N}, {g_muc.blk[0], E},
-             {g_muc.blk[1], nd > 1 ? E : 0}, {g_muc.blk[2], nd > 2 ? E : 0}, {g_muc.blk[3], nd > 3 ? E : 0}, {g_muc.blk[4], nd > 4 ? E : 0},
-             {g_muc.blk[5], nd > 5 ? E : 0}, {g_muc.blk[6], nd > 6 ? E : 0}, {g_muc.blk[7], nd > 7 ? E : 0});
-    g_muc.src = src;
-    g_muc.level = level;
-    g_muc.valid = true;
+    for (u32 d = 0; d < nd; ++d) cancel_fills(m.blk[d], level + c.K);
+    HIPCHK_T(acehip_modup_digits_to(c.hip, m.blk, src, level, nullptr), {src, (size_t)level * c.N}, {m.blk[0], E},
+             {m.blk[1], nd > 1 ? E : 0}, {m.blk[2], nd > 2 ? E : 0}, {m.blk[3], nd > 3 ? E : 0}, {m.blk[4], nd > 4 ? E : 0},
+             {m.blk[5], nd > 5 ? E : 0}, {m.blk[6], nd > 6 ? E : 0}, {m.blk[7], nd > 7 ? E : 0});
+    m.src = src;
+    m.level = level;
+    m.ok = true;
+    m.lent = nullptr;
+    for (u32 d = 0; d < 8; ++d) m.holds[d] = d < nd ? (int)d : -1;
+    m.n_raise++;
+    slot = 0;
+  } else if (q_part_idx == 0) {
+    m.n_reuse++;
   }
-  g_muc.next_part = q_part_idx + 1;
   // hand the digit over by exchanging blocks: res keeps its size (asserted above: level + K limbs), the cache gets res's
   // old block, which queued ops may still read -- it is rewritten only by the next all-digit ModUp, a direct launch that
-  // hands the queue over first.  Fills still queued for the old block are dead unless a queued op reads them.
+  // hands the queue over first.  Fills still queued for the old block are dead unless a queued op reads them.  If the old
+  // block is the digit handed out last, untouched, it goes back into the cache as that digit.
   u64* old = (u64*)res->_data;
   if (pool_block_words(old) == E) {
-    const bool keep = g_muc.valid;
-    cancel_fills(old, level + c.K);
-    res->_data = (int64_t*)g_muc.blk[q_part_idx];
-    g_muc.blk[q_part_idx] = old;
-    g_muc.valid = keep;
+    const bool comes_back = old == m.lent;
+    const int back_digit = m.lent_digit;
+    if (!comes_back) cancel_fills(old, level + c.K);
+    res->_data = (int64_t*)m.blk[slot];
+    m.blk[slot] = old;
+    m.holds[slot] = comes_back ? back_digit : -1;
+    m.lent = (u64*)res->_data;
+    m.lent_digit = (int)q_part_idx;
   } else {  // res is not a pool block of its own (a view, foreign memory): copy
-    const bool keep = g_muc.valid;
-    copy_limbs(q_limbs(res), g_muc.blk[q_part_idx], E);
-    g_muc.valid = keep;
+    copy_limbs(q_limbs(res), m.blk[slot], E);  // (queued: counts as a write of res, which is neither the source nor a digit)
   }
   res->_is_ntt = true;
   return res;
@@ -810,7 +873,7 @@ POLY Mod_down(POLY res, POLY poly) {
              {p.in, (size_t)(level + c.K) * c.N}, {in, (size_t)(level + c.K) * c.N});
   } else {
     pending_flush();  // an unpaired predecessor; this call is held back (the queue is handed over when it is issued)
-    g_muc.valid = false;
+    g_muc.written(out, (size_t)level * c.N);
     g_pend.kind = 1;
     g_pend.out = out;
     g_pend.in = in;
@@ -842,7 +905,7 @@ POLY Rescale(POLY res, POLY poly) {
                {out, (size_t)(level - 1) * c.N}, {p.in, (size_t)level * c.N}, {in, (size_t)level * c.N});
     } else {
       pending_flush();
-      g_muc.valid = false;
+      g_muc.written(out, (size_t)(level - 1) * c.N);
       g_pend.kind = 2;
       g_pend.out = out;
       g_pend.in = in;

@@ -72,6 +72,36 @@ def test_deferred_zero_fills_are_never_seen_late(tmp_path):
     assert outs[("1", "1")] == outs[("0", "1")] == outs[("0", "0")]
 
 
+def test_raised_digits_are_never_reused_stale(tmp_path):
+    """tests/c/modup_reuse.c: rotations spelled at the polynomial level like the generated Rotate(); the same ciphertext
+    rotated three times (digits raised once), then changed in place by queued ops, rewritten at the same address by direct
+    launches, freed and its memory reused -- correct against the clear computation and bit-identical, slot by slot, with
+    ACEHIP_MODUP_REUSE=0 (digits raised for every rotation, as the reference does)."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "modup_reuse")
+    inc = os.path.join(ROOT, "include")
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c", "modup_reuse.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe]
+    subprocess.check_call(cmd)
+    outs, raised = {}, {}
+    for reuse in ("1", "0"):
+        env = dict(os.environ, ACEHIP_SEED="4711", ACEHIP_MODUP_REUSE=reuse, ACEHIP_PROFILE="1")
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[reuse] = [ln for ln in r.stdout.splitlines() if ln.startswith("slot ")]
+        assert len(outs[reuse]) == 61
+        stat = [ln for ln in r.stdout.splitlines() if "all-digit ModUp" in ln]
+        assert stat, r.stdout[-1500:]
+        raised[reuse] = [int(t) for t in stat[0].replace(",", " ").split() if t.isdigit()]
+    assert outs["1"] == outs["0"]
+    # 7 rotations: with reuse only the second and third tap of case 1 are served from digits raised before
+    assert raised["0"] == [7, 0] and raised["1"] == [5, 2], raised
+
+
 def test_resnet20_logits_match_reference_cpu_run(tmp_path):
     """BASELINE configs[3] end to end: the UNCHANGED ACE-generated ResNet-20 source (resnet20_cifar10_pre.onnx.inc,
     linked against our library by `make -C workloads models`) on the synthetic weight file of tools/make_weight_file.py
