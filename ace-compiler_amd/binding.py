@@ -84,6 +84,7 @@ SYMBOLS = [
     ("acehip_modup_digits", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_modup_digits_to", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_inner_product", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_key_inner_product_add", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_bsgs_inner", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),

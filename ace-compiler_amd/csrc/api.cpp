@@ -1955,6 +1955,23 @@ int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, cons
   return post_launch();
 }
 
+int acehip_key_inner_product_add(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, const uint64_t* key, const uint64_t* ext, uint32_t level,
+                                 const uint64_t* add0, const uint64_t* h_scalars, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_inner_product_add: bad level");
+  if (!add0 || !h_scalars) return fail(ACEHIP_EINVAL, "acehip_key_inner_product_add: null addend");
+  if (level > 64) return fail(ACEHIP_EINVAL, "acehip_key_inner_product_add: at most 64 q-limbs");
+  LimbConsts w{};
+  for (u32 i = 0; i < level; ++i) {
+    if (h_scalars[i] >= c->hp.primes[i].q) return fail(ACEHIP_EINVAL, "acehip_key_inner_product_add: scalar is not a residue of its prime");
+    w.w[i] = h_scalars[i];
+  }
+  const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
+  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s, add0, &w);
+  stat(ST_KEYMAC, 1, 8ull * E * (3ull * c->hp.num_decomp(level) + 2) + 8ull * level * c->hp.N);
+  return post_launch();
+}
+
 // Rotate_iteration's inner loop (ckks_bootstrap_context.c:1326-1341): out_i = sum_j rot_j (*) pt_{i,j} in the PQ basis
 int acehip_bsgs_inner(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out1, const uint64_t* const* in0, const uint64_t* const* in1,
                       const uint64_t* const* pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs, uint32_t level, acehip_stream s) {

@@ -169,8 +169,11 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
                             const PtrTab8& outz = PtrTab8{});
 // fused key inner product over all digits (generated code inc:7011-7036 for every part):
 //   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
+struct LimbConsts;
+// add0 / w (may be null): acc0[pos] += add0[pos] * w->w[pos] on the q-limbs
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
-                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s);
+                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0 = nullptr,
+                          const LimbConsts* w = nullptr);
 // BSGS inner products (keyswitch.hip bsgs_inner_kernel): kernel-argument block, g <= 16, b <= 16, g*b <= 128
 constexpr u32 BSGS_MAX_G = 16, BSGS_MAX_B = 16, BSGS_MAX_PT = 128;
 struct BsgsArgs {

@@ -153,10 +153,11 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
 }
 
 // acc{0,1}[pos][n] = sum_d key{0,1}[d][gi][n] * e_d[pos][n];  key layout [nd][2][L+K][N]
+// add0 (may be null): acc0[pos] += add0[pos] * w.w[pos] on the q-limbs -- the "+ P*c0" of Fast_rotate_ext (ckks_evaluator.c:539-575)
 __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __restrict__ acc0, u64* __restrict__ acc1,
                                                             const u64* __restrict__ key, const u64* __restrict__ ext,
                                                             size_t ext_stride, const u64* __restrict__ in, u32 level,
-                                                            u32 nd, u32 alpha) {
+                                                            u32 nd, u32 alpha, const u64* __restrict__ add0, LimbConsts w) {
   const u32 pos = blockIdx.y;
   const u32 gi = limb_prime(pos, level, c.L);
   const DevPrime P = c.primes[gi];
@@ -178,15 +179,22 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __res
     r1.x = add_mod(r1.x, mul_mod(k1.x, e.x, P), P.q);
     r1.y = add_mod(r1.y, mul_mod(k1.y, e.y, P), P.q);
   }
+  if (add0 != nullptr && pos < level) {  // uniform for the workgroup
+    const ulong2 a = *reinterpret_cast<const ulong2*>(add0 + pb + i);
+    const u64 wl = w.w[pos];
+    r0.x = add_mod(r0.x, mul_mod(a.x, wl, P), P.q);
+    r0.y = add_mod(r0.y, mul_mod(a.y, wl, P), P.q);
+  }
   *reinterpret_cast<ulong2*>(acc0 + pb + i) = r0;
   *reinterpret_cast<ulong2*>(acc1 + pb + i) = r1;
 }
 
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
-                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s) {
+                          const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0, const LimbConsts* w) {
   ACEHIP_ABLATE(ABL_KEYMAC);
   dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
-  hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha);
+  hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0,
+                     w ? *w : LimbConsts{});
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -444,13 +444,11 @@ void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool 
   Ct tmp;
   ev::init(tmp, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots, false);  // the inner product writes every limb
   u64 *t0 = q_limbs(&tmp.c._c0_poly), *t1 = q_limbs(&tmp.c._c1_poly);
-  HIPCHK(acehip_key_inner_product(c.hip, t0, t1, key->data, digits, l, nullptr));
-  if (add_first) {
+  if (add_first) {  // + P*c0 on the q-limbs, in the pass that forms the inner product
     std::vector<u64> pm = p_mod_q(l);
-    u64* psi = dalloc((size_t)l * c.N, false);
-    q_scalars(ACEHIP_HW_MULC, psi, q_limbs(&in.c._c0_poly), pm.data(), l, 0, l);
-    q_ew(ACEHIP_HW_ADD, t0, t0, psi, l, 0, l);
-    dfree(psi);
+    HIPCHK(acehip_key_inner_product_add(c.hip, t0, t1, key->data, digits, l, q_limbs(&in.c._c0_poly), pm.data(), nullptr));
+  } else {
+    HIPCHK(acehip_key_inner_product(c.hip, t0, t1, key->data, digits, l, nullptr));
   }
   ev::init(rot, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots, false);  // the automorphism writes every limb
   const uint32_t* perm = acehip_auto_order(c.hip, k);

@@ -258,6 +258,11 @@ int acehip_modup_digits(acehip_ctx* ctx, uint64_t* d_ext, const uint64_t* d_in, 
  * (level + K) limbs.  (The rt_ant shim swaps these blocks into the caller's polynomials instead of copying.) */
 int acehip_modup_digits_to(acehip_ctx* ctx, uint64_t* const* h_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext, uint32_t level, acehip_stream stream);
+/* Fast_rotate_ext (ckks_evaluator.c:539-575) adds P * c0 to the first accumulator before the automorphism: the same inner
+ * product with d_acc0[i] += d_add0[i] * h_scalars[i] mod q_i on the q-limbs i < level (h_scalars: host array of `level`
+ * residues, P mod q_i there), in the same pass. */
+int acehip_key_inner_product_add(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext,
+                                 uint32_t level, const uint64_t* d_add0, const uint64_t* h_scalars, acehip_stream stream);
 /* Baby-step giant-step inner products of Rotate_iteration (ckks_bootstrap_context.c:1326-1341: Mul_plaintext +
  * Add_ciphertext over one giant step, for every baby step): d_out{0,1}[i] = sum_{j<g} d_in{0,1}[j] (*) pt[i*g + j],
  * i < b, over the level+K limbs of PQ-extended ciphertexts, in ONE pass over the plaintext diagonals.  pt entries are
