@@ -88,6 +88,7 @@ SYMBOLS = [
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_bsgs_inner", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    ("acehip_bsgs_inner_rot", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     ("acehip_shard_create", _vp, [_vp, _u32, _u32]),
     ("acehip_shard_destroy", None, [_vp]),
     ("acehip_shard_num_q", _u32, [_vp, _u32]),

@@ -1975,6 +1975,12 @@ int acehip_key_inner_product_add(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, 
 // Rotate_iteration's inner loop (ckks_bootstrap_context.c:1326-1341): out_i = sum_j rot_j (*) pt_{i,j} in the PQ basis
 int acehip_bsgs_inner(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out1, const uint64_t* const* in0, const uint64_t* const* in1,
                       const uint64_t* const* pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs, uint32_t level, acehip_stream s) {
+  return acehip_bsgs_inner_rot(c, out0, out1, in0, in1, nullptr, pt, g, b, pt_q_limbs, level, s);
+}
+
+int acehip_bsgs_inner_rot(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out1, const uint64_t* const* in0, const uint64_t* const* in1,
+                          const uint32_t* in_auto, const uint64_t* const* pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs, uint32_t level,
+                          acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L || pt_q_limbs < level || pt_q_limbs > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: bad level");
   if (g == 0 || b == 0 || g > BSGS_MAX_G || b > BSGS_MAX_B || g * b > BSGS_MAX_PT) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: g, b out of range");
@@ -1984,6 +1990,12 @@ int acehip_bsgs_inner(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out
     if (!in0[j] || !in1[j]) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: null input");
     a.in0[j] = in0[j];
     a.in1[j] = in1[j];
+    a.in_auto[j] = in_auto ? in_auto[j] : 0;
+    if (a.in_auto[j] != 0 && (a.in_auto[j] % 2 == 0 || a.in_auto[j] >= 2 * c->hp.N))
+      return fail(ACEHIP_EINVAL, "acehip_bsgs_inner_rot: automorphism index must be odd and below 2N");
+    for (u32 i = 0; i < b && a.in_auto[j] != 0; ++i)  // a gathered input is read at other lanes' positions: it cannot be an output
+      if (out0[i] == in0[j] || out0[i] == in1[j] || out1[i] == in0[j] || out1[i] == in1[j])
+        return fail(ACEHIP_EINVAL, "acehip_bsgs_inner_rot: a rotated input aliases an output");
   }
   for (u32 i = 0; i < b; ++i) {
     if (!out0[i] || !out1[i]) return fail(ACEHIP_EINVAL, "acehip_bsgs_inner: null output");

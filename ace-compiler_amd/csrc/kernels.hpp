@@ -183,6 +183,9 @@ struct BsgsArgs {
   u64* out1[BSGS_MAX_B];
   const u64* pt[BSGS_MAX_PT];   // [b][g] plaintext polynomials (q-limbs first, p-limbs at limb pt_q_alloc); nullptr = absent
   u32 g, b, pt_q_alloc;
+  // in_auto[j] != 0: input j is read through the automorphism X -> X^k of this context, k = in_auto[j] (the kernel computes
+  // the index map like hw_batch_rotate_kernel): the hoisted rotations of Rotate_iteration need no pass of their own
+  u32 in_auto[BSGS_MAX_G];
 };
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s);
 // ---- limb-sharded execution (shard.hip): kernels over PACKED limb lists, limb y of prime gi[y] ----

@@ -219,11 +219,21 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
   ulong2 r0[G], r1[G];
+  const u32 sh = __builtin_clz(c.N) + 1;  // 32 - log2(N)
+  const u32 b0 = __brev(i) >> sh, b1 = __brev(i + 1) >> sh;
 #pragma unroll
   for (int j = 0; j < G; ++j) {
     if (j < (int)a.g) {
-      r0[j] = *reinterpret_cast<const ulong2*>(a.in0[j] + ct_off + i);
-      r1[j] = *reinterpret_cast<const ulong2*>(a.in1[j] + ct_off + i);
+      const u32 k = a.in_auto[j];
+      if (k == 0) {
+        r0[j] = *reinterpret_cast<const ulong2*>(a.in0[j] + ct_off + i);
+        r1[j] = *reinterpret_cast<const ulong2*>(a.in1[j] + ct_off + i);
+      } else {  // rotated input: in[perm_k(i)], perm_k(i) = rev(((2 rev(i) + 1) k mod 2N) / 2)  (automorphism_order_ntt)
+        const u32 px = __brev((((2 * b0 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
+        const u32 py = __brev((((2 * b1 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
+        r0[j] = ulong2{a.in0[j][ct_off + px], a.in0[j][ct_off + py]};
+        r1[j] = ulong2{a.in1[j][ct_off + px], a.in1[j][ct_off + py]};
+      }
     }
   }
   for (u32 bi = 0; bi < a.b; ++bi) {

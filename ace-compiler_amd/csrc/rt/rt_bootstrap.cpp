@@ -436,7 +436,9 @@ std::vector<u64> p_mod_q(u32 level) {
 }
 
 // Fast_rotate_ext ckks_evaluator.c:539-575: automorphism( <key, digits> [+ P*c0] ) in the PQ basis
-void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool add_first) {
+// defer_k != nullptr: the automorphism is left to the consumer (acehip_bsgs_inner_rot reads its inputs through it): rot gets
+// the inner product as it is and *defer_k the automorphism index
+void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool add_first, u32* defer_k = nullptr) {
   Context& c = ctx();
   const u32 l = in.level();
   const u32 k = ensure_rot_key(rotation);
@@ -449,6 +451,11 @@ void fast_rotate_ext(Ct& rot, Ct& in, int32_t rotation, const u64* digits, bool 
     HIPCHK(acehip_key_inner_product_add(c.hip, t0, t1, key->data, digits, l, q_limbs(&in.c._c0_poly), pm.data(), nullptr));
   } else {
     HIPCHK(acehip_key_inner_product(c.hip, t0, t1, key->data, digits, l, nullptr));
+  }
+  if (defer_k) {
+    *defer_k = k;
+    rot.take(tmp);
+    return;
   }
   ev::init(rot, l, c.K, in.c._scaling_factor, in.c._sf_degree, in.c._slots, false);  // the automorphism writes every limb
   const uint32_t* perm = acehip_auto_order(c.hip, k);
@@ -498,20 +505,8 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
   const u32 nd = acehip_num_decomp(c.hip, l);
   u64* digits = dalloc(nd * E, false);
   HIPCHK(acehip_modup_digits(c.hip, digits, q_limbs(&result.c._c1_poly), l, nullptr));
-  std::vector<Ct> fast_rot(giant_step);
-  for (int j = 0; j < giant_step; j++) {
-    const int32_t val = rot_in[step][j];
-    if (val != 0) fast_rotate_ext(fast_rot[j], result, val, digits, true);
-    else switch_key_ext(fast_rot[j], result);
-  }
-  dfree(digits);
-  POLYNOMIAL first{}, temp_poly{};
-  poly_alloc(&first, c.N, l, c.K);
-  poly_alloc(&temp_poly, c.N, l, c.K);
-  first._is_ntt = temp_poly._is_ntt = true;
   // inner_i = sum_j fast_rot[j] (*) diag[giant_step*i + j] for all baby steps in one pass over the diagonals
-  // (acehip_bsgs_inner); the per-output multiply-accumulate chains are the fallback for shapes the kernel does not take
-  std::vector<Ct> inners(baby_step);
+  // (acehip_bsgs_inner_rot); the per-output multiply-accumulate chains are the fallback for shapes the kernel does not take
   bool fused = giant_step <= 16 && baby_step <= 16 && giant_step * baby_step <= 128;
   u32 pt_q = 0;
   if (fused) {
@@ -524,6 +519,20 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         pt_q = nq;
       }
   }
+  // with the fused kernel the automorphisms of the hoisted rotations are applied where that kernel reads its inputs
+  std::vector<Ct> fast_rot(giant_step);
+  std::vector<u32> rot_k(giant_step, 0);
+  for (int j = 0; j < giant_step; j++) {
+    const int32_t val = rot_in[step][j];
+    if (val != 0) fast_rotate_ext(fast_rot[j], result, val, digits, true, fused ? &rot_k[j] : nullptr);
+    else switch_key_ext(fast_rot[j], result);
+  }
+  dfree(digits);
+  POLYNOMIAL first{}, temp_poly{};
+  poly_alloc(&first, c.N, l, c.K);
+  poly_alloc(&temp_poly, c.N, l, c.K);
+  first._is_ntt = temp_poly._is_ntt = true;
+  std::vector<Ct> inners(baby_step);
   if (fused) {
     std::vector<u64*> o0(baby_step), o1(baby_step);
     std::vector<const u64*> i0(giant_step), i1(giant_step), pts((size_t)baby_step * giant_step, nullptr);
@@ -541,7 +550,8 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         if (j == 0 || giant_step * i + j != num_rot)
           pts[(size_t)i * giant_step + j] = q_limbs(&conj_pre[step][giant_step * i + j]->_poly);
     }
-    HIPCHK(acehip_bsgs_inner(c.hip, o0.data(), o1.data(), i0.data(), i1.data(), pts.data(), (u32)giant_step, (u32)baby_step, pt_q, l, nullptr));
+    HIPCHK(acehip_bsgs_inner_rot(c.hip, o0.data(), o1.data(), i0.data(), i1.data(), rot_k.data(), pts.data(), (u32)giant_step, (u32)baby_step,
+                                 pt_q, l, nullptr));
   }
   Ct outer;
   for (int i = 0; i < baby_step; i++) {

@@ -271,6 +271,13 @@ int acehip_key_inner_product_add(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_
 int acehip_bsgs_inner(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* const* d_out1, const uint64_t* const* d_in0,
                       const uint64_t* const* d_in1, const uint64_t* const* d_pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs,
                       uint32_t level, acehip_stream stream);
+/* The same with the automorphisms of the hoisted rotations (Fast_rotate_ext ckks_evaluator.c:539-575 ends with
+ * Automorphism_transform on both polynomials) applied while the inputs are read: h_in_auto[j] = automorphism index k
+ * (acehip_auto_index) of input j, 0 = input j is taken as it is; d_in{0,1}[j] then hold the ciphertext BEFORE the
+ * automorphism.  A rotated input must not alias an output. */
+int acehip_bsgs_inner_rot(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* const* d_out1, const uint64_t* const* d_in0,
+                          const uint64_t* const* d_in1, const uint32_t* h_in_auto, const uint64_t* const* d_pt, uint32_t g, uint32_t b,
+                          uint32_t pt_q_limbs, uint32_t level, acehip_stream stream);
 
 /* ---- limb-sharded execution (BASELINE configs[4]: RNS limbs spread over the GPUs of a node) ----
  * Rank r of `world` owns the limbs gi with gi % world == r (q_i: gi = i, p_j: gi = L + j) of every polynomial and

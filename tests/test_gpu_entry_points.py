@@ -237,5 +237,36 @@ def test_bsgs_inner(env, g, b, missing):
         assert np.array_equal(d_o1[i].download((E, N)), exp1[i]), i
     assert rt.lib.acehip_bsgs_inner(rt.h, arr([d.ptr for d in d_o0]), arr([d.ptr for d in d_o1]), arr([d.ptr for d in d_r0]),
                                     arr([d.ptr for d in d_r1]), pt_tab, 17, b, pt_q, level, None) < 0
-    for d in d_r0 + d_r1 + d_o0 + d_o1 + list(d_pt.values()):
+    # the same products with the inputs given BEFORE their automorphisms (acehip_bsgs_inner_rot: Fast_rotate_ext's
+    # Automorphism_transform applied where the kernel reads them): un-rotate the inputs on the host, pass the indices
+    ks = [0 if j % 3 == 0 else rt.auto_index([1, -2, 5, 7][j % 4]) for j in range(g)]
+    pre0, pre1 = [], []
+    for j in range(g):
+        if ks[j] == 0:
+            pre0.append(rot0[j])
+            pre1.append(rot1[j])
+        else:
+            perm = np.asarray(o.automorphism(ks[j], True), dtype=np.int64)   # rotated[i] = pre[perm[i]]
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(N)
+            pre0.append(np.ascontiguousarray(rot0[j][:, inv]))
+            pre1.append(np.ascontiguousarray(rot1[j][:, inv]))
+            assert np.array_equal(pre0[j][:, perm], rot0[j])
+    d_p0 = [rt.to_device(x) for x in pre0]
+    d_p1 = [rt.to_device(x) for x in pre1]
+    for d in d_o0 + d_o1:
+        d.upload(np.zeros(E * N, dtype=np.uint64))
+    autos = (C.c_uint32 * g)(*ks)
+    rt.check(rt.lib.acehip_bsgs_inner_rot(rt.h, arr([d.ptr for d in d_o0]), arr([d.ptr for d in d_o1]), arr([d.ptr for d in d_p0]),
+                                          arr([d.ptr for d in d_p1]), autos, pt_tab, g, b, pt_q, level, None))
+    for i in range(b):
+        assert np.array_equal(d_o0[i].download((E, N)), exp0[i]), i
+        assert np.array_equal(d_o1[i].download((E, N)), exp1[i]), i
+    even = (C.c_uint32 * g)(*([2] + [0] * (g - 1)))
+    assert rt.lib.acehip_bsgs_inner_rot(rt.h, arr([d.ptr for d in d_o0]), arr([d.ptr for d in d_o1]), arr([d.ptr for d in d_p0]),
+                                        arr([d.ptr for d in d_p1]), even, pt_tab, g, b, pt_q, level, None) < 0
+    if g > 1 and ks[1] != 0:   # a rotated input that is also an output
+        assert rt.lib.acehip_bsgs_inner_rot(rt.h, arr([d_p0[1].ptr] + [d.ptr for d in d_o0[1:]]), arr([d.ptr for d in d_o1]),
+                                            arr([d.ptr for d in d_p0]), arr([d.ptr for d in d_p1]), autos, pt_tab, g, b, pt_q, level, None) < 0
+    for d in d_r0 + d_r1 + d_o0 + d_o1 + d_p0 + d_p1 + list(d_pt.values()):
         d.free()
