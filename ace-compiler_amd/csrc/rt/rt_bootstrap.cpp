@@ -578,10 +578,10 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         poly_add_ext(&first, &first, &temp_poly);
         u64* idig = dalloc(nd * E, false);
         HIPCHK(acehip_modup_digits(c.hip, idig, c1q, l, nullptr));
-        Ct red, tmp;
-        ev::init(red, l, 0, inner.c._scaling_factor, inner.c._sf_degree, inner.c._slots);
-        copy_limbs((u64*)q_limbs(&red.c._c1_poly), (const u64*)c1q, (size_t)l * c.N);
-        fast_rotate_ext(tmp, red, val, idig, false);
+        // (without add_first Fast_rotate_ext takes only level and scale from its ciphertext argument: the reduced c1 itself
+        // enters through its digits)
+        Ct tmp;
+        fast_rotate_ext(tmp, inner, val, idig, false);
         dfree(idig);
         dfree(c1q);
         poly_add_ext(&outer.c._c0_poly, &outer.c._c0_poly, &tmp.c._c0_poly);
