@@ -56,6 +56,7 @@ SYMBOLS = [
     ("acehip_modmul", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_modmuladd", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_rotate", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_rotate_add2", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     ("acehip_hw_modadd", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_modmul", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_hw_rotate", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),

@@ -520,6 +520,18 @@ int acehip_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32_t*
   return post_launch();
 }
 
+int acehip_rotate_add2(acehip_ctx* c, uint64_t* r0, uint64_t* r1, const uint64_t* acc0, const uint64_t* acc1, const uint64_t* a0,
+                       const uint64_t* a1, uint32_t auto_k, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (!r0 || !acc0 || !a0 || (r1 && (!acc1 || !a1))) return fail(ACEHIP_EINVAL, "acehip_rotate_add2: null operand");
+  if (auto_k % 2 == 0 || auto_k >= 2 * c->hp.N) return fail(ACEHIP_EINVAL, "acehip_rotate_add2: automorphism index must be odd and below 2N");
+  if (r0 == a0 || r0 == a1 || (r1 && (r1 == a0 || r1 == a1)))
+    return fail(ACEHIP_EINVAL, "acehip_rotate_add2: the rotated operand must not alias a result");
+  launch_rotate_add2(c->dc, r0, r1, acc0, acc1, a0, a1, auto_k, level, pos0, n, (hipStream_t)s);
+  stat(ST_ROTATE, (r1 ? 2u : 1u) * n, (r1 ? 2ull : 1ull) * n * 24ull * c->hp.N);
+  return post_launch();
+}
+
 // single-limb forms: the limb pointers are used directly; prime_gi selects the modulus
 static int hw(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 gi, acehip_stream s) {
   if (int e = check_dev(c)) return e;

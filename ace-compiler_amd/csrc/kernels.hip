@@ -219,6 +219,38 @@ void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 p
   hipLaunchKernelGGL(rotate_kernel, grid, block, 0, s, c.N, r, a, perm, pos0);
 }
 
+// r_z[pos][j] = acc_z[pos][j] + a_z[pos][perm_k(j)] for one or two polynomials (blockIdx.z): the accumulation of a rotated
+// ciphertext (Rotate_iteration's outer sums, ckks_bootstrap_context.c:1343-1377: Automorphism_transform, then Add_poly)
+// in one pass; the index map of the automorphism X -> X^k is computed (automorphism_order_ntt), not loaded
+__global__ __launch_bounds__(256) void rotate_add2_kernel(DevCtx c, u64* __restrict__ r0, u64* __restrict__ r1,
+                                                          const u64* acc0, const u64* acc1, const u64* __restrict__ a0,
+                                                          const u64* __restrict__ a1, u32 auto_k, u32 level, u32 pos0) {
+  const u32 pos = pos0 + blockIdx.y;
+  const u64 q = c.primes[limb_prime(pos, level, c.L)].q;
+  const size_t base = (size_t)pos * c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const u32 sh = __builtin_clz(c.N) + 1;  // 32 - log2(N)
+  const u32 b0 = __brev(i) >> sh, b1 = __brev(i + 1) >> sh;
+  const u32 px = __brev((((2 * b0 + 1) * auto_k) & (2 * c.N - 1)) >> 1) >> sh;
+  const u32 py = __brev((((2 * b1 + 1) * auto_k) & (2 * c.N - 1)) >> 1) >> sh;
+  const u64* a = blockIdx.z ? a1 : a0;
+  const u64* acc = blockIdx.z ? acc1 : acc0;
+  u64* r = blockIdx.z ? r1 : r0;
+  ulong2 v = *reinterpret_cast<const ulong2*>(acc + base + i);
+  v.x = add_mod(v.x, a[base + px], q);
+  v.y = add_mod(v.y, a[base + py], q);
+  *reinterpret_cast<ulong2*>(r + base + i) = v;
+}
+
+void launch_rotate_add2(const DevCtx& c, u64* r0, u64* r1, const u64* acc0, const u64* acc1, const u64* a0, const u64* a1, u32 auto_k,
+                        u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_ROTATE);
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, r1 ? 2 : 1), block(256);
+  hipLaunchKernelGGL(rotate_add2_kernel, grid, block, 0, s, c, r0, r1, acc0, acc1, a0, a1, auto_k, level, pos0);
+}
+
 // r[l][n] = a[l][n] * w[l] mod prime(gi[l])   (Shoup; per-limb constants in HBM)
 __global__ __launch_bounds__(256) void mul_const_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
                                                         const u64* __restrict__ w, const u64* __restrict__ wp,

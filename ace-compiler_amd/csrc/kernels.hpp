@@ -153,6 +153,9 @@ void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_l
 void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs, hipStream_t s,
                u32 pos_off = 0);
 void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 pos0, u32 n_limbs, hipStream_t s);
+// r_z = acc_z + automorphism_k(a_z) for one (r1 == nullptr) or two polynomials, limbs [pos0, pos0 + n_limbs) at `level`
+void launch_rotate_add2(const DevCtx& c, u64* r0, u64* r1, const u64* acc0, const u64* acc1, const u64* a0, const u64* a1, u32 auto_k,
+                        u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // r[l][n] = shoup(a[l][n], w[l], wp[l]) for limbs l in [0,n) with primes gi[l]  (tables in HBM)
 void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const u64* wp, const u32* gi, u32 n_limbs, hipStream_t s);
 // base conversion: out[pos[j]][n] = (sum_i in[i][n] * hat[i*hat_ld + j]) mod prime(out_gi[j])

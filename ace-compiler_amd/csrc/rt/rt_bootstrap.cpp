@@ -528,10 +528,9 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
     else switch_key_ext(fast_rot[j], result);
   }
   dfree(digits);
-  POLYNOMIAL first{}, temp_poly{};
+  POLYNOMIAL first{};
   poly_alloc(&first, c.N, l, c.K);
-  poly_alloc(&temp_poly, c.N, l, c.K);
-  first._is_ntt = temp_poly._is_ntt = true;
+  first._is_ntt = true;
   std::vector<Ct> inners(baby_step);
   if (fused) {
     std::vector<u64*> o0(baby_step), o1(baby_step);
@@ -573,19 +572,20 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         u64* c1q = dalloc((size_t)l * c.N, false);
         HIPCHK(acehip_mod_down(c.hip, c1q, q_limbs(&inner.c._c1_poly), l, nullptr));
         const u32 k = ensure_rot_key(val);
-        const uint32_t* perm = acehip_auto_order(c.hip, k);
-        q_rotate(q_limbs(&temp_poly), q_limbs(&inner.c._c0_poly), perm, l, 0, l + c.K);
-        poly_add_ext(&first, &first, &temp_poly);
+        // first += automorphism(inner.c0), outer += automorphism(key-switched c1): each sum in the pass that applies the map
+        HIPCHK(acehip_rotate_add2(c.hip, q_limbs(&first), nullptr, q_limbs(&first), nullptr, q_limbs(&inner.c._c0_poly), nullptr, k, l, 0,
+                                  l + c.K, nullptr));
         u64* idig = dalloc(nd * E, false);
         HIPCHK(acehip_modup_digits(c.hip, idig, c1q, l, nullptr));
         // (without add_first Fast_rotate_ext takes only level and scale from its ciphertext argument: the reduced c1 itself
         // enters through its digits)
         Ct tmp;
-        fast_rotate_ext(tmp, inner, val, idig, false);
+        u32 k2 = 0;
+        fast_rotate_ext(tmp, inner, val, idig, false, &k2);
         dfree(idig);
         dfree(c1q);
-        poly_add_ext(&outer.c._c0_poly, &outer.c._c0_poly, &tmp.c._c0_poly);
-        poly_add_ext(&outer.c._c1_poly, &outer.c._c1_poly, &tmp.c._c1_poly);
+        HIPCHK(acehip_rotate_add2(c.hip, q_limbs(&outer.c._c0_poly), q_limbs(&outer.c._c1_poly), q_limbs(&outer.c._c0_poly),
+                                  q_limbs(&outer.c._c1_poly), q_limbs(&tmp.c._c0_poly), q_limbs(&tmp.c._c1_poly), k2, l, 0, l + c.K, nullptr));
       } else {
         poly_add_ext(&first, &first, &inner.c._c0_poly);
         poly_add_ext(&outer.c._c1_poly, &outer.c._c1_poly, &inner.c._c1_poly);
@@ -598,7 +598,6 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
   HIPCHK(acehip_mod_down2(c.hip, q_limbs(&out.c._c0_poly), q_limbs(&out.c._c1_poly), q_limbs(&outer.c._c0_poly),
                           q_limbs(&outer.c._c1_poly), l, nullptr));
   poly_free(&first);
-  poly_free(&temp_poly);
   result.take(out);
 }
 

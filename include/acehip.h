@@ -113,6 +113,12 @@ int acehip_modmul(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const u
 /* res += a*b   (Multiply_add polynomial.c:148-183) */
 int acehip_modmuladd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
 int acehip_rotate(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint32_t* d_perm, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+/* res_z = acc_z + automorphism_k(a_z) on one (d_res1 == NULL) or two polynomials: Automorphism_transform followed by Add_poly
+ * (the outer sums of Rotate_iteration, ckks_bootstrap_context.c:1343-1377) in one pass.  auto_k: acehip_auto_index();
+ * d_res may be d_acc, d_a must not alias a result. */
+int acehip_rotate_add2(acehip_ctx* ctx, uint64_t* d_res0, uint64_t* d_res1, const uint64_t* d_acc0, const uint64_t* d_acc1,
+                       const uint64_t* d_a0, const uint64_t* d_a1, uint32_t auto_k, uint32_t level, uint32_t pos0, uint32_t n_limbs,
+                       acehip_stream stream);
 /* single-limb forms with an explicit prime index, the exact shape of the generated code's calls
  * Hw_modadd(res, a, b, modulus, degree) where modulus = Q_modulus()+i or P_modulus()+i */
 int acehip_hw_modadd(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* d_b, uint32_t prime_gi, acehip_stream stream);

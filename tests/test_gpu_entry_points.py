@@ -97,6 +97,34 @@ def test_key_inner_product_add(env):
         d.free()
 
 
+def test_rotate_add2(env):
+    """res_z = acc_z + automorphism_k(a_z) on PQ-extended polynomials (Rotate_iteration's outer sums: Automorphism_transform
+    then Add_poly, ckks_bootstrap_context.c:1343-1377), one and two polynomials, in place on the accumulator"""
+    o, rt, level = env
+    N, K = o.N, o.K
+    E = level + K
+    gis = _gis(o, level, E)
+    k = rt.auto_index(-3)
+    perm = np.asarray(o.automorphism(k, True), dtype=np.int64)
+    acc = [o.uniform(E, level, 760 + z) for z in range(2)]
+    a = [o.uniform(E, level, 770 + z) for z in range(2)]
+    want = [o.hw_modadd(acc[z], np.ascontiguousarray(a[z][:, perm]), gis) for z in range(2)]
+    d_acc = [rt.to_device(x) for x in acc]
+    d_a = [rt.to_device(x) for x in a]
+    d_r = rt.buf(E * N)
+    # one polynomial, out of place
+    rt.check(rt.lib.acehip_rotate_add2(rt.h, d_r.ptr, None, d_acc[0].ptr, None, d_a[0].ptr, None, k, level, 0, E, None))
+    assert np.array_equal(d_r.download((E, N)), want[0])
+    # two polynomials, in place on the accumulators
+    rt.check(rt.lib.acehip_rotate_add2(rt.h, d_acc[0].ptr, d_acc[1].ptr, d_acc[0].ptr, d_acc[1].ptr, d_a[0].ptr, d_a[1].ptr, k, level, 0, E, None))
+    assert np.array_equal(d_acc[0].download((E, N)), want[0]) and np.array_equal(d_acc[1].download((E, N)), want[1])
+    # the rotated operand as a result, an even index
+    assert rt.lib.acehip_rotate_add2(rt.h, d_a[0].ptr, None, d_acc[0].ptr, None, d_a[0].ptr, None, k, level, 0, E, None) < 0
+    assert rt.lib.acehip_rotate_add2(rt.h, d_r.ptr, None, d_acc[0].ptr, None, d_a[0].ptr, None, 4, level, 0, E, None) < 0
+    for d in d_acc + d_a + [d_r]:
+        d.free()
+
+
 def test_decomp_then_mod_up_equals_decomp_modup(env):
     """the unfused pair of the generated code (eg_fhertlib_relin.inc:79-80): Decomp copies the digit's limbs, Mod_up raises
     them; together they must give what Decomp_modup gives (oracle: Decompose_modup polynomial.c:1241-1335)."""
