@@ -562,9 +562,10 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
         if (giant + j != num_rot) mul_plain_ext(inner, fast_rot[j], conj_pre[step][giant + j], true);
     }
     if (i == 0) {
-      poly_copy(&first, &inner.c._c0_poly);
-      fill_zero((u64*)inner.c._c0_poly._data, E);
-      ev::copy(outer, inner);
+      // first = inner.c0, outer = (0, inner.c1): by exchanging blocks -- `first` was allocated zero-filled with the very shape of
+      // inner.c0 (l q-limbs + K p-limbs), so after the exchange inner.c0 IS the zero polynomial the reference fills in
+      std::swap(first._data, inner.c._c0_poly._data);
+      outer.take(inner);
     } else {
       const int32_t val = rot_out[step][i];
       if (val != 0) {
