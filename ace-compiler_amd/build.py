@@ -24,8 +24,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacehip.so")
-SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "rt_kernels.hip", "embed.hip", "hw_batch.hip", "shard.hip", "api.cpp", "host_params.cpp"]
-HEADERS = ["kernels.hpp", "device_arith.hpp", "host_params.hpp", "rou_table.inc", os.path.join("..", "..", "include", "acehip.h")]
+SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "rt_kernels.hip", "embed.hip", "hw_batch.hip", "shard.hip", "api_core.cpp", "api_hw_batch.cpp", "api_ops.cpp", "api_shard.cpp", "host_params.cpp"]
+HEADERS = ["kernels.hpp", "api_internal.hpp", "device_arith.hpp", "host_params.hpp", "rou_table.inc", os.path.join("..", "..", "include", "acehip.h")]
 ROCM_LIB = "/opt/rocm/lib"
 
 

@@ -1,0 +1,349 @@
+// api_core.cpp -- C ABI (include/acehip.h): context / table upload, device memory helpers, call statistics.
+#include "api_internal.hpp"
+
+std::string& acehip_err_slot() {
+  static thread_local std::string e;
+  return e;
+}
+acehip_stat* acehip_stat_slots() {
+  static thread_local acehip_stat g[ST_COUNT];
+  return g;
+}
+static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
+                                                "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed"};
+
+extern "C" {
+
+const char* acehip_last_error(void) { return acehip_err_slot().c_str(); }
+
+int acehip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+acehip_ctx* acehip_ctx_create_host(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum) {
+  std::unique_ptr<acehip_ctx> ctx;
+  try {
+    ctx.reset(new acehip_ctx());
+    ctx->hp = make_params(N, L, q0_bits, sf_bits, dnum);
+    return ctx.release();
+  } catch (const std::exception& e) {  // the half-built context is released (found by `make -C oracle asan`)
+    acehip_err_slot() = e.what();
+    return nullptr;
+  }
+}
+
+acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t sf_bits, uint32_t dnum, int device) {
+  if (acehip_device_count() <= device || device < 0) {
+    acehip_err_slot() = "acehip_ctx_create: no such GPU device (the HIP path has no CPU fallback)";
+    return nullptr;
+  }
+  acehip_ctx* ctx = acehip_ctx_create_host(N, L, q0_bits, sf_bits, dnum);
+  if (!ctx) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) {
+    acehip_err_slot() = "hipSetDevice failed";
+    delete ctx;
+    return nullptr;
+  }
+  ctx->device = device;
+  const HostParams& hp = ctx->hp;
+  const u32 T = hp.L + hp.K;
+  std::vector<DevPrime> dp(T);
+  std::memcpy(dp.data(), hp.primes.data(), T * sizeof(DevPrime));
+  ctx->dc.primes = ctx->up(dp);
+  {  // interleave {w, Shoup companion} so that a twiddle is one 16-byte load
+    std::vector<ulong2> tw((size_t)T * hp.N);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = ulong2{hp.rou[i], hp.rou_prec[i]};
+    ctx->dc.tw_fwd = ctx->up(tw);
+    for (size_t i = 0; i < tw.size(); ++i) tw[i] = ulong2{hp.rou_inv[i], hp.rou_inv_prec[i]};
+    ctx->dc.tw_inv = ctx->up(tw);
+  }
+  ctx->dc.N = hp.N;
+  ctx->dc.logN = hp.logN;
+  ctx->dc.L = hp.L;
+  ctx->dc.K = hp.K;
+  {
+    u32 max_bits = 0;
+    for (u32 i = 0; i < T; ++i) max_bits = std::max(max_bits, (u32)hp.primes[i].nbits);
+    ctx->dc.split_bits = (max_bits + 1) / 2;  // <= 31: primes are below 2^61 (host_params)
+  }
+  ctx->phat_inv = ctx->up(hp.phat_inv_modp);
+  ctx->phat_inv_prec = ctx->up(hp.phat_inv_modp_prec);
+  // base_conv wants hat[i_src][j_dst]: transpose phat_modq[L][K] -> [K][L]
+  std::vector<u64> tr((size_t)hp.K * hp.L);
+  for (u32 i = 0; i < hp.L; ++i)
+    for (u32 j = 0; j < hp.K; ++j) tr[(size_t)j * hp.L + i] = hp.phat_modq[(size_t)i * hp.K + j];
+  ctx->phat_modq_t = ctx->up(tr);
+  ctx->pinv = ctx->up(hp.pinv_modq);
+  ctx->pinv_prec = ctx->up(hp.pinv_modq_prec);
+  ctx->ql_inv = ctx->up(hp.ql_inv);
+  ctx->ql_inv_prec = ctx->up(hp.ql_inv_prec);
+  ctx->qlql = ctx->up(hp.qlql);
+  ctx->qlql_prec = ctx->up(hp.qlql_prec);
+  std::vector<u32> pgi(hp.K), qgi(hp.L);
+  for (u32 j = 0; j < hp.K; ++j) pgi[j] = hp.L + j;
+  for (u32 i = 0; i < hp.L; ++i) qgi[i] = i;
+  ctx->p_gi = ctx->up(pgi);
+  ctx->q_gi = ctx->up(qgi);
+  ctx->q_pos = ctx->q_gi;
+  if (hp.logN == 16) {  // companion-only twiddle tables (ntt_fast.hip Tp15): 8-byte twiddle stream in the contiguous passes
+    // ACEHIP_NTT_TW8_POLYS = largest number of polynomials per launch that uses them (0: never).  Measured: ResNet-20 1.68 ->
+    // 1.73 images/s, C3 key-switch 0.248 -> 0.237 ms, 1024-limb batch 0.555 -> 0.537 ms with every launch on the 8-byte stream
+    const char* e = getenv("ACEHIP_NTT_TW8_POLYS");
+    const u32 maxp = e ? (u32)strtoul(e, nullptr, 0) : 65535u;
+    if (maxp) {
+      ctx->dc.twp_fwd = ctx->up(hp.rou_prec);
+      ctx->dc.twp_inv = ctx->up(hp.rou_inv_prec);
+      ctx->dc.tw8_max_polys = (ctx->dc.twp_fwd && ctx->dc.twp_inv) ? maxp : 0;
+      if (!ctx->dc.tw8_max_polys) ctx->dc.twp_fwd = ctx->dc.twp_inv = nullptr;
+    }
+  }
+  {  // ACEHIP_NTT_NARROW = largest launch (limb rows) that takes the narrow small-launch passes (0: never)
+    const char* e = getenv("ACEHIP_NTT_NARROW");
+    ctx->dc.ntt_narrow_max_rows = e ? (u32)strtoul(e, nullptr, 0) : 16u;
+  }
+  // workspace of the batched key-switch: coef (L) + ext[dnum] + two accumulators (L+K each) + tmp (2L)
+  ctx->ws_words = ((size_t)hp.L * 3 + (size_t)(hp.dnum + 2) * T) * hp.N;
+  if (hipMalloc(&ctx->ws, ctx->ws_words * sizeof(u64)) != hipSuccess || !ctx->dc.primes || !ctx->dc.tw_inv) {
+    acehip_err_slot() = "acehip_ctx_create: device allocation/upload failed";
+    acehip_ctx_destroy(ctx);
+    return nullptr;
+  }
+  ctx->owned.push_back(ctx->ws);
+  ctx->on_device = true;
+  return ctx;
+}
+
+void acehip_ctx_destroy(acehip_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  for (void* p : ctx->owned) (void)hipFree(p);
+  if (ctx->hw_scratch) (void)hipFree(ctx->hw_scratch);
+  delete ctx;
+}
+
+uint32_t acehip_degree(const acehip_ctx* c) { return c->hp.N; }
+uint32_t acehip_num_q(const acehip_ctx* c) { return c->hp.L; }
+uint32_t acehip_num_p(const acehip_ctx* c) { return c->hp.K; }
+uint32_t acehip_num_q_parts(const acehip_ctx* c) { return c->hp.dnum; }
+uint32_t acehip_part_size(const acehip_ctx* c) { return c->hp.alpha; }
+uint32_t acehip_num_decomp(const acehip_ctx* c, uint32_t level) { return c->hp.num_decomp(level); }
+uint64_t acehip_prime(const acehip_ctx* c, uint32_t gi) { return gi < c->hp.L + c->hp.K ? c->hp.primes[gi].q : 0; }
+
+int64_t acehip_get_table(const acehip_ctx* c, int what, uint32_t gi, uint64_t* out, size_t cap) {
+  const HostParams& hp = c->hp;
+  const u32 T = hp.L + hp.K;
+  auto copy = [&](const u64* src, size_t n) -> int64_t {
+    if (cap < n) return fail(ACEHIP_EINVAL, "acehip_get_table: buffer too small");
+    std::memcpy(out, src, n * sizeof(u64));
+    return (int64_t)n;
+  };
+  if (what >= 0 && what <= 4) {
+    if (cap < T) return fail(ACEHIP_EINVAL, "acehip_get_table: buffer too small");
+    for (u32 i = 0; i < T; ++i) {
+      const PrimeConsts& p = hp.primes[i];
+      out[i] = what == 0 ? p.psi : what == 1 ? p.n_inv : what == 2 ? p.n_inv_prec : what == 3 ? p.prec128_lo : p.prec128_hi;
+    }
+    return T;
+  }
+  if (what >= 10 && what <= 13) {
+    if (gi >= T) return fail(ACEHIP_EINVAL, "acehip_get_table: bad prime index");
+    const std::vector<u64>& v = what == 10 ? hp.rou : what == 11 ? hp.rou_prec : what == 12 ? hp.rou_inv : hp.rou_inv_prec;
+    return copy(v.data() + (size_t)gi * hp.N, hp.N);
+  }
+  switch (what) {
+    case 20: return copy(hp.phat_inv_modp.data(), hp.K);
+    case 21: return copy(hp.phat_inv_modp_prec.data(), hp.K);
+    case 22: return copy(hp.phat_modq.data(), (size_t)hp.L * hp.K);
+    case 23: return copy(hp.pinv_modq.data(), hp.L);
+    case 30: return copy(hp.ql_inv.data(), (size_t)hp.L * hp.L);
+    case 31: return copy(hp.ql_inv_prec.data(), (size_t)hp.L * hp.L);
+    case 32: return copy(hp.qlql.data(), (size_t)hp.L * hp.L);
+    case 33: return copy(hp.qlql_prec.data(), (size_t)hp.L * hp.L);
+  }
+  return fail(ACEHIP_EINVAL, "acehip_get_table: unknown table id");
+}
+
+int acehip_get_modup_tables(const acehip_ctx* c, uint32_t level, uint32_t digit, uint64_t* hat_inv,
+                            uint32_t* compl_idx, uint64_t* hat_mod, uint32_t* nc_out) {
+  if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "bad level/digit");
+  HostParams::ModUp t = c->hp.modup(level, digit);
+  std::memcpy(hat_inv, t.hat_inv.data(), t.n2 * sizeof(u64));
+  std::memcpy(compl_idx, t.compl_idx.data(), t.nc * sizeof(u32));
+  std::memcpy(hat_mod, t.hat_mod.data(), (size_t)t.n2 * t.nc * sizeof(u64));
+  *nc_out = t.nc;
+  return (int)t.n2;
+}
+
+uint32_t acehip_auto_index(const acehip_ctx* c, int32_t rot_idx) { return find_automorphism_index(rot_idx, c->hp.N); }
+
+int acehip_auto_order_host(const acehip_ctx* c, uint32_t k, uint32_t* out_perm) {
+  if ((k & 1) == 0 || k >= 2 * c->hp.N) return fail(ACEHIP_EINVAL, "automorphism index must be odd and < 2N");
+  automorphism_order_ntt(out_perm, k, c->hp.N);
+  return ACEHIP_OK;
+}
+
+const uint32_t* acehip_auto_order(acehip_ctx* c, uint32_t k) {
+  if (!c->on_device) {
+    acehip_err_slot() = "acehip_auto_order: context has no device";
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto it = c->auto_tabs.find(k);
+  if (it != c->auto_tabs.end()) return it->second;
+  std::vector<u32> perm(c->hp.N);
+  if (acehip_auto_order_host(c, k, perm.data()) != ACEHIP_OK) return nullptr;
+  (void)hipSetDevice(c->device);
+  u32* d = c->up(perm);
+  if (!d) {
+    acehip_err_slot() = "acehip_auto_order: upload failed";
+    return nullptr;
+  }
+  c->auto_tabs[k] = d;
+  c->auto_tab_k[d] = k;
+  return d;
+}
+
+// ---- memory helpers ----
+void* acehip_malloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    acehip_err_slot() = "hipMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+int acehip_free(void* p) {
+  HIP_TRY(hipFree(p));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_h2d(void* d, const void* h, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+void* acehip_malloc_host(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    acehip_err_slot() = "hipHostMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+int acehip_free_host(void* p) {
+  HIP_TRY(hipHostFree(p));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_h2d_async(void* d, const void* h, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_event_sync(void* e) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)e));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_d2h(void* h, const void* d, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_memcpy_d2d(void* d, const void* s_, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_memset(void* d, int v, size_t n, acehip_stream s) {
+  HIP_TRY(hipMemsetAsync(d, v, n, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_stream_sync(acehip_stream s) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+void* acehip_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) {
+    acehip_err_slot() = "hipEventCreate failed";
+    return nullptr;
+  }
+  return (void*)e;
+}
+int acehip_event_record(void* e, acehip_stream s) {
+  HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_event_elapsed_ms(void* a, void* b, float* ms) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return ACEHIP_OK;
+}
+int acehip_event_destroy(void* e) {
+  HIP_TRY(hipEventDestroy((hipEvent_t)e));
+  return ACEHIP_OK;
+}
+
+}  // extern "C"
+
+int check_dev(acehip_ctx* c) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if (!c->on_device) return fail(ACEHIP_ENODEV, "context was created without a GPU; the HIP path has no CPU fallback");
+  // every entry point launches on the context's own device, whichever device the calling thread last selected (a thread
+  // may hold contexts on several GPUs; hipGetDevice is a thread-local read)
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
+    if (hipSetDevice(c->device) != hipSuccess) return fail(ACEHIP_EHIP, "hipSetDevice failed");
+  }
+  return ACEHIP_OK;
+}
+int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n) {
+  if (int e = check_dev(c)) return e;
+  if (level > c->hp.L) return fail(ACEHIP_EINVAL, "level exceeds the number of q primes");
+  if (pos0 + n > level + c->hp.K) return fail(ACEHIP_EINVAL, "limb range exceeds level + K");
+  return ACEHIP_OK;
+}
+int post_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ACEHIP_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return ACEHIP_OK;
+}
+
+const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto key = std::make_pair(level, digit);
+  auto it = c->modup.find(key);
+  if (it != c->modup.end()) return &it->second;
+  HostParams::ModUp t = c->hp.modup(level, digit);
+  DevModUp d;
+  d.n2 = t.n2;
+  d.nc = t.nc;
+  d.start = t.start;
+  std::vector<u32> src_gi(t.n2), pos(t.nc);
+  for (u32 i = 0; i < t.n2; ++i) src_gi[i] = t.start + i;
+  for (u32 j = 0; j < t.nc; ++j) pos[j] = t.compl_idx[j] < c->hp.L ? t.compl_idx[j] : level + (t.compl_idx[j] - c->hp.L);
+  d.hat_inv = c->up(t.hat_inv);
+  d.hat_inv_prec = c->up(t.hat_inv_prec);
+  d.hat_mod = c->up(t.hat_mod);
+  d.src_gi = c->up(src_gi);
+  d.out_gi = c->up(t.compl_idx);
+  d.out_pos = c->up(pos);
+  if (!d.hat_inv || !d.hat_mod || !d.out_pos) return nullptr;
+  return &(c->modup[key] = d);
+}
+
+extern "C" {
+
+int acehip_stats(acehip_stat* out, int n, int reset) {
+  acehip_stat* g_stat = acehip_stat_slots();
+  for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = g_stat[i];
+  if (reset) std::memset(g_stat, 0, sizeof(acehip_stat) * ST_COUNT);
+  return ST_COUNT;
+}
+const char* acehip_stat_name(int i) { return i >= 0 && i < ST_COUNT ? kStatName[i] : nullptr; }
+
+uint64_t acehip_key_switch_bytes(const acehip_ctx* c, uint32_t level) {
+  const HostParams& hp = c->hp;
+  const u64 b = hp.num_decomp(level);
+  return 8ull * hp.N * (level + 2 * b * (level + hp.K) + 2 * level);
+}
+
+}  // extern "C"

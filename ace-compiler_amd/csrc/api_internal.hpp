@@ -1,0 +1,120 @@
+// api_internal.hpp -- shared between the translation units of the C ABI (include/acehip.h):
+//   api_core.cpp      context, tables, memory helpers, statistics
+//   api_hw_batch.cpp  acehip_hw_batch: analysis of a per-limb op list and its launches
+//   api_ops.cpp       the launch entry points and the Decomp_modup / Mod_down / Rescale / key-switch / encode pipelines
+//   api_shard.cpp     packed-list phases of limb-sharded execution (acehip_shard_*)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/acehip.h"
+#include "host_params.hpp"
+#include "kernels.hpp"
+
+using namespace acehip;
+
+std::string& acehip_err_slot();  // this thread's last error message
+inline int fail(int code, const std::string& msg) {
+  acehip_err_slot() = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(ACEHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static_assert(sizeof(PrimeConsts) == sizeof(DevPrime), "host/device prime layout mismatch");
+
+struct DevModUp {
+  u32 n2 = 0, nc = 0, start = 0;
+  u64 *hat_inv = nullptr, *hat_inv_prec = nullptr, *hat_mod = nullptr;
+  u32 *src_gi = nullptr, *out_gi = nullptr, *out_pos = nullptr;
+};
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+  T* d = nullptr;
+  if (v.empty()) return nullptr;
+  if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return d;
+}
+
+// Per-level plan of the batched key-switch: one ConvDesc per digit (ModUp) and one for ModDown.
+struct KsPlan {
+  ConvDesc* d_descs = nullptr;  // [nd] ModUp problems, then [1] ModDown problem
+  u32 nd = 0, max_nc = 0;
+  // N = 2^16: the pre-factors of both base conversions ride in the last stage of the inverse NTT (NttFuse::inv_scale)
+  u64* inv_up = nullptr;    // [level][4]
+  u64* inv_down = nullptr;  // [K][4]
+};
+
+struct acehip_ctx {
+  HostParams hp;
+  bool on_device = false;
+  int device = -1;
+  DevCtx dc{};
+  std::vector<void*> owned;  // device allocations freed at destroy
+  // device CRT tables
+  u64 *phat_inv = nullptr, *phat_inv_prec = nullptr, *phat_modq_t = nullptr, *pinv = nullptr, *pinv_prec = nullptr;
+  u64 *ql_inv = nullptr, *ql_inv_prec = nullptr, *qlql = nullptr, *qlql_prec = nullptr;
+  u32 *p_gi = nullptr;                     // [K] global indices of the p primes
+  u32 *q_gi = nullptr, *q_pos = nullptr;   // [L] identity lists for ModDown targets
+  std::mutex mu;
+  std::map<std::pair<u32, u32>, DevModUp> modup;
+  std::map<u32, u32*> auto_tabs;
+  std::map<const void*, u32> auto_tab_k;   // device table -> automorphism index (hw_run_rotate: the kernel computes the index map)
+  std::map<u32, KsPlan> ks_plans;
+  // workspace (one per context; launches of one context are expected on one stream at a time)
+  u64* ws = nullptr;
+  size_t ws_words = 0;
+  // encode (embed.hip): twiddles cos/sin(2 pi j / 2N) from the host libm, 5^i mod 2N, scratch, sticky overflow flag
+  u64* hw_scratch = nullptr;       // acehip_hw_batch: private limbs for renamed intermediate versions
+  size_t hw_scratch_limbs = 0;
+  cd* emb_rou = nullptr;
+  u32* emb_rot = nullptr;
+  cd* emb_work = nullptr;
+  int64_t* emb_msg = nullptr;
+  int* emb_err = nullptr;
+  std::map<std::pair<u64, u32>, u64*> enc_scales;  // (Delta, sf_degree) -> [L] Delta^(sf_degree-1) mod q_i
+
+  template <typename T>
+  T* up(const std::vector<T>& v) {
+    T* d = upload(v);
+    if (d) owned.push_back(d);
+    return d;
+  }
+};
+
+// ---- call statistics: algorithmic bytes of SURVEY 8(d) per entry point (tables and scratch excluded) ----
+enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_COUNT };
+acehip_stat* acehip_stat_slots();  // this thread's counters [ST_COUNT] (one host thread = one image stream)
+inline void stat(int k, u64 units, u64 bytes) {
+  acehip_stat* g = acehip_stat_slots();
+  g[k].calls++;
+  g[k].units += units;
+  g[k].bytes += bytes;
+}
+
+// ---- argument checks shared by the launch entry points ----
+int check_dev(acehip_ctx* c);
+int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n);
+int post_launch();
+const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit);
+const KsPlan* get_ks_plan(acehip_ctx* c, u32 level);
+bool conv_fusable(const acehip_ctx* c, u32 n_in);
+// workspace carving (in limbs of N words)
+inline u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
+int ensure_embed_tables(acehip_ctx* c);

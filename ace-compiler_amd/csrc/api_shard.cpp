@@ -1,0 +1,439 @@
+// api_shard.cpp -- packed-list phases of limb-sharded execution (include/acehip.h "Limb-sharded execution").
+#include "api_internal.hpp"
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------
+// Limb-sharded execution (BASELINE configs[4]): rank r of `world` holds the limbs gi with gi % world == r
+// of every polynomial and key (q_i: gi = i, p_j: gi = L + j), packed in ascending gi.  NTT, limb-wise arithmetic and
+// the key inner product are local; the two base conversions of a key-switch and the last limb of a rescale need the
+// other ranks' limbs: the caller moves those with one all-gather / broadcast each (RCCL over xGMI on a node) between
+// the phases below.  Every phase is a handful of batched launches on the caller's stream and never synchronises.
+// The arithmetic is that of acehip_key_switch / acehip_rescale: gathering every rank's result reproduces them bit
+// for bit (tests/test_gpu_shard.py runs world simulated ranks on one GPU).
+// ------------------------------------------------------------------------------------------------
+struct ShardLevelPlan {
+  u32 nq = 0, nd = 0;
+  ConvDesc* d_up = nullptr;             // [nd] ModUp onto the owned complement limbs of each digit
+  ConvDesc* d_down = nullptr;           // [1]  ModDown onto the owned q-limbs
+  std::vector<u32> n_tgt;               // per digit: converted limbs
+  std::vector<std::vector<u32>> tgt_y;  // per digit: packed index (among the owned limbs at this level) of each target
+  std::vector<u32*> d_tgt_gi;           // per digit: primes of the targets (NTT of the raised limbs)
+  u32 max_tgt = 0;
+  u64 *d_pinv = nullptr, *d_pinv_prec = nullptr;                      // [nq]  P^-1 mod q (ModDown tail)
+  u64 *d_rs_c1 = nullptr, *d_rs_c1p = nullptr, *d_rs_inv = nullptr, *d_rs_invp = nullptr;  // rescale constants of the owned limbs < level-1
+  u32 nq_rs = 0;
+};
+struct acehip_shard {
+  acehip_ctx* c = nullptr;
+  u32 rank = 0, world = 1;
+  std::vector<u32> q_own, p_own;        // owned q indices i (ascending), owned p indices j
+  u32 *d_q_gi = nullptr, *d_p_gi = nullptr, *d_own_gi_full = nullptr;  // device: gi of owned q-limbs / p-limbs / both
+  u64 *full = nullptr, *ext = nullptr, *acc = nullptr, *pfull = nullptr, *conv = nullptr, *tmp = nullptr;
+  std::map<u32, ShardLevelPlan> plans;
+  std::mutex mu;
+};
+
+namespace {
+using PtrTab = PackedPtrs;
+u32 shard_nq(const acehip_shard* sh, u32 level) {
+  u32 n = 0;
+  while (n < sh->q_own.size() && sh->q_own[n] < level) ++n;
+  return n;
+}
+u32 shard_pad(const acehip_shard* sh, u32 n_total) {  // most limbs any rank owns out of gi in [0, n_total)
+  return (n_total + sh->world - 1) / sh->world;
+}
+// NTT of n packed limbs of primes h_gi[0..n) (device copy d_gi), n_polys polynomials `stride` words apart, optionally
+// reading the input out of place (inverse, N = 2^16) from src0 / src1
+void ntt_packed(acehip_ctx* c, u64* data, const u64* src0, const u64* src1, const u32* d_gi, const u32* h_gi, u32 n, u32 n_polys,
+                size_t stride, bool inverse, hipStream_t s) {
+  if (n == 0) return;
+  const size_t N = c->hp.N;
+  if (c->dc.logN == 16) {
+    NttFuse f;
+    f.gi_tab = d_gi;
+    f.src0 = src0;
+    f.src1 = src1;
+    launch_ntt_fused(c->dc, data, 0, 0, n, inverse, s, 0, n_polys, stride, 0, f);
+    return;
+  }
+  for (u32 z = 0; z < n_polys; ++z) {
+    const u64* src = z ? src1 : src0;
+    if (src) (void)hipMemcpyAsync(data + z * stride, src, (size_t)n * N * sizeof(u64), hipMemcpyDeviceToDevice, s);
+    for (u32 k = 0; k < n; ++k) {
+      const u32 gi = h_gi[k];
+      u64* ptr = data + z * stride + (size_t)k * N;
+      if (gi < c->hp.L) launch_ntt(c->dc, ptr, c->hp.L, gi, 1, inverse, s, gi);
+      else              launch_ntt(c->dc, ptr, 0, gi - c->hp.L, 1, inverse, s, gi - c->hp.L);
+    }
+  }
+}
+const ShardLevelPlan* shard_plan(acehip_shard* sh, u32 level) {
+  std::lock_guard<std::mutex> g(sh->mu);
+  auto it = sh->plans.find(level);
+  if (it != sh->plans.end()) return &it->second;
+  acehip_ctx* c = sh->c;
+  const HostParams& hp = c->hp;
+  ShardLevelPlan pl;
+  pl.nq = shard_nq(sh, level);
+  pl.nd = hp.num_decomp(level);
+  // owned limbs at this level, in packed order: (position, prime)
+  std::vector<std::pair<u32, u32>> own;
+  for (u32 k = 0; k < pl.nq; ++k) own.push_back({sh->q_own[k], sh->q_own[k]});
+  for (u32 j : sh->p_own) own.push_back({level + j, hp.L + j});
+  std::vector<ConvDesc> up(pl.nd);
+  pl.n_tgt.resize(pl.nd);
+  pl.tgt_y.resize(pl.nd);
+  pl.d_tgt_gi.resize(pl.nd, nullptr);
+  for (u32 d = 0; d < pl.nd; ++d) {
+    const DevModUp* t = get_modup(c, level, d);
+    if (!t) return nullptr;
+    HostParams::ModUp hm = hp.modup(level, d);
+    std::vector<u32> gi, col, pos;
+    for (u32 y = 0; y < own.size(); ++y) {
+      const u32 p = own[y].first, want = own[y].second;
+      if (p >= hm.start && p < hm.start + hm.n2) continue;  // the digit's own limbs pass through
+      u32 j = 0;
+      while (j < hm.nc && hm.compl_idx[j] != want) ++j;
+      if (j == hm.nc) return nullptr;
+      gi.push_back(want);
+      col.push_back(j);
+      pos.push_back((u32)pl.tgt_y[d].size());
+      pl.tgt_y[d].push_back(y);
+    }
+    pl.n_tgt[d] = (u32)gi.size();
+    pl.max_tgt = std::max(pl.max_tgt, pl.n_tgt[d]);
+    ConvDesc cd{};
+    cd.hat = t->hat_mod;
+    cd.scale = t->hat_inv;
+    cd.scale_prec = t->hat_inv_prec;
+    cd.src_gi = t->src_gi;
+    cd.n_in = t->n2;
+    cd.hat_ld = t->nc;
+    cd.src_pos0 = hm.start;
+    cd.n_out = pl.n_tgt[d];
+    if (cd.n_out) {
+      cd.out_gi = pl.d_tgt_gi[d] = c->up(gi);
+      cd.col = c->up(col);
+      cd.out_pos = c->up(pos);
+      if (!cd.out_gi || !cd.col || !cd.out_pos) return nullptr;
+    }
+    up[d] = cd;
+  }
+  pl.d_up = c->up(up);
+  if (pl.nq) {
+    std::vector<u32> gi(pl.nq), pos(pl.nq);
+    std::vector<u64> pinv(pl.nq), pinvp(pl.nq);
+    for (u32 k = 0; k < pl.nq; ++k) {
+      gi[k] = sh->q_own[k];
+      pos[k] = k;
+      pinv[k] = hp.pinv_modq[gi[k]];
+      pinvp[k] = hp.pinv_modq_prec[gi[k]];
+    }
+    ConvDesc md{};
+    md.hat = c->phat_modq_t;
+    md.scale = c->phat_inv;
+    md.scale_prec = c->phat_inv_prec;
+    md.src_gi = c->p_gi;
+    md.n_in = hp.K;
+    md.hat_ld = hp.L;
+    md.src_pos0 = 0;
+    md.n_out = pl.nq;
+    md.out_gi = c->up(gi);
+    md.col = md.out_gi;  // column of phat_modq_t = the q index
+    md.out_pos = c->up(pos);
+    std::vector<ConvDesc> one(1, md);
+    pl.d_down = c->up(one);
+    pl.d_pinv = c->up(pinv);
+    pl.d_pinv_prec = c->up(pinvp);
+    if (!pl.d_down || !pl.d_pinv || !pl.d_pinv_prec) return nullptr;
+  }
+  if (level > 1) {  // rescale constants (crt.c:270-326) of the owned limbs below the last one
+    const size_t row = (size_t)(level - 2) * hp.L;
+    std::vector<u64> c1, c1p, inv, invp;
+    for (u32 k = 0; k < pl.nq && sh->q_own[k] < level - 1; ++k) {
+      const u32 i = sh->q_own[k];
+      c1.push_back(hp.qlql[row + i]);
+      c1p.push_back(hp.qlql_prec[row + i]);
+      inv.push_back(hp.ql_inv[row + i]);
+      invp.push_back(hp.ql_inv_prec[row + i]);
+    }
+    pl.nq_rs = (u32)c1.size();
+    if (pl.nq_rs) {
+      pl.d_rs_c1 = c->up(c1);
+      pl.d_rs_c1p = c->up(c1p);
+      pl.d_rs_inv = c->up(inv);
+      pl.d_rs_invp = c->up(invp);
+    }
+  }
+  return &(sh->plans[level] = pl);
+}
+}  // namespace
+
+acehip_shard* acehip_shard_create(acehip_ctx* c, uint32_t rank, uint32_t world) {
+  if (!c) {
+    fail(ACEHIP_EINVAL, "null context");
+    return nullptr;
+  }
+  if (world == 0 || rank >= world) {
+    fail(ACEHIP_EINVAL, "acehip_shard_create: rank outside [0, world)");
+    return nullptr;
+  }
+  const HostParams& hp = c->hp;
+  auto* sh = new acehip_shard();
+  sh->c = c;
+  sh->rank = rank;
+  sh->world = world;
+  std::vector<u32> qg, pg, all;
+  for (u32 i = 0; i < hp.L; ++i)
+    if (i % world == rank) sh->q_own.push_back(i), qg.push_back(i), all.push_back(i);
+  for (u32 j = 0; j < hp.K; ++j)
+    if ((hp.L + j) % world == rank) sh->p_own.push_back(j), pg.push_back(hp.L + j), all.push_back(hp.L + j);
+  if (!c->on_device) return sh;  // host-only context: ownership / exchange-layout queries only, every phase returns ENODEV
+  sh->d_q_gi = c->up(qg);
+  sh->d_p_gi = c->up(pg);
+  sh->d_own_gi_full = c->up(all);
+  const size_t N = hp.N, nown = std::max<size_t>(all.size(), 1);
+  auto dev = [&](size_t limbs) {
+    u64* p = nullptr;
+    if (hipMalloc((void**)&p, std::max<size_t>(limbs, 1) * N * sizeof(u64)) != hipSuccess) return (u64*)nullptr;
+    c->owned.push_back(p);
+    return p;
+  };
+  sh->full = dev(hp.L);
+  sh->ext = dev((size_t)hp.dnum * nown);
+  sh->acc = dev(2 * nown);
+  sh->pfull = dev(2ull * hp.K);
+  sh->conv = dev(2 * nown);
+  sh->tmp = dev(2 * nown);
+  if (!sh->full || !sh->ext || !sh->acc || !sh->pfull || !sh->conv || !sh->tmp) {
+    fail(ACEHIP_EHIP, "acehip_shard_create: device allocation failed");
+    delete sh;
+    return nullptr;
+  }
+  return sh;
+}
+void acehip_shard_destroy(acehip_shard* sh) { delete sh; }  // device memory belongs to the context
+uint32_t acehip_shard_num_q(const acehip_shard* sh, uint32_t level) { return sh ? shard_nq(sh, level) : 0; }
+uint32_t acehip_shard_num_p(const acehip_shard* sh) { return sh ? (u32)sh->p_own.size() : 0; }
+uint32_t acehip_shard_pad_q(const acehip_shard* sh, uint32_t level) { return sh ? shard_pad(sh, level) : 0; }
+uint32_t acehip_shard_pad_p(const acehip_shard* sh) {
+  if (!sh) return 0;
+  u32 m = 0;  // p-limbs start at gi = L: count per rank
+  for (u32 r = 0; r < sh->world; ++r) {
+    u32 n = 0;
+    for (u32 j = 0; j < sh->c->hp.K; ++j) n += (sh->c->hp.L + j) % sh->world == r;
+    m = std::max(m, n);
+  }
+  return m;
+}
+uint32_t acehip_shard_owned(const acehip_shard* sh, uint32_t level, uint32_t* q_out, uint32_t* p_out) {
+  if (!sh) return 0;
+  const u32 nq = shard_nq(sh, level);
+  if (q_out) std::copy(sh->q_own.begin(), sh->q_own.begin() + nq, q_out);
+  if (p_out) std::copy(sh->p_own.begin(), sh->p_own.end(), p_out);
+  return nq;
+}
+
+// phase 1: the owned q-limbs of the key-switch input (NTT domain, packed) to the coefficient domain, written into the
+// send buffer of the first exchange ([pad_q][N]; the caller all-gathers it rank-major)
+int acehip_shard_ks_phase1(acehip_shard* sh, uint64_t* d_send, const uint64_t* d_x_own, uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L || !d_send || !d_x_own) return fail(ACEHIP_EINVAL, "acehip_shard_ks_phase1: bad arguments");
+  const u32 nq = shard_nq(sh, level);
+  ntt_packed(c, d_send, d_x_own, nullptr, sh->d_q_gi, sh->q_own.data(), nq, 1, 0, true, (hipStream_t)s_);
+  stat(ST_NTT, 1, 16ull * c->hp.N * nq);
+  return post_launch();
+}
+
+// phase 2: from the gathered coefficient-domain limbs ([world][pad_q][N], rank-major): ModUp of every digit onto the owned
+// limbs, NTT, key inner product over the owned limbs (d_key_own: [dnum][2][n_own][N], this rank's limbs of the switch
+// key in packed order: owned q-limbs of the full chain, then owned p-limbs), inverse NTT of the owned p-limbs of both
+// accumulators into the send buffer of the second exchange ([2][pad_p][N])
+int acehip_shard_ks_phase2(acehip_shard* sh, uint64_t* d_send2, const uint64_t* d_gath, const uint64_t* d_x_own, const uint64_t* d_key_own,
+                           uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  const HostParams& hp = c->hp;
+  if (level == 0 || level > hp.L || !d_send2 || !d_gath || !d_x_own || !d_key_own) return fail(ACEHIP_EINVAL, "acehip_shard_ks_phase2: bad arguments");
+  if (hp.L > 256 || hp.dnum * (sh->q_own.size() + sh->p_own.size()) > 256) return fail(ACEHIP_EINVAL, "acehip_shard: pointer table too large");
+  const ShardLevelPlan* pl = shard_plan(sh, level);
+  if (!pl) return fail(ACEHIP_EHIP, "acehip_shard: plan upload failed");
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = hp.N;
+  const u32 G = sh->world, pad_q = shard_pad(sh, level), nq = pl->nq, np = (u32)sh->p_own.size(), nown = nq + np;
+  const u32 nq_full = (u32)sh->q_own.size(), nown_full = nq_full + np;
+  // (a) every q-limb in position order: limb i is the (i / G)-th owned limb of rank i % G
+  PtrTab gt{};
+  for (u32 i = 0; i < level; ++i) gt.p[i] = d_gath + ((size_t)(i % G) * pad_q + i / G) * N;
+  launch_packed_gather(c->dc, sh->full, gt, level, s);
+  // (b) ModUp: all digits in one launch onto the owned complement limbs; ext digit d at ext + d*nown_full*N
+  const size_t ext_stride = (size_t)nown_full * N;
+  if (pl->max_tgt) launch_base_conv_batch(c->dc, sh->ext, ext_stride, sh->full, 0, pl->d_up, 1, pl->nd, pl->max_tgt, s, hp.alpha);
+  // (c) NTT of the raised limbs
+  for (u32 d = 0; d < pl->nd; ++d) {
+    std::vector<u32> h_gi(pl->n_tgt[d]);
+    for (u32 k = 0; k < pl->n_tgt[d]; ++k) {
+      const u32 y = pl->tgt_y[d][k];
+      h_gi[k] = y < nq ? sh->q_own[y] : hp.L + sh->p_own[y - nq];
+    }
+    ntt_packed(c, sh->ext + d * ext_stride, nullptr, nullptr, pl->d_tgt_gi[d], h_gi.data(), pl->n_tgt[d], 1, 0, false, s);
+  }
+  // (d) key inner product over the owned limbs; e_d[y] = the input's own limb (y in digit d) or the raised limb
+  PtrTab qt{}, pt{};
+  for (u32 d = 0; d < pl->nd; ++d) {
+    const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
+    std::vector<const u64*> of_y(nown, nullptr);
+    for (u32 k = 0; k < pl->n_tgt[d]; ++k) of_y[pl->tgt_y[d][k]] = sh->ext + d * ext_stride + (size_t)k * N;
+    for (u32 y = 0; y < nq; ++y)
+      if (sh->q_own[y] >= start && sh->q_own[y] < start + n2) of_y[y] = d_x_own + (size_t)y * N;
+    for (u32 y = 0; y < nq; ++y) qt.p[d * nq + y] = of_y[y];
+    for (u32 y = 0; y < np; ++y) pt.p[d * np + y] = of_y[nq + y];
+  }
+  u64 *acc0 = sh->acc, *acc1 = sh->acc + (size_t)nown_full * N;
+  const size_t key_stride = (size_t)nown_full * N;
+  launch_packed_key_mac(c->dc, acc0, acc1, d_key_own, key_stride, qt, sh->d_q_gi, pl->nd, nq, s);
+  launch_packed_key_mac(c->dc, acc0 + (size_t)nq * N, acc1 + (size_t)nq * N, d_key_own + (size_t)nq_full * N, key_stride, pt,
+                        sh->d_p_gi, pl->nd, np, s);
+  // (e) owned p-limbs of both accumulators to the coefficient domain, into the send buffer [2][pad_p][N]
+  const u32 pad_p = acehip_shard_pad_p(sh);
+  std::vector<u32> h_pgi(np);
+  for (u32 k = 0; k < np; ++k) h_pgi[k] = hp.L + sh->p_own[k];
+  ntt_packed(c, d_send2, acc0 + (size_t)nq * N, acc1 + (size_t)nq * N, sh->d_p_gi, h_pgi.data(), np, 2, (size_t)pad_p * N, true, s);
+  stat(ST_KEYMAC, 1, 8ull * N * nown * (3ull * pl->nd + 2));
+  return post_launch();
+}
+
+// phase 3: from the gathered coefficient-domain p-limbs of both accumulators ([world][2][pad_p][N]): conversion P -> owned
+// q-limbs, NTT, out = (acc - conv) * P^-1 on the owned q-limbs (packed)
+int acehip_shard_ks_phase3(acehip_shard* sh, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_gath2, uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  const HostParams& hp = c->hp;
+  if (level == 0 || level > hp.L || !d_out0 || !d_out1 || !d_gath2) return fail(ACEHIP_EINVAL, "acehip_shard_ks_phase3: bad arguments");
+  const ShardLevelPlan* pl = shard_plan(sh, level);
+  if (!pl) return fail(ACEHIP_EHIP, "acehip_shard: plan upload failed");
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = hp.N;
+  const u32 G = sh->world, pad_p = acehip_shard_pad_p(sh), nq = pl->nq, nq_full = (u32)sh->q_own.size(), np = (u32)sh->p_own.size();
+  const u32 nown_full = nq_full + np;
+  if (nq == 0) return 0;
+  // p-limb j of accumulator z: rank (L + j) % G, its k-th owned p-limb
+  PtrTab gt{};
+  for (u32 z = 0; z < 2; ++z)
+    for (u32 j = 0; j < hp.K; ++j) {
+      const u32 r = (hp.L + j) % G;
+      u32 k = 0;
+      for (u32 jj = 0; jj < j; ++jj) k += (hp.L + jj) % G == r;
+      gt.p[z * hp.K + j] = d_gath2 + (((size_t)r * 2 + z) * pad_p + k) * N;
+    }
+  launch_packed_gather(c->dc, sh->pfull, gt, 2 * hp.K, s);
+  // both accumulators: P -> owned q-limbs (problem z reads pfull + z*K*N, writes conv + z*nq_full*N)
+  launch_base_conv_batch(c->dc, sh->conv, (size_t)nq_full * N, sh->pfull, (size_t)hp.K * N, pl->d_down, 0, 2, nq, s, hp.K);
+  ntt_packed(c, sh->conv, nullptr, nullptr, sh->d_q_gi, sh->q_own.data(), nq, 2, (size_t)nq_full * N, false, s);
+  u64 *acc0 = sh->acc, *acc1 = sh->acc + (size_t)nown_full * N;
+  launch_packed_moddown_tail(c->dc, d_out0, d_out1, acc0, acc1, sh->conv, (size_t)nq_full * N, sh->d_q_gi, pl->d_pinv, pl->d_pinv_prec, nq, 2, s);
+  stat(ST_MODDOWN, 2, 8ull * N * (2ull * hp.K + 2ull * nq));
+  return post_launch();
+}
+
+// Rescale (Rescale_poly polynomial.c:1097-1163), exchange = broadcast of the last limb of c0 and c1 in the coefficient
+// domain.  _send: on the rank that owns limb level-1, writes it for both polynomials into d_send ([2][N]) and returns 1;
+// the other ranks return 0 and receive the broadcast.  _apply: every rank, owned limbs below level-1 (packed, in and out).
+int acehip_shard_rescale_send(acehip_shard* sh, uint64_t* d_send, const uint64_t* d_c0_own, const uint64_t* d_c1_own, uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  if (level < 2 || level > c->hp.L || !d_send || !d_c0_own || !d_c1_own) return fail(ACEHIP_EINVAL, "acehip_shard_rescale_send: bad arguments");
+  if ((level - 1) % sh->world != sh->rank) return 0;
+  const size_t N = c->hp.N;
+  const u32 y = shard_nq(sh, level) - 1;  // the last owned limb is limb level-1
+  const u32 gi = level - 1;
+  ntt_packed(c, d_send, d_c0_own + (size_t)y * N, d_c1_own + (size_t)y * N, sh->d_q_gi + y, &gi, 1, 2, N, true, (hipStream_t)s_);
+  if (int e = post_launch()) return e;
+  return 1;
+}
+int acehip_shard_rescale_apply(acehip_shard* sh, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_c0_own, const uint64_t* d_c1_own,
+                               const uint64_t* d_last, uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  if (level < 2 || level > c->hp.L || !d_out0 || !d_out1 || !d_c0_own || !d_c1_own || !d_last) return fail(ACEHIP_EINVAL, "acehip_shard_rescale_apply: bad arguments");
+  const ShardLevelPlan* pl = shard_plan(sh, level);
+  if (!pl) return fail(ACEHIP_EHIP, "acehip_shard: plan upload failed");
+  hipStream_t s = (hipStream_t)s_;
+  const size_t N = c->hp.N;
+  const u32 n = pl->nq_rs, nq_full = (u32)sh->q_own.size();
+  if (n == 0) return 0;
+  u64* t = sh->tmp;  // [2][nq_full][N]
+  launch_packed_rescale_spread(c->dc, t, (size_t)nq_full * N, d_last, N, sh->d_q_gi, level - 1, pl->d_rs_c1, pl->d_rs_c1p, n, 2, s);
+  ntt_packed(c, t, nullptr, nullptr, sh->d_q_gi, sh->q_own.data(), n, 2, (size_t)nq_full * N, false, s);
+  launch_packed_rescale_tail(c->dc, d_out0, d_out1, d_c0_own, d_c1_own, t, (size_t)nq_full * N, sh->d_q_gi, pl->d_rs_inv, pl->d_rs_invp, n, 2, s);
+  stat(ST_RESCALE, 2, 8ull * N * (2ull * n + 1) * 2);
+  return post_launch();
+}
+
+// Encode (SURVEY 8e collective 4): the integer message of a plaintext (rounded, scaled inverse embedding: N signed words) is
+// computed once (acehip_encode_message, any rank) and broadcast; every rank then reduces it into its own limbs and
+// transforms them (acehip_shard_encode_limbs).  Ranks may also each compute the message themselves: no exchange at all.
+int acehip_encode_message(acehip_ctx* c, int64_t* d_msg, const void* d_vals, int kind, size_t len, uint32_t slots, double sf, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  const u32 N = c->hp.N;
+  if (slots == 0) slots = N / 2;
+  if (kind < 0 || kind > 2 || slots > N / 2 || (slots & (slots - 1)) || len > slots || !d_msg || (!d_vals && len))
+    return fail(ACEHIP_EINVAL, "acehip_encode_message: bad arguments");
+  if (int e = ensure_embed_tables(c)) return e;
+  launch_embed_inv(d_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_shard_encode_limbs(acehip_shard* sh, uint64_t* d_q_own, const int64_t* d_msg, double sf, uint32_t sf_degree, uint32_t level, acehip_stream s_) {
+  if (!sh) return fail(ACEHIP_EINVAL, "null shard");
+  acehip_ctx* c = sh->c;
+  if (int e = check_dev(c)) return e;
+  const HostParams& hp = c->hp;
+  if (level == 0 || level > hp.L || sf_degree < 1 || !d_q_own || !d_msg) return fail(ACEHIP_EINVAL, "acehip_shard_encode_limbs: bad arguments");
+  hipStream_t s = (hipStream_t)s_;
+  const u32 nq = shard_nq(sh, level);
+  if (nq == 0) return 0;
+  const size_t N = hp.N;
+  const u64 sfi = (u64)sf;
+  std::vector<u64> w(nq, 1);
+  for (u32 k = 0; k < nq && sf_degree > 1; ++k) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1)
+    const u64 q = hp.primes[sh->q_own[k]].q;
+    u64 pw = sfi % q;
+    for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+    w[k] = pw;
+  }
+  if (c->dc.logN == 16) {
+    NttFuse f;
+    f.gi_tab = sh->d_q_gi;
+    f.msg = d_msg;
+    if (sf_degree > 1) {
+      u64* tab = sh->tmp;  // [nq] words at the head of tmp (stream ordered)
+      HIP_TRY(hipMemcpyAsync(tab, w.data(), nq * sizeof(u64), hipMemcpyHostToDevice, s));
+      f.msg_scale = tab;
+    }
+    launch_ntt_fused(c->dc, d_q_own, 0, 0, nq, false, s, 0, 1, 0, 0, f);
+  } else {
+    for (u32 k = 0; k < nq; ++k) {
+      const u32 gi = sh->q_own[k];
+      u64* ptr = d_q_own + (size_t)k * N;
+      launch_values_to_rns(c->dc, ptr - (size_t)gi * N, d_msg, hp.L, gi, 1, s);
+      if (sf_degree > 1) {
+        LimbConsts lc{};
+        lc.w[0] = w[k];
+        launch_mul_scalars(c->dc, ptr - (size_t)gi * N, ptr - (size_t)gi * N, lc, hp.L, gi, 1, s);
+      }
+      launch_ntt(c->dc, ptr, hp.L, gi, 1, false, s, gi);
+    }
+  }
+  stat(ST_ENCODE, 1, 8ull * N * (nq + 1));
+  return post_launch();
+}
+
+}  // extern "C"

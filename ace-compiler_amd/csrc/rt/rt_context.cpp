@@ -240,7 +240,7 @@ void Prepare_context() {
   for (size_t i = 0; i < m; ++i) {
     const double angle = 2 * M_PI * i / m;
     double sn, cs;
-    sincos(angle, &sn, &cs);  // what gcc emits for the reference's cos()/sin() pair (see csrc/api.cpp)
+    sincos(angle, &sn, &cs);  // what gcc emits for the reference's cos()/sin() pair (see csrc/api_ops.cpp)
     c->fft_rou[i] = cplx(cs, sn);
   }
   c->rot_group.resize(c->N / 2);

@@ -1,5 +1,5 @@
 """Limb-sharded execution (BASELINE configs[4]): harness around the C-ABI phases of include/acehip.h
-(acehip_shard_*).  The arithmetic and every launch live in the library (csrc/api.cpp "Limb-sharded execution",
+(acehip_shard_*).  The arithmetic and every launch live in the library (csrc/api_shard.cpp,
 csrc/shard.hip); this module only moves the exchange buffers:
 
   * `TorchComm`: one process per GPU, torch.distributed all_gather_into_tensor / broadcast on device tensors

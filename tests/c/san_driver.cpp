@@ -1,7 +1,7 @@
 // san_driver.cpp -- host-side logic of libacehip under sanitizers (test infrastructure; CPU only, no GPU needed).
 // Built by `make -C oracle asan` (-fsanitize=address,undefined) and `make -C oracle tsan` (-fsanitize=thread) from the
 // product sources; exercises what runs on the host: parameter/table generation (host_params.cpp), context life cycle,
-// automorphism tables, the ModUp/ModDown constant caches and the batch planner of acehip_hw_batch (api.cpp) -- from one
+// automorphism tables, the ModUp/ModDown constant caches and the batch planner of acehip_hw_batch (api_hw_batch.cpp) -- from one
 // thread and from four threads, on separate contexts and on a shared one (the shim gives every image thread its own
 // context, but the C ABI documents contexts as usable from any thread).
 #include <cstdio>

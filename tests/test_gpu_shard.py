@@ -1,4 +1,4 @@
-"""Limb-sharded execution (BASELINE configs[4]) through the C-ABI phases acehip_shard_* (csrc/api.cpp, shard.hip):
+"""Limb-sharded execution (BASELINE configs[4]) through the C-ABI phases acehip_shard_* (csrc/api_shard.cpp, shard.hip):
 `world` simulated ranks on one GPU, limb gi on rank gi % world, exchanges replaced by device copies
 (ace-compiler_amd/shard.py LocalWorld).  Assembling the ranks' owned output limbs must reproduce the unsharded oracle
 results bit for bit -- key-switch (two all-gathers), rescale (broadcast of the last limb) and encode (broadcast message)

@@ -120,7 +120,7 @@ def test_reference_link_line_with_archives(tmp_path):
     for f in (bmod.RT_ARCHIVE, bmod.RT_OBJS_ARCHIVE, bmod.RT_COMMON_ARCHIVE):
         assert os.path.exists(f), f
     members = subprocess.run(["ar", "t", bmod.RT_OBJS_ARCHIVE], capture_output=True, text=True, check=True).stdout.split()
-    assert "rt_rt_poly_cpp.o" in members and "ntt_fast_hip.o" in members and "api_cpp.o" in members
+    assert "rt_rt_poly_cpp.o" in members and "ntt_fast_hip.o" in members and "api_ops_cpp.o" in members
     inc = os.path.join(ROOT, "include")
     exe = str(tmp_path / "dropin_c1_static")
     subprocess.check_call(["cc", os.path.join(ROOT, "tests", "c", "dropin_c1.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
