@@ -104,7 +104,31 @@ SYMBOLS = [
     ("acehip_shard_rescale_apply", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_encode_message", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _vp]),
     ("acehip_shard_encode_limbs", C.c_int, [_vp, _vp, _vp, C.c_double, _u32, _u32, _vp]),
+    # replicas of the caller's arena (image batches, simulated ranks)
+    ("acehip_ctx_set_arena", C.c_int, [_vp, _vp]),
+    ("acehip_workspace_words", C.c_size_t, [_vp]),
+    ("acehip_ctx_select", C.c_int, [_vp, _u32, _u32]),
+    ("acehip_upload", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    ("acehip_download", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    ("acehip_fill", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
+    ("acehip_copy", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    # limb-sharded execution as a mode of the context
+    ("acehip_ctx_shard_sim", C.c_int, [_vp, _u32]),
+    ("acehip_rccl_unique_id", C.c_int, [_vp, C.c_size_t]),
+    ("acehip_ctx_shard_rccl", C.c_int, [_vp, _u32, _u32, _vp, C.c_size_t]),
+    ("acehip_shard_gather", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    ("acehip_shard_world", _u32, [_vp]),
+    ("acehip_shard_rank", _u32, [_vp]),
+    ("acehip_shard_owned_limbs", _u32, [_vp, _u32]),
+    ("acehip_shard_traffic", _u64, [_vp, _vp, C.c_int]),
+    ("acehip_shard_schedule", C.c_int, [_vp, _u32, C.c_int, _u32, _vp, _vp, _vp, C.c_size_t]),
 ]
+
+
+class ArenaCfg(C.Structure):
+    """acehip_arena_cfg of include/acehip.h"""
+    _fields_ = [("base", C.c_void_p), ("bytes", C.c_size_t), ("stride_bytes", C.c_size_t), ("n_replicas", C.c_uint32),
+                ("workspace", C.c_void_p), ("hw_scratch", C.c_void_p), ("hw_scratch_limbs", C.c_size_t)]
 
 _lib = None
 

@@ -9,6 +9,10 @@ acehip_stat* acehip_stat_slots() {
   static thread_local acehip_stat g[ST_COUNT];
   return g;
 }
+u32& acehip_stat_mult() {
+  static thread_local u32 m = 1;
+  return m;
+}
 static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
                                                 "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed"};
 
@@ -119,7 +123,7 @@ void acehip_ctx_destroy(acehip_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   for (void* p : ctx->owned) (void)hipFree(p);
-  if (ctx->hw_scratch) (void)hipFree(ctx->hw_scratch);
+  if (ctx->hw_scratch && !ctx->scratch_external) (void)hipFree(ctx->hw_scratch);
   delete ctx;
 }
 
@@ -203,6 +207,128 @@ const uint32_t* acehip_auto_order(acehip_ctx* c, uint32_t k) {
   c->auto_tabs[k] = d;
   c->auto_tab_k[d] = k;
   return d;
+}
+
+// ---- replicas of the caller's arena ----
+size_t acehip_workspace_words(const acehip_ctx* c) { return c ? c->ws_words : 0; }
+
+int acehip_ctx_set_arena(acehip_ctx* c, const acehip_arena_cfg* cfg) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if (c->sh_world > 1 && c->rccl == nullptr) return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: the arena cannot change while simulated ranks occupy its replicas");
+  if (cfg == nullptr || cfg->base == nullptr) {
+    if (c->ws_external || c->scratch_external) return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: the workspace lives in the arena that is being removed");
+    c->dc.rep_lo = c->dc.rep_span = c->dc.rep_stride = 0;
+    c->n_replicas = 1;
+    c->sel0 = 0;
+    c->seln = 1;
+    return ACEHIP_OK;
+  }
+  const u64 lo = (u64)cfg->base, span = cfg->bytes;
+  auto inside = [&](const void* p, size_t bytes) { return (u64)p >= lo && (u64)p + bytes <= lo + span; };
+  if (cfg->n_replicas == 0 || cfg->bytes == 0 || (cfg->n_replicas > 1 && cfg->stride_bytes < cfg->bytes) || (cfg->stride_bytes & 15))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: bad geometry");
+  if (cfg->n_replicas > 1 && (cfg->workspace == nullptr || cfg->hw_scratch == nullptr))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: several replicas need a workspace and a hw scratch of their own inside the arena");
+  if (cfg->workspace && !inside(cfg->workspace, c->ws_words * sizeof(u64)))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: the workspace must lie inside replica 0 (acehip_workspace_words() words)");
+  if (cfg->hw_scratch && (cfg->hw_scratch_limbs == 0 || !inside(cfg->hw_scratch, cfg->hw_scratch_limbs * c->hp.N * sizeof(u64))))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_set_arena: the hw scratch must lie inside replica 0");
+  if (c->on_device) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();  // launches that still use the old workspace / scratch
+  }
+  if (cfg->workspace) {
+    if (!c->ws_external && c->ws) {
+      c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), (void*)c->ws), c->owned.end());
+      (void)hipFree(c->ws);
+    }
+    c->ws = (u64*)cfg->workspace;
+    c->ws_external = true;
+  }
+  if (cfg->hw_scratch) {
+    if (!c->scratch_external && c->hw_scratch) (void)hipFree(c->hw_scratch);
+    c->hw_scratch = (u64*)cfg->hw_scratch;
+    c->hw_scratch_limbs = cfg->hw_scratch_limbs;
+    c->scratch_external = true;
+  }
+  c->dc.rep_lo = lo;
+  c->dc.rep_span = span;
+  c->dc.rep_stride = cfg->n_replicas > 1 ? cfg->stride_bytes : 0;
+  c->n_replicas = cfg->n_replicas;
+  c->sel0 = 0;
+  c->seln = 1;
+  return ACEHIP_OK;
+}
+
+int acehip_ctx_select(acehip_ctx* c, uint32_t rep0, uint32_t nrep) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if (nrep == 0 || rep0 + nrep > c->n_replicas) return fail(ACEHIP_EINVAL, "acehip_ctx_select: replicas outside the arena");
+  if (c->sh_world > 1 && c->rccl == nullptr && (rep0 != 0 || nrep != 1))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_select: simulated ranks occupy the replicas");
+  c->sel0 = rep0;
+  c->seln = nrep;
+  return ACEHIP_OK;
+}
+
+}  // extern "C"
+namespace {
+// every (replica, in-arena?) instance of a device address the current selection covers
+template <class F>
+int for_each_instance(acehip_ctx* c, const void* d_ptr, bool all, F f) {
+  const u64 a = (u64)d_ptr;
+  const bool in_arena = a - c->dc.rep_lo < c->dc.rep_span;
+  if (!in_arena || c->dc.rep_stride == 0) return f((void*)a);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs)
+    for (u32 r = dc.rep0; r < dc.rep0 + dc.nrep; ++r) {
+      if (int e = f((void*)(a + (u64)r * c->dc.rep_stride))) return e;
+      if (!all) return ACEHIP_OK;
+    }
+  return ACEHIP_OK;
+}
+}  // namespace
+extern "C" {
+
+int acehip_upload(acehip_ctx* c, void* d, const void* h, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (int e = for_each_instance(c, d, true, [&](void* p) -> int {
+        HIP_TRY(hipMemcpyAsync(p, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+        return ACEHIP_OK;
+      }))
+    return e;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_download(acehip_ctx* c, void* h, const void* d, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (int e = for_each_instance(c, d, false, [&](void* p) -> int {
+        HIP_TRY(hipMemcpyAsync(h, p, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+        return ACEHIP_OK;
+      }))
+    return e;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return ACEHIP_OK;
+}
+int acehip_fill(acehip_ctx* c, void* d, int v, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  return for_each_instance(c, d, true, [&](void* p) -> int {
+    HIP_TRY(hipMemsetAsync(p, v, n, (hipStream_t)s));
+    return ACEHIP_OK;
+  });
+}
+int acehip_copy(acehip_ctx* c, void* d, const void* src, size_t n, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  const u64 a = (u64)src, d0 = (u64)d;
+  const bool rep_on = c->dc.rep_stride != 0;
+  const bool src_in = rep_on && a - c->dc.rep_lo < c->dc.rep_span, dst_in = rep_on && d0 - c->dc.rep_lo < c->dc.rep_span;
+  const u64 first = (u64)launch_dcs(c).d[0].rep0 * c->dc.rep_stride;
+  return for_each_instance(c, d, true, [&](void* p) -> int {
+    // replica r's copy reads replica r's instance of the source when that lies in the arena too; a destination outside the
+    // arena gets the first selected replica's source
+    const u64 from = !src_in ? a : dst_in ? a + ((u64)p - d0) : a + first;
+    HIP_TRY(hipMemcpyAsync(p, (const void*)from, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return ACEHIP_OK;
+  });
 }
 
 // ---- memory helpers ----
@@ -293,6 +419,7 @@ int check_dev(acehip_ctx* c) {
   if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
     if (hipSetDevice(c->device) != hipSuccess) return fail(ACEHIP_EHIP, "hipSetDevice failed");
   }
+  acehip_stat_mult() = c->seln;
   return ACEHIP_OK;
 }
 int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n) {
@@ -305,6 +432,45 @@ int post_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ACEHIP_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return ACEHIP_OK;
+}
+
+// ---- replicas / limb ownership ----
+DcList launch_dcs(const acehip_ctx* c) {
+  DcList l;
+  DevCtx d = c->dc;
+  d.sh_world = c->sh_world;
+  if (c->sh_world > 1 && c->rccl == nullptr) {  // simulated ranks: one launch set per hosted rank, replica h
+    for (u32 h = 0; h < c->sh_hosted.size() && h < 16; ++h) {
+      d.rep0 = h;
+      d.nrep = 1;
+      d.sh_rank = c->sh_hosted[h];
+      l.d[l.n++] = d;
+    }
+    return l;
+  }
+  d.rep0 = c->sel0;
+  d.nrep = c->seln;
+  d.sh_rank = c->sh_world > 1 ? c->sh_hosted[0] : 0;
+  l.d[l.n++] = d;
+  return l;
+}
+
+void copy_limbs_dc(const DevCtx& dc, u64* dst, const u64* src, u32 n_limbs, u32 gi0, hipStream_t s) {
+  HwBatchArgs cp;
+  u32 n = 0;
+  auto flush = [&] {
+    if (n == 0) return;
+    cp.seg_start[n] = (uint16_t)n;
+    launch_hw_batch_ew(dc, cp, n, s);
+    n = 0;
+  };
+  for (u32 i = 0; i < n_limbs; ++i) {
+    if (!dc_owns(dc, gi0 + i)) continue;
+    if (n == HW_BATCH_MAX) flush();
+    cp.seg_start[n] = (uint16_t)n;
+    cp.op[n++] = HwBatchOp{dst + (size_t)i * dc.N, src + (size_t)i * dc.N, nullptr, HW_OP_COPY, 0};
+  }
+  flush();
 }
 
 const DevModUp* get_modup(acehip_ctx* c, u32 level, u32 digit) {

@@ -77,6 +77,8 @@ struct HwPlanSink {
   u64 scratch_base;
 };
 static thread_local HwPlanSink* g_plan = nullptr;
+// the launch set the list is being issued for (replicas of the arena, or one simulated rank): hw_batch_run
+static thread_local const DevCtx* g_dc = nullptr;
 static void plan_append(const HwBatchOp& o, u32 seg) {
   HwPlanSink& p = *g_plan;
   if (p.n < p.cap) {
@@ -188,7 +190,7 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg) {
 static void emit_ew(acehip_ctx* c, const HwBatchArgs& args, u32 n_seg, hipStream_t st) {
   if (hw_traffic_on()) hw_traffic_count(args, n_seg);
   if (!g_plan) {
-    launch_hw_batch_ew(c->dc, args, n_seg, st);
+    launch_hw_batch_ew(*g_dc, args, n_seg, st);
     return;
   }
   for (u32 sgm = 0; sgm < n_seg; ++sgm)
@@ -197,7 +199,7 @@ static void emit_ew(acehip_ctx* c, const HwBatchArgs& args, u32 n_seg, hipStream
 }
 static void emit_rotate(acehip_ctx* c, const HwBatchArgs& args, u32 n_ops, hipStream_t st) {
   if (!g_plan) {
-    launch_hw_batch_rotate(c->dc, args, n_ops, st);
+    launch_hw_batch_rotate(*g_dc, args, n_ops, st);
     return;
   }
   if (n_ops == 0) return;
@@ -245,6 +247,7 @@ void hw_issue_one(acehip_ctx* c, const acehip_hw_op& o, hipStream_t st) {
 static u64* hw_scratch(acehip_ctx* c, size_t limbs) {
   if (g_plan) return (u64*)g_plan->scratch_base;  // recording: addresses only
   if (limbs <= c->hw_scratch_limbs) return c->hw_scratch;
+  if (c->scratch_external) return nullptr;  // the caller's block inside its arena: fixed size (the analysis stays within it)
   size_t want = std::max<size_t>(256, c->hw_scratch_limbs);
   while (want < limbs) want *= 2;
   (void)hipDeviceSynchronize();  // launches that still use the old arena
@@ -408,6 +411,7 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
   if (live == 0) return;
   // forwards: give intermediate versions private scratch limbs
   size_t n_scratch = 0;
+  const size_t scratch_cap = c->scratch_external ? std::min(c->hw_scratch_limbs, kHwScratchMaxLimbs) : kHwScratchMaxLimbs;
   if (rename_useful) {
     h.cur.resize(n_base);
     for (u32 i = 0; i < n_base; ++i) h.cur[i] = i;
@@ -420,7 +424,7 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
       if (hw_has_a(op)) h.state[h.n_a[k]] = 1;
       if (hw_has_b(op)) h.state[h.n_b[k]] = 1;
       if (pure) {
-        if (h.last_pure[nr0] != k && h.state[nr0] && n_scratch < kHwScratchMaxLimbs) {
+        if (h.last_pure[nr0] != k && h.state[nr0] && n_scratch < scratch_cap) {
           h.cur[nr0] = (u32)h.parent.size();
           h.parent.push_back(h.cur[nr0]);
           h.node_ptr.push_back(n_scratch++);  // index into the scratch arena, resolved below
@@ -598,8 +602,30 @@ void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t
 }
 }  // namespace
 
+static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st, const acehip_hw_range* dead, size_t n_dead);
+// Limb-sharded execution: every rank gets the list (SPMD) and runs the ops on the limbs it owns -- prime_gi names the limb
+// of every op (ACEHIP_HW_ANY_RANK: an op on memory that is not a limb of the chain, run by everyone).
 static int hw_batch_run(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st, const acehip_hw_range* dead = nullptr,
                         size_t n_dead = 0) {
+  const DcList dcs = launch_dcs(c);
+  int rc = ACEHIP_OK;
+  static thread_local std::vector<acehip_hw_op> mine;
+  for (const DevCtx& dc : dcs) {
+    g_dc = &dc;
+    if (dc.sh_world > 1) {
+      mine.clear();
+      for (size_t k = 0; k < n; ++k)
+        if (ops[k].prime_gi == ACEHIP_HW_ANY_RANK || ops[k].prime_gi % dc.sh_world == dc.sh_rank) mine.push_back(ops[k]);
+      rc = hw_batch_run_one(c, mine.data(), mine.size(), st, dead, n_dead);
+    } else {
+      rc = hw_batch_run_one(c, ops, n, st, dead, n_dead);
+    }
+    if (rc) break;
+  }
+  g_dc = nullptr;
+  return rc;
+}
+static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st, const acehip_hw_range* dead, size_t n_dead) {
   if (n == 0) return ACEHIP_OK;
   if (!ops) return fail(ACEHIP_EINVAL, "acehip_hw_batch: null op list");
   if (n_dead && !dead) return fail(ACEHIP_EINVAL, "acehip_hw_batch_discard: null range list");

@@ -89,6 +89,17 @@ struct acehip_ctx {
   int64_t* emb_msg = nullptr;
   int* emb_err = nullptr;
   std::map<std::pair<u64, u32>, u64*> enc_scales;  // (Delta, sf_degree) -> [L] Delta^(sf_degree-1) mod q_i
+  // ---- replicas of the caller's polynomial arena (acehip_ctx_set_arena): image batches, simulated ranks.  dc.rep_lo / rep_span /
+  // rep_stride describe the arena; launches cover replicas [sel0, sel0 + seln) (acehip_ctx_select)
+  u32 n_replicas = 1, sel0 = 0, seln = 1;
+  bool ws_external = false, scratch_external = false;  // workspace / hw scratch handed in by the caller (inside the arena)
+  // ---- limb-sharded execution (api_shard.cpp): world ranks, limb gi belongs to rank gi % world.  hosted[h] = rank whose limbs
+  // live in replica h of the arena: every rank of a simulation (ACEHIP_SHARD_SIM: exchanges are copies between replicas), or
+  // the one rank of this process (exchanges are RCCL broadcasts from the owner)
+  u32 sh_world = 1;
+  std::vector<u32> sh_hosted;
+  void* rccl = nullptr;            // RcclComm* (api_shard.cpp) when the ranks are processes
+  u64 xchg_bytes = 0, xchg_calls = 0;  // bytes this process received through exchanges / exchange steps
 
   template <typename T>
   T* up(const std::vector<T>& v) {
@@ -101,11 +112,13 @@ struct acehip_ctx {
 // ---- call statistics: algorithmic bytes of SURVEY 8(d) per entry point (tables and scratch excluded) ----
 enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_COUNT };
 acehip_stat* acehip_stat_slots();  // this thread's counters [ST_COUNT] (one host thread = one image stream)
+u32& acehip_stat_mult();  // replicas the current call covers (set by check_dev): an op on B images counts B times
 inline void stat(int k, u64 units, u64 bytes) {
   acehip_stat* g = acehip_stat_slots();
+  const u32 m = acehip_stat_mult();
   g[k].calls++;
-  g[k].units += units;
-  g[k].bytes += bytes;
+  g[k].units += units * m;
+  g[k].bytes += bytes * m;
 }
 
 // ---- argument checks shared by the launch entry points ----
@@ -118,3 +131,26 @@ bool conv_fusable(const acehip_ctx* c, u32 n_in);
 // workspace carving (in limbs of N words)
 inline u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
 int ensure_embed_tables(acehip_ctx* c);
+
+// ---- replicas / limb ownership ----
+// The launch sets one call has to issue: ONE DevCtx covering the selected replicas, or -- simulated limb-sharded execution --
+// one per hosted rank (replica h, owner filter hosted[h]).
+struct DcList {
+  DevCtx d[16];
+  u32 n = 0;
+  const DevCtx* begin() const { return d; }
+  const DevCtx* end() const { return d + n; }
+};
+DcList launch_dcs(const acehip_ctx* c);
+inline bool sharded(const acehip_ctx* c) { return c->sh_world > 1; }
+inline bool dc_owns(const DevCtx& dc, u32 gi) { return dc.sh_world <= 1 || gi % dc.sh_world == dc.sh_rank; }
+// dst limb i = src limb i for i < n_limbs, limb i having prime gi0 + i (only the limbs the DevCtx owns; every replica it covers):
+// the d2d copies of the pipelines
+void copy_limbs_dc(const DevCtx& dc, u64* dst, const u64* src, u32 n_limbs, u32 gi0, hipStream_t s);
+// Limbs that are valid on their owner only become valid on every rank (no-op when not sharded).  Addresses as the caller sees
+// them (replica 0 of the arena / shared memory); root = owning rank.
+struct XItem {
+  u64* ptr;
+  u32 root;
+};
+int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s);

@@ -9,7 +9,7 @@
 // tests/test_gpu_parity.py::test_conv_fusion_matches).
 bool conv_fusable(const acehip_ctx* c, u32 n_in) {
   static const bool on = [] { const char* e = getenv("ACEHIP_CONV_FUSION"); return e && *e == '1'; }();
-  return on && c->dc.logN == 16 && c->dc.split_bits <= 30 && n_in <= 12;
+  return on && c->dc.logN == 16 && c->dc.split_bits <= 30 && n_in <= 12 && c->sh_world <= 1;
 }
 
 static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s);
@@ -19,32 +19,52 @@ static int do_decomp_modup(acehip_ctx* c, u64* out, const u64* in, u32 level, u3
   const DevModUp* t = get_modup(c, level, digit);
   if (!t) return fail(ACEHIP_EHIP, "ModUp table upload failed");
   const size_t N = hp.N;
-  // digit limbs pass through unchanged (polynomial.c:1265-1273)
-  HIP_TRY(hipMemcpyAsync(out + t->start * N, in + t->start * N, t->n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  // iNTT of the digit limbs in scratch, scaled by (Q_d/q_i)^-1 mod q_i (polynomial.c:1276-1301)
-  HIP_TRY(hipMemcpyAsync(scratch, in + t->start * N, t->n2 * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  // scratch limb i has prime start+i: run the iNTT as "positions [start, start+n2) of a level-L poly"
-  launch_ntt(c->dc, scratch, hp.L, t->start, t->n2, true, s, t->start);
-  launch_mul_const(c->dc, scratch, scratch, t->hat_inv, t->hat_inv_prec, t->src_gi, t->n2, s);
-  // exact 128-bit sums + reduction into the complement limbs (polynomial.c:1302-1320)
-  launch_base_conv(c->dc, out, scratch, t->hat_mod, t->out_gi, t->out_pos, t->n2, t->nc, t->nc, s);
-  // NTT of the complement limbs (polynomial.c:1322-1329)
-  launch_ntt(c->dc, out, level, 0, t->start, false, s);
-  launch_ntt(c->dc, out, level, t->start + t->n2, level + hp.K - (t->start + t->n2), false, s);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {
+    // digit limbs pass through unchanged (polynomial.c:1265-1273)
+    copy_limbs_dc(dc, out + t->start * N, in + t->start * N, t->n2, t->start, s);
+    // iNTT of the digit limbs in scratch, scaled by (Q_d/q_i)^-1 mod q_i (polynomial.c:1276-1301)
+    copy_limbs_dc(dc, scratch, in + t->start * N, t->n2, t->start, s);
+    // scratch limb i has prime start+i: run the iNTT as "positions [start, start+n2) of a level-L poly"
+    launch_ntt(dc, scratch, hp.L, t->start, t->n2, true, s, t->start);
+    launch_mul_const(dc, scratch, scratch, t->hat_inv, t->hat_inv_prec, t->src_gi, t->n2, s);
+  }
+  if (sharded(c)) {  // the conversion needs every source limb of the digit: each comes from its owner
+    std::vector<XItem> x;
+    for (u32 i = 0; i < t->n2; ++i) x.push_back(XItem{scratch + (size_t)i * N, (t->start + i) % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+  }
+  for (const DevCtx& dc : dcs) {
+    // exact 128-bit sums + reduction into the complement limbs (polynomial.c:1302-1320)
+    launch_base_conv(dc, out, scratch, t->hat_mod, t->out_gi, t->out_pos, t->n2, t->nc, t->nc, s);
+    // NTT of the complement limbs (polynomial.c:1322-1329)
+    launch_ntt(dc, out, level, 0, t->start, false, s);
+    launch_ntt(dc, out, level, t->start + t->n2, level + hp.K - (t->start + t->n2), false, s);
+  }
   return post_launch();
 }
 
 static int do_mod_down(acehip_ctx* c, u64* out, const u64* in, u32 level, u64* scratch, hipStream_t s) {
   const HostParams& hp = c->hp;
   const size_t N = hp.N;
-  // P part -> coefficient domain, times (P/p_j)^-1 mod p_j  (polynomial.c:941-945, 779-790)
-  HIP_TRY(hipMemcpyAsync(scratch, in + level * N, hp.K * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-  launch_ntt(c->dc, scratch, 0, 0, hp.K, true, s);  // level 0: position j -> prime p_j
-  launch_mul_const(c->dc, scratch, scratch, c->phat_inv, c->phat_inv_prec, c->p_gi, hp.K, s);
-  // conv P -> Q (polynomial.c:791-803); phat_modq_t is [K][L]: use its first `level` columns via n_out = L stride
-  launch_base_conv(c->dc, out, scratch, c->phat_modq_t, c->q_gi, c->q_pos, hp.K, level, hp.L, s);
-  launch_ntt(c->dc, out, level, 0, level, false, s);
-  launch_moddown_tail(c->dc, out, in, c->pinv, c->pinv_prec, level, s);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {
+    // P part -> coefficient domain, times (P/p_j)^-1 mod p_j  (polynomial.c:941-945, 779-790)
+    copy_limbs_dc(dc, scratch, in + level * N, hp.K, hp.L, s);
+    launch_ntt(dc, scratch, 0, 0, hp.K, true, s);  // level 0: position j -> prime p_j
+    launch_mul_const(dc, scratch, scratch, c->phat_inv, c->phat_inv_prec, c->p_gi, hp.K, s);
+  }
+  if (sharded(c)) {
+    std::vector<XItem> x;
+    for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{scratch + (size_t)j * N, (hp.L + j) % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+  }
+  for (const DevCtx& dc : dcs) {
+    // conv P -> Q (polynomial.c:791-803); phat_modq_t is [K][L]: use its first `level` columns via n_out = L stride
+    launch_base_conv(dc, out, scratch, c->phat_modq_t, c->q_gi, c->q_pos, hp.K, level, hp.L, s);
+    launch_ntt(dc, out, level, 0, level, false, s);
+    launch_moddown_tail(dc, out, in, c->pinv, c->pinv_prec, level, s);
+  }
   return post_launch();
 }
 
@@ -52,13 +72,13 @@ extern "C" {
 
 int acehip_ntt_forward(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  launch_ntt(c->dc, d, level, pos0, n, false, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, false, (hipStream_t)s);
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
 int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  launch_ntt(c->dc, d, level, pos0, n, true, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, true, (hipStream_t)s);
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
@@ -68,7 +88,7 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
   if (int e = check_range(c, level, pos0, n)) return e;
   if (n_polys == 0) return ACEHIP_OK;
   if (n_polys > 65535) return fail(ACEHIP_EINVAL, "acehip_ntt_batch: at most 65535 polynomials per launch");
-  launch_ntt(c->dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
   stat(ST_NTT, (u64)n * n_polys, 16ull * c->hp.N * n * n_polys);
   return post_launch();
 }
@@ -76,7 +96,7 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
 static int ew(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n, acehip_stream s) {
   if (c) stat(ST_EW, n, (op == EwOp::MulAdd ? 32ull : 24ull) * c->hp.N * n);
   if (int e = check_range(c, level, pos0, n)) return e;
-  launch_ew(c->dc, op, r, a, b, level, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_ew(dc, op, r, a, b, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
 int acehip_modadd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) { return ew(c, EwOp::Add, r, a, b, level, pos0, n, s); }
@@ -87,7 +107,7 @@ int acehip_modmuladd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64
 int acehip_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32_t* perm, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
   if (r == a) return fail(ACEHIP_EINVAL, "acehip_rotate: in-place rotation is not supported");
-  launch_rotate(c->dc, r, a, perm, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_rotate(dc, r, a, perm, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
 
@@ -98,7 +118,7 @@ int acehip_rotate_add2(acehip_ctx* c, uint64_t* r0, uint64_t* r1, const uint64_t
   if (auto_k % 2 == 0 || auto_k >= 2 * c->hp.N) return fail(ACEHIP_EINVAL, "acehip_rotate_add2: automorphism index must be odd and below 2N");
   if (r0 == a0 || r0 == a1 || (r1 && (r1 == a0 || r1 == a1)))
     return fail(ACEHIP_EINVAL, "acehip_rotate_add2: the rotated operand must not alias a result");
-  launch_rotate_add2(c->dc, r0, r1, acc0, acc1, a0, a1, auto_k, level, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_rotate_add2(dc, r0, r1, acc0, acc1, a0, a1, auto_k, level, pos0, n, (hipStream_t)s);
   stat(ST_ROTATE, (r1 ? 2u : 1u) * n, (r1 ? 2ull : 1ull) * n * 24ull * c->hp.N);
   return post_launch();
 }
@@ -108,8 +128,10 @@ static int hw(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 gi
   if (int e = check_dev(c)) return e;
   const u32 L = c->hp.L;
   if (gi >= L + c->hp.K) return fail(ACEHIP_EINVAL, "prime index out of range");
-  if (gi < L) launch_ew(c->dc, op, r, a, b, L, gi, 1, (hipStream_t)s, gi);
-  else launch_ew(c->dc, op, r, a, b, 0, gi - L, 1, (hipStream_t)s, gi - L);
+  for (const DevCtx& dc : launch_dcs(c)) {
+    if (gi < L) launch_ew(dc, op, r, a, b, L, gi, 1, (hipStream_t)s, gi);
+    else launch_ew(dc, op, r, a, b, 0, gi - L, 1, (hipStream_t)s, gi - L);
+  }
   return post_launch();
 }
 int acehip_hw_modadd(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* b, uint32_t gi, acehip_stream s) { return hw(c, EwOp::Add, r, a, b, gi, s); }
@@ -118,7 +140,11 @@ int acehip_hw_rotate(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint32
   if (int e = check_dev(c)) return e;
   if (gi >= c->hp.L + c->hp.K) return fail(ACEHIP_EINVAL, "prime index out of range");
   if (r == a) return fail(ACEHIP_EINVAL, "acehip_hw_rotate: in-place rotation is not supported");
-  launch_rotate(c->dc, r, a, perm, 0, 1, (hipStream_t)s);
+  for (DevCtx dc : launch_dcs(c)) {  // the limb pointers are used directly: ownership is decided here, by the prime index
+    if (!dc_owns(dc, gi)) continue;
+    dc.sh_world = 1;
+    launch_rotate(dc, r, a, perm, 0, 0, 1, (hipStream_t)s);
+  }
   return post_launch();
 }
 
@@ -149,41 +175,52 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
   const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N;
   u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
   u64* tmp = pc + 2 * PK;     // [2][level][N]
-  if (c->dc.logN == 16) {
-    NttFuse fi;
-    fi.src0 = in0 + QL;
-    fi.src1 = in1 ? in1 + QL : nullptr;
-    fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
-    launch_ntt_fused(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
-  } else {
-    HIP_TRY(hipMemcpyAsync(pc, in0 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    if (in1) HIP_TRY(hipMemcpyAsync(pc + PK, in1 + QL, PK * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    launch_ntt(c->dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
-  }
-  // the ModDown descriptor reads source limbs at positions level.. : hand it a base `level` limbs below pc
-  const bool conv_in_ntt = conv_fusable(c, hp.K);
-  if (!conv_in_ntt) launch_base_conv_batch(c->dc, tmp, QL, pc - QL, PK, plan->d_descs + plan->nd, 0, np, level, s, hp.K);
-  if (c->dc.logN == 16) {
-    NttFuse fo;
-    if (conv_in_ntt) {  // the conversion P -> Q rides in the first pass of the NTT
-      fo.conv = plan->d_descs + plan->nd;
-      fo.conv_step = 0;
-      fo.conv_max_in = hp.K;
-      fo.conv_src = pc - QL;
-      fo.conv_src_stride = PK;
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {
+    if (dc.logN == 16) {
+      NttFuse fi;
+      fi.src0 = in0 + QL;
+      fi.src1 = in1 ? in1 + QL : nullptr;
+      fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
+      launch_ntt_fused(dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
+    } else {
+      copy_limbs_dc(dc, pc, in0 + QL, hp.K, hp.L, s);
+      if (in1) copy_limbs_dc(dc, pc + PK, in1 + QL, hp.K, hp.L, s);
+      launch_ntt(dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
     }
-    fo.epi = 2;
-    fo.out0 = out0;
-    fo.out1 = out1;
-    fo.x0 = in0;
-    fo.x1 = in1;
-    fo.w = c->pinv;
-    fo.wp = c->pinv_prec;
-    launch_ntt_fused(c->dc, tmp, level, 0, level, false, s, 0, np, QL, 0, fo);
-  } else {
-    launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, np, QL);
-    launch_moddown_tail2(c->dc, out0, out1 ? out1 : out0, in0, in1 ? in1 : in0, tmp, tmp + (in1 ? QL : 0), c->pinv, c->pinv_prec,
-                         level, s, np);
+  }
+  if (sharded(c)) {  // the conversion P -> Q needs every P-limb: each comes from its owner (SURVEY 8e collective 2)
+    std::vector<XItem> x;
+    for (u32 z = 0; z < np; ++z)
+      for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{pc + z * PK + (size_t)j * N, (hp.L + j) % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+  }
+  // (descriptor nd + 1: the ModDown problem with its K sources at limb positions 0.. of `pc`)
+  const bool conv_in_ntt = conv_fusable(c, hp.K);
+  for (const DevCtx& dc : dcs) {
+    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, QL, pc, PK, plan->d_descs + plan->nd + 1, 0, np, level, s, hp.K);
+    if (dc.logN == 16) {
+      NttFuse fo;
+      if (conv_in_ntt) {  // the conversion P -> Q rides in the first pass of the NTT
+        fo.conv = plan->d_descs + plan->nd + 1;
+        fo.conv_step = 0;
+        fo.conv_max_in = hp.K;
+        fo.conv_src = pc;
+        fo.conv_src_stride = PK;
+      }
+      fo.epi = 2;
+      fo.out0 = out0;
+      fo.out1 = out1;
+      fo.x0 = in0;
+      fo.x1 = in1;
+      fo.w = c->pinv;
+      fo.wp = c->pinv_prec;
+      launch_ntt_fused(dc, tmp, level, 0, level, false, s, 0, np, QL, 0, fo);
+    } else {
+      launch_ntt(dc, tmp, level, 0, level, false, s, 0, np, QL);
+      launch_moddown_tail2(dc, out0, out1 ? out1 : out0, in0, in1 ? in1 : in0, tmp, tmp + (in1 ? QL : 0), c->pinv, c->pinv_prec,
+                           level, s, np);
+    }
   }
   stat(ST_MODDOWN, np, 8ull * np * N * (2 * level + hp.K));
   return post_launch();
@@ -209,24 +246,38 @@ int acehip_mod_raise(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64
   const size_t N = hp.N;
   const u32 np = in1 ? 2 : 1;
   u64* last = ws_at(c, 0);  // [np][N]
-  if (c->dc.logN == 16) {
-    NttFuse fi;
-    fi.src0 = in0;
-    fi.src1 = in1;
-    fi.center_out = true;
-    launch_ntt_fused(c->dc, last, hp.L, 0, 1, true, s, 0, np, N, 0, fi);
-    NttFuse fo;
-    fo.msg = (const int64_t*)last;
-    fo.msg_stride = N;
-    launch_ntt_fused(c->dc, out0, level_out, 0, level_out, false, s, 0, np, (size_t)(out1 - out0), 0, fo);
-  } else {
-    for (u32 z = 0; z < np; ++z) {
-      HIP_TRY(hipMemcpyAsync(last + z * N, z ? in1 : in0, N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-      launch_ntt(c->dc, last + z * N, hp.L, 0, 1, true, s);
-      launch_center(c->dc, (int64_t*)(last + z * N), last + z * N, 0, s);
-      u64* out = z ? out1 : out0;
-      launch_values_to_rns(c->dc, out, (const int64_t*)(last + z * N), level_out, 0, level_out, s);
-      launch_ntt(c->dc, out, level_out, 0, level_out, false, s);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {  // limb 0 (its owner only) -> coefficient domain, centred lift
+    if (dc.logN == 16) {
+      NttFuse fi;
+      fi.src0 = in0;
+      fi.src1 = in1;
+      fi.center_out = true;
+      launch_ntt_fused(dc, last, hp.L, 0, 1, true, s, 0, np, N, 0, fi);
+    } else {
+      for (u32 z = 0; z < np; ++z) {
+        copy_limbs_dc(dc, last + z * N, z ? in1 : in0, 1, 0, s);
+        launch_ntt(dc, last + z * N, hp.L, 0, 1, true, s);
+        launch_center(dc, (int64_t*)(last + z * N), last + z * N, 0, s);
+      }
+    }
+  }
+  if (sharded(c)) {
+    XItem x[2] = {{last, 0}, {last + N, 0}};
+    if (int e = shard_exchange(c, x, np, s)) return e;
+  }
+  for (const DevCtx& dc : dcs) {
+    if (dc.logN == 16) {
+      NttFuse fo;
+      fo.msg = (const int64_t*)last;
+      fo.msg_stride = N;
+      launch_ntt_fused(dc, out0, level_out, 0, level_out, false, s, 0, np, (size_t)(out1 - out0), 0, fo);
+    } else {
+      for (u32 z = 0; z < np; ++z) {
+        u64* out = z ? out1 : out0;
+        launch_values_to_rns(dc, out, (const int64_t*)(last + z * N), level_out, 0, level_out, s);
+        launch_ntt(dc, out, level_out, 0, level_out, false, s);
+      }
     }
   }
   stat(ST_RESCALE, np, 8ull * N * (1 + level_out) * np);
@@ -297,7 +348,10 @@ int acehip_base_conv(acehip_ctx* c, uint64_t* d_out, const uint64_t* d_in, uint3
   cd.n_out = n_out;
   HIP_TRY(hipMemcpy(d_desc, &cd, sizeof(ConvDesc), hipMemcpyHostToDevice));
   hipStream_t s = (hipStream_t)s_;
-  launch_base_conv_batch(c->dc, d_out, 0, d_in, 0, d_desc, 0, 1, n_out, s, cd.n_in);
+  for (DevCtx dc : launch_dcs(c)) {
+    dc.sh_world = 1;  // (the caller names the outputs it wants)
+    launch_base_conv_batch(dc, d_out, 0, d_in, 0, d_desc, 0, 1, n_out, s, cd.n_in);
+  }
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(d_blob);
   (void)hipFree(d_desc);
@@ -312,40 +366,46 @@ static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const
   u64* last = ws_at(c, 0);   // [np][N]
   u64* t = ws_at(c, 2);      // [np][level-1][N]
   const size_t t_stride = (size_t)(level - 1) * N;
-  HwBatchArgs cp;            // the last limbs into scratch, one launch
-  for (u32 z = 0; z < np; ++z) {
-    cp.op[z] = HwBatchOp{last + z * N, (z ? in1 : in0) + (size_t)(level - 1) * N, nullptr, HW_OP_COPY, 0};
-    cp.seg_start[z] = (uint16_t)z;
-  }
-  cp.seg_start[np] = (uint16_t)np;
   const size_t row = (size_t)(level - 2) * hp.L;
-  if (c->dc.logN == 16) {
-    // fused: the iNTT reads the last limbs where they lie and leaves their centred lift; the forward NTT of the
-    // remaining limbs starts from that lift (modulus switch and constant folded into its first pass) and applies
-    // the Rescale tail in its last pass: 4 launches, no intermediate polynomial in memory
-    NttFuse fi;
-    fi.src0 = in0 + (size_t)(level - 1) * N;
-    fi.src1 = in1 ? in1 + (size_t)(level - 1) * N : nullptr;
-    fi.center_out = true;
-    launch_ntt_fused(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N, 0, fi);
-    NttFuse fo;
-    fo.msg = (const int64_t*)last;
-    fo.msg_stride = N;
-    fo.msg_scale = c->qlql + row;
-    fo.epi = 1;
-    fo.out0 = out0;
-    fo.out1 = out1;
-    fo.x0 = in0;
-    fo.x1 = in1;
-    fo.w = c->ql_inv + row;
-    fo.wp = c->ql_inv_prec + row;
-    launch_ntt_fused(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride, 0, fo);
-  } else {
-    launch_hw_batch_ew(c->dc, cp, np, s);
-    launch_ntt(c->dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N);
-    launch_rescale_spread(c->dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
-    launch_ntt(c->dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride);
-    launch_rescale_tail(c->dc, out0, out1, in0, in1, t, t_stride, c->ql_inv + row, c->ql_inv_prec + row, level, np, s);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {  // the last limb (its owner only) -> coefficient domain
+    if (dc.logN == 16) {
+      // fused: the iNTT reads the last limbs where they lie and leaves their centred lift; the forward NTT of the
+      // remaining limbs starts from that lift (modulus switch and constant folded into its first pass) and applies
+      // the Rescale tail in its last pass: 4 launches, no intermediate polynomial in memory
+      NttFuse fi;
+      fi.src0 = in0 + (size_t)(level - 1) * N;
+      fi.src1 = in1 ? in1 + (size_t)(level - 1) * N : nullptr;
+      fi.center_out = true;
+      launch_ntt_fused(dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N, 0, fi);
+    } else {
+      for (u32 z = 0; z < np; ++z) copy_limbs_dc(dc, last + z * N, (z ? in1 : in0) + (size_t)(level - 1) * N, 1, level - 1, s);
+      launch_ntt(dc, last, hp.L, level - 1, 1, true, s, level - 1, np, N);
+    }
+  }
+  if (sharded(c)) {  // SURVEY 8e collective 3: the owner of limb level-1 sends it to everyone
+    XItem x[2] = {{last, (level - 1) % c->sh_world}, {last + N, (level - 1) % c->sh_world}};
+    if (int e = shard_exchange(c, x, np, s)) return e;
+  }
+  for (const DevCtx& dc : dcs) {
+    if (dc.logN == 16) {
+      NttFuse fo;
+      fo.msg = (const int64_t*)last;
+      fo.msg_stride = N;
+      fo.msg_scale = c->qlql + row;
+      fo.epi = 1;
+      fo.out0 = out0;
+      fo.out1 = out1;
+      fo.x0 = in0;
+      fo.x1 = in1;
+      fo.w = c->ql_inv + row;
+      fo.wp = c->ql_inv_prec + row;
+      launch_ntt_fused(dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride, 0, fo);
+    } else {
+      launch_rescale_spread(dc, t, t_stride, last, N, c->qlql + row, c->qlql_prec + row, level, np, s);
+      launch_ntt(dc, t, hp.L, 0, level - 1, false, s, 0, np, t_stride);
+      launch_rescale_tail(dc, out0, out1, in0, in1, t, t_stride, c->ql_inv + row, c->ql_inv_prec + row, level, np, s);
+    }
   }
   stat(ST_RESCALE, np, 8ull * N * (2 * level - 1) * np);
   return post_launch();
@@ -426,6 +486,8 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   md.n_out = level;
   md.hat_ld = hp.L;
   descs.push_back(md);
+  md.src_pos0 = 0;  // [nd + 1]: the same problem with the K sources at limb positions 0.. (Mod_down: the P-limbs sit in a scratch of their own)
+  descs.push_back(md);
   std::lock_guard<std::mutex> lk(c->mu);
   plan.d_descs = c->up(descs);
   if (!plan.d_descs) return nullptr;
@@ -454,65 +516,83 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   u64* acc0 = ext + nd * E;
   u64* acc1 = acc0 + E;
   u64* tmp = acc1 + E;
-  // 1. all digit limbs to the coefficient domain in one launch (polynomial.c:1276-1283 for every part)
   const bool fused = c->dc.logN == 16;
-  if (fused) {
-    NttFuse fi;
-    fi.src0 = in;
-    fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
-    launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
-  } else {
-    HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
-  }
-  // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the inverse NTT) and
-  // 3. the NTT of every digit's complement limbs (own digit limbs are skipped): at N = 2^16 one pipeline, the conversion
-  //    is computed by the first NTT pass while it loads its input
+  const DcList dcs = launch_dcs(c);
   const u32 n_ext_rows = level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1));
-  if (conv_fusable(c, hp.alpha)) {
-    NttFuse fc;
-    fc.conv = plan->d_descs;
-    fc.conv_step = 1;
-    fc.conv_max_in = hp.alpha;
-    fc.conv_src = coef;
-    fc.conv_src_stride = 0;
-    launch_ntt_fused(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
-  } else {
-    launch_base_conv_batch(c->dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
-    launch_ntt(c->dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
+  // 1. all digit limbs to the coefficient domain in one launch (polynomial.c:1276-1283 for every part)
+  for (const DevCtx& dc : dcs) {
+    if (fused) {
+      NttFuse fi;
+      fi.src0 = in;
+      fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
+      launch_ntt_fused(dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
+    } else {
+      copy_limbs_dc(dc, coef, in, level, 0, s);
+      launch_ntt(dc, coef, hp.L, 0, level, true, s);
+    }
   }
-  // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
-  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
-  // 5. ModDown of both accumulators together (polynomial.c:928-967)
-  if (fused) {
-    NttFuse fa;
-    fa.inv_scale = plan->inv_down - 4 * (size_t)level;  // the p-limbs sit at positions level .. level+K-1
-    launch_ntt_fused(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E, 0, fa);
-  } else {
-    launch_ntt(c->dc, acc0, level, level, hp.K, true, s, 0, 2, E);
+  if (sharded(c)) {  // SURVEY 8e collective 1: every rank needs every source limb of the conversions
+    std::vector<XItem> x;
+    for (u32 i = 0; i < level; ++i) x.push_back(XItem{coef + (size_t)i * N, i % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+  }
+  for (const DevCtx& dc : dcs) {
+    // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the inverse NTT) and
+    // 3. the NTT of every digit's complement limbs (own digit limbs are skipped): at N = 2^16 one pipeline, the conversion
+    //    is computed by the first NTT pass while it loads its input
+    if (conv_fusable(c, hp.alpha)) {
+      NttFuse fc;
+      fc.conv = plan->d_descs;
+      fc.conv_step = 1;
+      fc.conv_max_in = hp.alpha;
+      fc.conv_src = coef;
+      fc.conv_src_stride = 0;
+      launch_ntt_fused(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
+    } else {
+      launch_base_conv_batch(dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
+      launch_ntt(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
+    }
+    // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
+    launch_key_mac_fused(dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
+    // 5. ModDown of both accumulators together (polynomial.c:928-967)
+    if (fused) {
+      NttFuse fa;
+      fa.inv_scale = plan->inv_down - 4 * (size_t)level;  // the p-limbs sit at positions level .. level+K-1
+      launch_ntt_fused(dc, acc0, level, level, hp.K, true, s, 0, 2, E, 0, fa);
+    } else {
+      launch_ntt(dc, acc0, level, level, hp.K, true, s, 0, 2, E);
+    }
+  }
+  if (sharded(c)) {  // collective 2: the P-limbs of both accumulators
+    std::vector<XItem> x;
+    for (u32 z = 0; z < 2; ++z)
+      for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{acc0 + z * E + (size_t)(level + j) * N, (hp.L + j) % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
   }
   const bool conv_in_ntt = fused && conv_fusable(c, hp.K);
-  if (!conv_in_ntt) launch_base_conv_batch(c->dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
-  if (fused) {  // the ModDown tail rides in the last NTT pass, the conversion P -> Q in the first
-    NttFuse fo;
-    if (conv_in_ntt) {
-      fo.conv = plan->d_descs + nd;
-      fo.conv_step = 0;
-      fo.conv_max_in = hp.K;
-      fo.conv_src = acc0;
-      fo.conv_src_stride = E;
+  for (const DevCtx& dc : dcs) {
+    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
+    if (fused) {  // the ModDown tail rides in the last NTT pass, the conversion P -> Q in the first
+      NttFuse fo;
+      if (conv_in_ntt) {
+        fo.conv = plan->d_descs + nd;
+        fo.conv_step = 0;
+        fo.conv_max_in = hp.K;
+        fo.conv_src = acc0;
+        fo.conv_src_stride = E;
+      }
+      fo.epi = 2;
+      fo.out0 = out0;
+      fo.out1 = out1;
+      fo.x0 = acc0;
+      fo.x1 = acc1;
+      fo.w = c->pinv;
+      fo.wp = c->pinv_prec;
+      launch_ntt_fused(dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N, 0, fo);
+    } else {
+      launch_ntt(dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
+      launch_moddown_tail2(dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
     }
-    fo.epi = 2;
-    fo.out0 = out0;
-    fo.out1 = out1;
-    fo.x0 = acc0;
-    fo.x1 = acc1;
-    fo.w = c->pinv;
-    fo.wp = c->pinv_prec;
-    launch_ntt_fused(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N, 0, fo);
-  } else {
-    launch_ntt(c->dc, tmp, level, 0, level, false, s, 0, 2, (size_t)level * N);
-    launch_moddown_tail2(c->dc, out0, out1, acc0, acc1, tmp, tmp + (size_t)level * N, c->pinv, c->pinv_prec, level, s);
   }
   stat(ST_KEYSWITCH, 1, acehip_key_switch_bytes(c, level));
   return post_launch();
@@ -520,12 +600,12 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
 
 int acehip_values_to_rns(acehip_ctx* c, uint64_t* d, const int64_t* vals, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  launch_values_to_rns(c->dc, d, vals, level, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_values_to_rns(dc, d, vals, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
 int acehip_sample_uniform(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, uint64_t seed, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  launch_sample_uniform(c->dc, d, level, pos0, n, seed, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_sample_uniform(dc, d, level, pos0, n, seed, (hipStream_t)s);
   return post_launch();
 }
 int acehip_mul_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
@@ -533,7 +613,7 @@ int acehip_mul_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint
   if (n > 64) return fail(ACEHIP_EINVAL, "acehip_mul_scalars: at most 64 limbs per call");
   LimbConsts w{};
   for (u32 i = 0; i < n; ++i) w.w[i] = h_scalars[i];
-  launch_mul_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_mul_scalars(dc, r, a, w, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
 }  // extern "C"
@@ -628,7 +708,7 @@ int acehip_encode_batch(acehip_ctx* c, uint64_t* const* h_q, const void* const* 
     f.msg_scale = encode_scale_table(c, (u64)sf, sf_degree);
     if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
   }
-  launch_ntt_fused(c->dc, h_q[0], level, 0, level, false, st, 0, n_batch, 0, 0, f);
+  for (const DevCtx& dc : launch_dcs(c)) launch_ntt_fused(dc, h_q[0], level, 0, level, false, st, 0, n_batch, 0, 0, f);
   stat(ST_ENCODE, n_batch, n_batch * (8ull * N * level + len * (kind == 0 ? 4 : kind == 1 ? 8 : 16)));
   return post_launch();
 }
@@ -645,36 +725,38 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
   hipStream_t st = (hipStream_t)s;
   launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
   const u64 sfi = (u64)sf;
-  if (c->dc.logN == 16) {  // the first NTT pass reduces (and scales) the message itself: no residue pass over memory
-    NttFuse f;
-    f.msg = c->emb_msg;
-    if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
-      f.msg_scale = encode_scale_table(c, sfi, sf_degree);
-      if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
-    }
-    launch_ntt_fused(c->dc, d_q, level, 0, level, false, st, 0, 1, 0, 0, f);
-    if (n_p) {
-      f.msg_scale = nullptr;
-      launch_ntt_fused(c->dc, d_p, 0, 0, n_p, false, st, 0, 1, 0, 0, f);
-    }
-  } else {
-    launch_values_to_rns(c->dc, d_q, c->emb_msg, level, 0, level, st);
-    if (n_p) launch_values_to_rns(c->dc, d_p, c->emb_msg, 0, 0, n_p, st);
-    if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
-      for (u32 l0 = 0; l0 < level; l0 += 64) {
-        LimbConsts w{};
-        const u32 n = std::min(64u, level - l0);
-        for (u32 i = 0; i < n; ++i) {
-          const u64 q = c->hp.primes[l0 + i].q;
-          u64 pw = sfi % q;
-          for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
-          w.w[i] = pw;
-        }
-        launch_mul_scalars(c->dc, d_q, d_q, w, level, l0, n, st);
+  for (const DevCtx& dc : launch_dcs(c)) {
+    if (dc.logN == 16) {  // the first NTT pass reduces (and scales) the message itself: no residue pass over memory
+      NttFuse f;
+      f.msg = c->emb_msg;
+      if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
+        f.msg_scale = encode_scale_table(c, sfi, sf_degree);
+        if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
       }
+      launch_ntt_fused(dc, d_q, level, 0, level, false, st, 0, 1, 0, 0, f);
+      if (n_p) {
+        f.msg_scale = nullptr;
+        launch_ntt_fused(dc, d_p, 0, 0, n_p, false, st, 0, 1, 0, 0, f);
+      }
+    } else {
+      launch_values_to_rns(dc, d_q, c->emb_msg, level, 0, level, st);
+      if (n_p) launch_values_to_rns(dc, d_p, c->emb_msg, 0, 0, n_p, st);
+      if (sf_degree > 1) {  // ckks_encoder.c:270-285: times Delta^(sf_degree-1) on the q limbs
+        for (u32 l0 = 0; l0 < level; l0 += 64) {
+          LimbConsts w{};
+          const u32 n = std::min(64u, level - l0);
+          for (u32 i = 0; i < n; ++i) {
+            const u64 q = c->hp.primes[l0 + i].q;
+            u64 pw = sfi % q;
+            for (u32 d = 2; d < sf_degree; ++d) pw = (u64)(((unsigned __int128)pw * (sfi % q)) % q);
+            w.w[i] = pw;
+          }
+          launch_mul_scalars(dc, d_q, d_q, w, level, l0, n, st);
+        }
+      }
+      launch_ntt(dc, d_q, level, 0, level, false, st);
+      if (n_p) launch_ntt(dc, d_p, 0, 0, n_p, false, st);
     }
-    launch_ntt(c->dc, d_q, level, 0, level, false, st);
-    if (n_p) launch_ntt(c->dc, d_p, 0, 0, n_p, false, st);
   }
   stat(ST_ENCODE, 1, 8ull * N * (level + n_p) + len * (kind == 0 ? 4 : kind == 1 ? 8 : 16));
   return post_launch();
@@ -697,7 +779,8 @@ int acehip_decomp(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t lev
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L || digit >= c->hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_decomp: bad level/digit");
   const u32 start = c->hp.alpha * digit, n2 = std::min(c->hp.alpha, level - start);
-  HIP_TRY(hipMemcpyAsync(out, in + (size_t)start * c->hp.N, (size_t)n2 * c->hp.N * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)s));
+  for (const DevCtx& dc : launch_dcs(c)) copy_limbs_dc(dc, out, in + (size_t)start * c->hp.N, n2, start, (hipStream_t)s);
+  if (int e = post_launch()) return e;
   return (int)n2;
 }
 int acehip_mod_up(acehip_ctx* c, uint64_t* out, const uint64_t* digit_limbs, uint32_t level, uint32_t digit, acehip_stream s) {
@@ -714,7 +797,7 @@ int acehip_add_scalars(acehip_ctx* c, uint64_t* r, const uint64_t* a, const uint
   if (n > 64) return fail(ACEHIP_EINVAL, "acehip_add_scalars: at most 64 limbs per call");
   LimbConsts w{};
   for (u32 i = 0; i < n; ++i) w.w[i] = h_scalars[i];
-  launch_add_scalars(c->dc, r, a, w, level, pos0, n, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_add_scalars(dc, r, a, w, level, pos0, n, (hipStream_t)s);
   return post_launch();
 }
 // Switch_key_precompute (polynomial.c:1224-1239, 1337-1343): every digit of d_in raised to level+K limbs.
@@ -735,49 +818,60 @@ static int modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t
     outz.p[d] = h_ext[d];
   }
   u64* coef = c->ws;
-  if (c->dc.logN == 16) {
-    NttFuse fi;
-    fi.src0 = in;
-    fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
-    launch_ntt_fused(c->dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
-  } else {
-    HIP_TRY(hipMemcpyAsync(coef, in, (size_t)level * N * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    launch_ntt(c->dc, coef, hp.L, 0, level, true, s);
+  const DcList dcs = launch_dcs(c);
+  for (const DevCtx& dc : dcs) {
+    if (dc.logN == 16) {
+      NttFuse fi;
+      fi.src0 = in;
+      fi.inv_scale = plan->inv_up;  // (Q_d/q_i)^-1 folded into the last inverse stage
+      launch_ntt_fused(dc, coef, hp.L, 0, level, true, s, 0, 1, 0, 0, fi);
+    } else {
+      copy_limbs_dc(dc, coef, in, level, 0, s);
+      launch_ntt(dc, coef, hp.L, 0, level, true, s);
+    }
+  }
+  if (sharded(c)) {  // SURVEY 8e collective 1: the source limbs of every digit's conversion come from their owners
+    std::vector<XItem> x;
+    for (u32 i = 0; i < level; ++i) x.push_back(XItem{coef + (size_t)i * N, i % c->sh_world});
+    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
   }
   const u32 n_ext_rows = level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1));
-  if (conv_fusable(c, hp.alpha)) {  // the conversions ride in the first pass of the NTT
-    NttFuse fc;
-    fc.conv = plan->d_descs;
-    fc.conv_step = 1;
-    fc.conv_max_in = hp.alpha;
-    fc.conv_src = coef;
-    fc.conv_src_stride = 0;
-    for (u32 d = 0; d < nd; ++d) fc.polyz[d] = outz.p[d];
-    launch_ntt_fused(c->dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fc);
-  } else {
-    launch_base_conv_batch(c->dc, outz.p[0], 0, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, outz);
-    if (c->dc.logN == 16) {
-      NttFuse fz;
-      for (u32 d = 0; d < nd; ++d) fz.polyz[d] = outz.p[d];
-      launch_ntt_fused(c->dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fz);
+  for (const DevCtx& dc : dcs) {
+    if (conv_fusable(c, hp.alpha)) {  // the conversions ride in the first pass of the NTT
+      NttFuse fc;
+      fc.conv = plan->d_descs;
+      fc.conv_step = 1;
+      fc.conv_max_in = hp.alpha;
+      fc.conv_src = coef;
+      fc.conv_src_stride = 0;
+      for (u32 d = 0; d < nd; ++d) fc.polyz[d] = outz.p[d];
+      launch_ntt_fused(dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fc);
     } else {
-      for (u32 d = 0; d < nd; ++d) {  // the generic passes address polynomials by stride: one digit at a time
-        const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
-        if (start) launch_ntt(c->dc, outz.p[d], level, 0, start, false, s);
-        launch_ntt(c->dc, outz.p[d], level, start + n2, level + hp.K - (start + n2), false, s);
+      launch_base_conv_batch(dc, outz.p[0], 0, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, outz);
+      if (dc.logN == 16) {
+        NttFuse fz;
+        for (u32 d = 0; d < nd; ++d) fz.polyz[d] = outz.p[d];
+        launch_ntt_fused(dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fz);
+      } else {
+        for (u32 d = 0; d < nd; ++d) {  // the generic passes address polynomials by stride: one digit at a time
+          const u32 start = hp.alpha * d, n2 = std::min(hp.alpha, level - start);
+          if (start) launch_ntt(dc, outz.p[d], level, 0, start, false, s);
+          launch_ntt(dc, outz.p[d], level, start + n2, level + hp.K - (start + n2), false, s);
+        }
       }
     }
-  }
-  {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
-    HwBatchArgs cp;
-    u32 n_ops = 0;
-    for (u32 pos = 0; pos < level; ++pos) {
-      if (n_ops == HW_BATCH_MAX) return fail(ACEHIP_EINVAL, "acehip_modup_digits: too many limbs");
+    {  // digit limbs pass through (polynomial.c:1265-1273): `level` limb copies in one launch
+      HwBatchArgs cp;
+      u32 n_ops = 0;
+      for (u32 pos = 0; pos < level; ++pos) {
+        if (!dc_owns(dc, pos)) continue;
+        if (n_ops == HW_BATCH_MAX) return fail(ACEHIP_EINVAL, "acehip_modup_digits: too many limbs");
+        cp.seg_start[n_ops] = (uint16_t)n_ops;
+        cp.op[n_ops++] = HwBatchOp{outz.p[pos / hp.alpha] + (size_t)pos * N, in + (size_t)pos * N, nullptr, HW_OP_COPY, 0};
+      }
       cp.seg_start[n_ops] = (uint16_t)n_ops;
-      cp.op[n_ops++] = HwBatchOp{outz.p[pos / hp.alpha] + (size_t)pos * N, in + (size_t)pos * N, nullptr, HW_OP_COPY, 0};
+      launch_hw_batch_ew(dc, cp, n_ops, s);
     }
-    cp.seg_start[n_ops] = (uint16_t)n_ops;
-    launch_hw_batch_ew(c->dc, cp, n_ops, s);
   }
   stat(ST_MODUP, nd, 8ull * N * (level + (u64)nd * (level + hp.K)));
   return post_launch();
@@ -800,7 +894,7 @@ int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, cons
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_inner_product: bad level");
   const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
-  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_key_mac_fused(dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s);
   stat(ST_KEYMAC, 1, 8ull * E * (3ull * c->hp.num_decomp(level) + 2));
   return post_launch();
 }
@@ -817,7 +911,7 @@ int acehip_key_inner_product_add(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, 
     w.w[i] = h_scalars[i];
   }
   const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
-  launch_key_mac_fused(c->dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s, add0, &w);
+  for (const DevCtx& dc : launch_dcs(c)) launch_key_mac_fused(dc, acc0, acc1, key, ext, E, nullptr, level, c->hp.num_decomp(level), c->hp.alpha, (hipStream_t)s, add0, &w);
   stat(ST_KEYMAC, 1, 8ull * E * (3ull * c->hp.num_decomp(level) + 2) + 8ull * level * c->hp.N);
   return post_launch();
 }
@@ -859,7 +953,7 @@ int acehip_bsgs_inner_rot(acehip_ctx* c, uint64_t* const* out0, uint64_t* const*
   a.g = g;
   a.b = b;
   a.pt_q_alloc = pt_q_limbs;
-  launch_bsgs_inner(c->dc, a, level, (hipStream_t)s);
+  for (const DevCtx& dc : launch_dcs(c)) launch_bsgs_inner(dc, a, level, (hipStream_t)s);
   const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
   stat(ST_EW, n_pt, 8ull * E * (2ull * g + n_pt + 2ull * b));
   return post_launch();

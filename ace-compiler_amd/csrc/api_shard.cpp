@@ -437,3 +437,226 @@ int acehip_shard_encode_limbs(acehip_shard* sh, uint64_t* d_q_own, const int64_t
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Limb-sharded execution as a mode of the context (include/acehip.h): the exchange steps of the pipelines in api_ops.cpp.
+// Simulated ranks (one process, replica h of the arena = hosted rank h): an exchange copies every listed limb from its
+// owner's replica into the other replicas.  Real ranks (one process per GPU): grouped RCCL broadcasts from the owner, in place,
+// on the launch stream.  RCCL is loaded with dlopen when first needed: unsharded programs never map it.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+
+struct Id128 {  // ncclUniqueId (rccl.h): passed by value to ncclCommInitRank
+  char b[128];
+};
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+    api.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, Id128, int))sym("ncclCommInitRank");
+    api.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    api.GroupStart = (int (*)())sym("ncclGroupStart");
+    api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    api.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
+    api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.GroupStart || !api.GroupEnd || !api.Broadcast) api.lib = nullptr;
+  });
+  return api.lib ? &api : nullptr;
+}
+struct RcclComm {
+  void* comm = nullptr;
+  u32 rank = 0, world = 1;
+};
+constexpr int kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
+}  // namespace
+
+int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
+  if (c->sh_world <= 1 || n == 0) return ACEHIP_OK;
+  const size_t N = c->hp.N;
+  const u64 lo = c->dc.rep_lo, span = c->dc.rep_span, stride = c->dc.rep_stride;
+  c->xchg_calls++;
+  if (c->rccl != nullptr) {  // one process per rank: broadcast from the owner, in place, for every selected replica
+    RcclComm* rc = (RcclComm*)c->rccl;
+    RcclApi* api = rccl_api();
+    int e = api->GroupStart();
+    for (size_t k = 0; k < n && e == 0; ++k) {
+      const u64 a = (u64)items[k].ptr;
+      const bool in_arena = a - lo < span && stride != 0;
+      for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1) && e == 0; ++r) {
+        void* p = (void*)(in_arena ? a + (u64)r * stride : a);
+        e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, s);
+        if (items[k].root != rc->rank) c->xchg_bytes += N * 8;
+      }
+    }
+    const int e2 = api->GroupEnd();
+    if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
+    return ACEHIP_OK;
+  }
+  // simulated ranks: owner's replica -> every other hosted replica (absolute addresses: a DevCtx without rebasing)
+  DevCtx dc = c->dc;
+  dc.rep_span = 0;
+  dc.rep0 = 0;
+  dc.nrep = 1;
+  dc.sh_world = 1;
+  HwBatchArgs cp;
+  u32 m = 0;
+  auto flush = [&] {
+    if (m == 0) return;
+    cp.seg_start[m] = (uint16_t)m;
+    launch_hw_batch_ew(dc, cp, m, s);
+    m = 0;
+  };
+  for (size_t k = 0; k < n; ++k) {
+    const u64 a = (u64)items[k].ptr;
+    if (!(a - lo < span) || stride == 0) continue;  // memory all simulated ranks share
+    u32 h_root = UINT32_MAX;
+    for (u32 h = 0; h < c->sh_hosted.size(); ++h)
+      if (c->sh_hosted[h] == items[k].root) h_root = h;
+    if (h_root == UINT32_MAX) return fail(ACEHIP_EINVAL, "shard_exchange: the owner of a limb is not hosted here");
+    for (u32 h = 0; h < c->sh_hosted.size(); ++h) {
+      if (h == h_root) continue;
+      if (m == HW_BATCH_MAX) flush();
+      cp.seg_start[m] = (uint16_t)m;
+      cp.op[m++] = HwBatchOp{(u64*)(a + (u64)h * stride), (const u64*)(a + (u64)h_root * stride), nullptr, HW_OP_COPY, 0};
+      c->xchg_bytes += N * 8;
+    }
+  }
+  flush();
+  return post_launch();
+}
+
+extern "C" {
+
+int acehip_ctx_shard_sim(acehip_ctx* c, uint32_t world) {
+  if (!c) return fail(ACEHIP_EINVAL, "null context");
+  if (world == 0 || world > 16) return fail(ACEHIP_EINVAL, "acehip_ctx_shard_sim: 1..16 simulated ranks");
+  if (world == 1) {
+    c->sh_world = 1;
+    c->sh_hosted.clear();
+    return ACEHIP_OK;
+  }
+  if (c->on_device && (c->n_replicas < world || !c->ws_external || !c->scratch_external))
+    return fail(ACEHIP_EINVAL, "acehip_ctx_shard_sim: needs an arena with one replica per rank, workspace and hw scratch inside (acehip_ctx_set_arena)");
+  c->sh_world = world;
+  c->sh_hosted.resize(world);
+  for (u32 r = 0; r < world; ++r) c->sh_hosted[r] = r;
+  c->sel0 = 0;
+  c->seln = 1;
+  return ACEHIP_OK;
+}
+
+int acehip_rccl_unique_id(void* out, size_t cap) {
+  if (!out || cap < 128) return fail(ACEHIP_EINVAL, "acehip_rccl_unique_id: 128 bytes needed");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(ACEHIP_ENODEV, "librccl.so could not be loaded");
+  Id128 id;
+  if (int e = api->GetUniqueId(&id)) return fail(ACEHIP_EHIP, std::string("ncclGetUniqueId: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  std::memcpy(out, id.b, 128);
+  return 128;
+}
+
+int acehip_ctx_shard_rccl(acehip_ctx* c, uint32_t rank, uint32_t world, const void* unique_id, size_t id_bytes) {
+  if (int e = check_dev(c)) return e;
+  if (world == 0 || rank >= world || !unique_id || id_bytes != 128) return fail(ACEHIP_EINVAL, "acehip_ctx_shard_rccl: bad arguments");
+  if (c->sh_world > 1) return fail(ACEHIP_EINVAL, "acehip_ctx_shard_rccl: the context is sharded already");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(ACEHIP_ENODEV, "librccl.so could not be loaded");
+  auto* rc = new RcclComm();
+  rc->rank = rank;
+  rc->world = world;
+  Id128 id;
+  std::memcpy(id.b, unique_id, 128);
+  if (int e = api->CommInitRank(&rc->comm, (int)world, id, (int)rank)) {
+    delete rc;
+    return fail(ACEHIP_EHIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  }
+  c->rccl = rc;
+  if (world > 1) {
+    c->sh_world = world;
+    c->sh_hosted.assign(1, rank);
+  }
+  return ACEHIP_OK;
+}
+
+int acehip_shard_gather(acehip_ctx* c, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n_limbs)) return e;
+  if (c->sh_world <= 1) return ACEHIP_OK;
+  std::vector<XItem> x;
+  for (u32 p = pos0; p < pos0 + n_limbs; ++p) x.push_back(XItem{d_poly + (size_t)p * c->hp.N, limb_prime(p, level, c->hp.L) % c->sh_world});
+  return shard_exchange(c, x.data(), x.size(), (hipStream_t)s);
+}
+
+uint32_t acehip_shard_world(const acehip_ctx* c) { return c ? c->sh_world : 1; }
+uint32_t acehip_shard_rank(const acehip_ctx* c) { return c && c->sh_world > 1 ? c->sh_hosted[0] : 0; }
+uint32_t acehip_shard_owned_limbs(const acehip_ctx* c, uint32_t rank) {
+  if (!c) return 0;
+  u32 n = 0;
+  for (u32 gi = 0; gi < c->hp.L + c->hp.K; ++gi) n += gi % c->sh_world == rank;
+  return n;
+}
+uint64_t acehip_shard_traffic(const acehip_ctx* c_, uint64_t* steps, int reset) {
+  acehip_ctx* c = const_cast<acehip_ctx*>(c_);
+  if (!c) return 0;
+  const u64 b = c->xchg_bytes;
+  if (steps) {
+    steps[0] = c->xchg_calls;
+    steps[1] = b / (8ull * c->hp.N);
+  }
+  if (reset) c->xchg_bytes = c->xchg_calls = 0;
+  return b;
+}
+
+// which limbs meet where: the exchange steps of the pipelines in api_ops.cpp, stated once more as data so that the schedule
+// can be checked against the CPU oracle without a GPU (tests/test_dist_gloo.py runs it over gloo with two processes)
+int acehip_shard_schedule(const acehip_ctx* c, uint32_t world, int op, uint32_t level, uint32_t* out_step, uint32_t* out_pos,
+                          uint32_t* out_root, size_t cap) {
+  if (!c || world == 0 || level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_shard_schedule: bad arguments");
+  const HostParams& hp = c->hp;
+  size_t n = 0;
+  auto put = [&](u32 step, u32 pos, u32 gi) {
+    if (n < cap) {
+      out_step[n] = step;
+      out_pos[n] = pos;
+      out_root[n] = gi % world;
+    }
+    ++n;
+  };
+  switch (op) {
+    case 0:  // ModUp of all digits: the coefficient-domain q-limbs (api_ops.cpp modup_digits_to / acehip_key_switch step 1)
+      for (u32 i = 0; i < level; ++i) put(0, i, i);
+      break;
+    case 1:  // ModDown: the coefficient-domain P-limbs at positions level.. (do_mod_down_n / acehip_key_switch step 5)
+      for (u32 j = 0; j < hp.K; ++j) put(0, level + j, hp.L + j);
+      break;
+    case 2:  // Rescale: the last limb (do_rescale)
+      if (level < 2) return fail(ACEHIP_EINVAL, "acehip_shard_schedule: rescale needs two limbs");
+      put(0, level - 1, level - 1);
+      break;
+    case 3:  // ModRaise: limb 0 (acehip_mod_raise)
+      put(0, 0, 0);
+      break;
+    default:
+      return fail(ACEHIP_EINVAL, "acehip_shard_schedule: unknown operation");
+  }
+  return (int)n;
+}
+
+}  // extern "C"

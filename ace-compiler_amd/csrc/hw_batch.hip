@@ -69,17 +69,22 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * kHwLanes;
   if (i >= c.N) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
+  const u32 rep = c.rep0 + blockIdx.z;  // replica of this workgroup: operands inside the replicated arena move with it
   const u64* prev_res = nullptr;
   V4 vprev{{0, 0}, {0, 0}};
   for (u32 k = beg; k < end; ++k) {
-    const HwBatchOp op = args.op[k];
+    HwBatchOp op = args.op[k];
     const u32 kind = op.kind & HW_OP_KIND_MASK;
-    const bool keep_in_regs = (op.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == op.res);
+    const u64 *const res0 = op.res, *const a0 = op.a, *const b0 = op.b;  // (registers are matched by the list's own addresses)
+    op.res = reb(c, op.res, rep);
+    op.a = reb(c, op.a, rep);
+    if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) op.b = reb(c, op.b, rep);  // (else an immediate)
+    const bool keep_in_regs = (op.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == res0);
     V4 vr;
     if (kind == HW_OP_ZERO) {
       vr = V4{{0, 0}, {0, 0}};
     } else {
-      const V4 va = op.a == prev_res ? vprev : ld4(op.a + i);
+      const V4 va = a0 == prev_res ? vprev : ld4(op.a + i);
       if (kind == HW_OP_COPY) {
         vr = va;
       } else {
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
           const u64 imm = (u64)(uintptr_t)op.b;
           vb = V4{{imm, imm}, {imm, imm}};
         } else {
-          vb = op.b == prev_res ? vprev : ld4(op.b + i);
+          vb = b0 == prev_res ? vprev : ld4(op.b + i);
         }
         switch (kind) {
           case HW_OP_ADD:
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
             vr = map2(va, vb, [q](u64 x, u64 y) { return sub_mod(x, y, q); });
             break;
           case HW_OP_MULADD: {
-            const V4 acc = op.res == prev_res ? vprev : ld4(op.res + i);
+            const V4 acc = res0 == prev_res ? vprev : ld4(op.res + i);
             const V4 pr = map2(va, vb, [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
             vr = map2(acc, pr, [q](u64 x, u64 y) { return add_mod(x, y, q); });
             break;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
       }
     }
     if (!keep_in_regs) st4(op.res + i, vr);
-    prev_res = op.res;
+    prev_res = res0;
     vprev = vr;
   }
 }
@@ -124,10 +129,13 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
 // order is perm[i] = rev(((2 rev(i) + 1) k mod 2N) >> 1) (host_params.cpp automorphism_order_ntt): computed here, 4 bytes per
 // coefficient less to load.  op.gi == 0: a caller-supplied permutation, loaded.
 template <int CAP>
-__global__ __launch_bounds__(256) void hw_batch_rotate_kernel(u32 N, HwBatchArgsT<CAP> args) {
+__global__ __launch_bounds__(256) void hw_batch_rotate_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
+  const u32 N = c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= N) return;
-  const HwBatchOp op = args.op[blockIdx.y];
+  HwBatchOp op = args.op[blockIdx.y];
+  op.res = reb(c, op.res, c.rep0 + blockIdx.z);
+  op.a = reb(c, op.a, c.rep0 + blockIdx.z);
   uint2 p;
   if (op.gi != 0) {  // uniform for the workgroup
     const u32 sh = __builtin_clz(N) + 1;  // 32 - log2(N)
@@ -154,7 +162,7 @@ static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_seg == 0) return;
-  dim3 grid((c.N / kHwLanes + 255) / 256, n_seg), block(256);
+  dim3 grid((c.N / kHwLanes + 255) / 256, n_seg, c.nrep), block(256);
   const u32 n_ops = args.seg_start[n_seg];
   if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));
   else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));
@@ -164,10 +172,10 @@ void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hip
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
   ACEHIP_ABLATE(ABL_ROTATE);
   if (n_ops == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_ops), block(256);
-  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_rotate_kernel<16>, grid, block, 0, s, c.N, shrink<16>(args, n_ops, 0));
-  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_rotate_kernel<48>, grid, block, 0, s, c.N, shrink<48>(args, n_ops, 0));
-  else hipLaunchKernelGGL(hw_batch_rotate_kernel<HW_BATCH_MAX>, grid, block, 0, s, c.N, args);
+  dim3 grid((c.N / 2 + 255) / 256, n_ops, c.nrep), block(256);
+  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_rotate_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, 0));
+  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_rotate_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, 0));
+  else hipLaunchKernelGGL(hw_batch_rotate_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args);
 }
 
 }  // namespace acehip

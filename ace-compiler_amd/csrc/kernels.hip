@@ -39,11 +39,13 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(DevCtx c, u64* __restrict
                                                        u32 s0, u32 r, u32 log_c, u32 skip_alpha) {
   extern __shared__ u64 tile[];
   u32 pos;
-  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blockIdx.y, blockIdx.z)) return;
+  const RepZ rz = rep_of_z(c);  // blockIdx.z = polynomial + n_polys * replica
+  if (!ntt_limb_pos(pos, pos0, level, c.K, skip_alpha, blockIdx.y, rz.z)) return;
   const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
   const DevPrime P = c.primes[gi];
   const u64 q = P.q;
-  u64* x = poly + blockIdx.z * poly_stride + (size_t)(pos - pos_off) * c.N;
+  u64* x = reb(c, poly, rz.rep) + rz.z * poly_stride + (size_t)(pos - pos_off) * c.N;
   const ulong2* W = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)gi * c.N;
   const u32 R = 1u << r, C = 1u << log_c;
   const u32 log_s = c.logN - s0 - r;
@@ -125,7 +127,7 @@ static void launch_pass(const DevCtx& c, u64* poly, size_t poly_stride, u32 n_po
                         u32 log_c, hipStream_t s, u32 skip_alpha) {
   ACEHIP_ABLATE(ABL_NTT);
   const u32 tiles = c.N >> (r + log_c);
-  dim3 grid(tiles, n_limbs, n_polys), block(256);
+  dim3 grid(tiles, n_limbs, n_polys * c.nrep), block(256);
   size_t lds = sizeof(u64) << (r + log_c);
   hipLaunchKernelGGL((ntt_pass_kernel<CONTIG, INVERSE>), grid, block, lds, s, c, poly, poly_stride, level, pos0, pos_off, s0, r, log_c, skip_alpha);
 }
@@ -159,9 +161,12 @@ void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bo
 // grid: (ceil(N/512), n_limbs); each lane handles 2 coefficients (16-byte accesses)
 // ------------------------------------------------------------------------------------------------
 template <int OP>
-__global__ __launch_bounds__(256) void ew_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
-                                                 const u64* __restrict__ b, u32 level, u32 pos0, u32 pos_off) {
+__global__ __launch_bounds__(256) void ew_kernel(DevCtx c, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 pos_off) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  r = reb(c, r, c.rep0 + blockIdx.z);
+  a = reb(c, a, c.rep0 + blockIdx.z);
+  b = reb(c, b, c.rep0 + blockIdx.z);
   const DevPrime P = c.primes[limb_prime(pos, level, c.L)];
   const size_t base = (size_t)(pos - pos_off) * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -190,7 +195,7 @@ void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32
                hipStream_t s, u32 pos_off) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, c.nrep), block(256);
   switch (op) {
     case EwOp::Add: hipLaunchKernelGGL(ew_kernel<0>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
     case EwOp::Sub: hipLaunchKernelGGL(ew_kernel<1>, grid, block, 0, s, c, r, a, b, level, pos0, pos_off); break;
@@ -200,8 +205,11 @@ void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32
 }
 
 // Hw_rotate (poly_arith.c:41-56) with an NTT-domain table: pure gather r[j] = a[perm[j]]
-__global__ __launch_bounds__(256) void rotate_kernel(u32 N, u64* __restrict__ r, const u64* __restrict__ a,
-                                                     const u32* __restrict__ perm, u32 pos0) {
+__global__ __launch_bounds__(256) void rotate_kernel(DevCtx c, u64* r, const u64* a, const u32* __restrict__ perm, u32 level, u32 pos0) {
+  const u32 N = c.N;
+  if (!owns(c, limb_prime(pos0 + blockIdx.y, level, c.L))) return;
+  r = reb(c, r, c.rep0 + blockIdx.z);
+  a = reb(c, a, c.rep0 + blockIdx.z);
   const size_t base = (size_t)(pos0 + blockIdx.y) * N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= N) return;
@@ -212,11 +220,11 @@ __global__ __launch_bounds__(256) void rotate_kernel(u32 N, u64* __restrict__ r,
   *reinterpret_cast<ulong2*>(r + base + i) = v;
 }
 
-void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 pos0, u32 n_limbs, hipStream_t s) {
+void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
   ACEHIP_ABLATE(ABL_ROTATE);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
-  hipLaunchKernelGGL(rotate_kernel, grid, block, 0, s, c.N, r, a, perm, pos0);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, c.nrep), block(256);
+  hipLaunchKernelGGL(rotate_kernel, grid, block, 0, s, c, r, a, perm, level, pos0);
 }
 
 // r_z[pos][j] = acc_z[pos][j] + a_z[pos][perm_k(j)] for one or two polynomials (blockIdx.z): the accumulation of a rotated
@@ -226,6 +234,8 @@ __global__ __launch_bounds__(256) void rotate_add2_kernel(DevCtx c, u64* __restr
                                                           const u64* acc0, const u64* acc1, const u64* __restrict__ a0,
                                                           const u64* __restrict__ a1, u32 auto_k, u32 level, u32 pos0) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  const RepZ rz = rep_of_z(c);  // blockIdx.z = polynomial + (1 or 2) * replica
   const u64 q = c.primes[limb_prime(pos, level, c.L)].q;
   const size_t base = (size_t)pos * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -234,9 +244,9 @@ __global__ __launch_bounds__(256) void rotate_add2_kernel(DevCtx c, u64* __restr
   const u32 b0 = __brev(i) >> sh, b1 = __brev(i + 1) >> sh;
   const u32 px = __brev((((2 * b0 + 1) * auto_k) & (2 * c.N - 1)) >> 1) >> sh;
   const u32 py = __brev((((2 * b1 + 1) * auto_k) & (2 * c.N - 1)) >> 1) >> sh;
-  const u64* a = blockIdx.z ? a1 : a0;
-  const u64* acc = blockIdx.z ? acc1 : acc0;
-  u64* r = blockIdx.z ? r1 : r0;
+  const u64* a = reb(c, rz.z ? a1 : a0, rz.rep);
+  const u64* acc = reb(c, rz.z ? acc1 : acc0, rz.rep);
+  u64* r = reb(c, rz.z ? r1 : r0, rz.rep);
   ulong2 v = *reinterpret_cast<const ulong2*>(acc + base + i);
   v.x = add_mod(v.x, a[base + px], q);
   v.y = add_mod(v.y, a[base + py], q);
@@ -247,15 +257,17 @@ void launch_rotate_add2(const DevCtx& c, u64* r0, u64* r1, const u64* acc0, cons
                         u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
   ACEHIP_ABLATE(ABL_ROTATE);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs, r1 ? 2 : 1), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, (r1 ? 2 : 1) * c.nrep), block(256);
   hipLaunchKernelGGL(rotate_add2_kernel, grid, block, 0, s, c, r0, r1, acc0, acc1, a0, a1, auto_k, level, pos0);
 }
 
 // r[l][n] = a[l][n] * w[l] mod prime(gi[l])   (Shoup; per-limb constants in HBM)
-__global__ __launch_bounds__(256) void mul_const_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
-                                                        const u64* __restrict__ w, const u64* __restrict__ wp,
-                                                        const u32* __restrict__ gi) {
+__global__ __launch_bounds__(256) void mul_const_kernel(DevCtx c, u64* r, const u64* a, const u64* __restrict__ w,
+                                                        const u64* __restrict__ wp, const u32* __restrict__ gi) {
   const u32 l = blockIdx.y;
+  if (!owns(c, gi[l])) return;
+  r = reb(c, r, c.rep0 + blockIdx.z);
+  a = reb(c, a, c.rep0 + blockIdx.z);
   const u64 q = c.primes[gi[l]].q, wl = w[l], wpl = wp[l];
   const size_t base = (size_t)l * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -270,7 +282,7 @@ void launch_mul_const(const DevCtx& c, u64* r, const u64* a, const u64* w, const
                       hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, c.nrep), block(256);
   hipLaunchKernelGGL(mul_const_kernel, grid, block, 0, s, c, r, a, w, wp, gi);
 }
 
@@ -285,12 +297,13 @@ constexpr int kConvGroup = 4;
 
 // n_in <= 64: 64 products below 2^122 cannot overflow the 128-bit sums.  Sources are taken in chunks of 16, the output
 // sums of the group stay in registers across chunks (the usual case is a single chunk: the loop runs once).
-__global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ in,
-                                                        const u64* __restrict__ hat, const u32* __restrict__ out_gi,
-                                                        const u32* __restrict__ out_pos, u32 n_in, u32 n_out,
-                                                        u32 hat_ld) {
+__global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* out, const u64* in, const u64* __restrict__ hat,
+                                                        const u32* __restrict__ out_gi, const u32* __restrict__ out_pos, u32 n_in,
+                                                        u32 n_out, u32 hat_ld) {
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);
+  in = reb(c, in, c.rep0 + blockIdx.z);
   const u32 j0 = blockIdx.y * kConvGroup;
   U128 acc[kConvGroup];
 #pragma unroll
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256) void base_conv_kernel(DevCtx c, u64* __restric
 #pragma unroll
   for (int g = 0; g < kConvGroup; ++g) {
     const u32 j = j0 + g;
-    if (j < n_out) {
+    if (j < n_out && owns(c, out_gi[j])) {
       const DevPrime P = c.primes[out_gi[j]];
       out[(size_t)out_pos[j] * c.N + n] = reduce128(acc[g], P.q, P.prec128_lo, P.prec128_hi);
     }
@@ -323,15 +336,17 @@ void launch_base_conv(const DevCtx& c, u64* out, const u64* in, const u64* hat, 
                       u32 n_in, u32 n_out, u32 hat_ld, hipStream_t s) {
   ACEHIP_ABLATE(ABL_CONV);
   if (n_out == 0) return;
-  dim3 grid((c.N + 255) / 256, (n_out + kConvGroup - 1) / kConvGroup), block(256);
+  dim3 grid((c.N + 255) / 256, (n_out + kConvGroup - 1) / kConvGroup, c.nrep), block(256);
   hipLaunchKernelGGL(base_conv_kernel, grid, block, 0, s, c, out, in, hat, out_gi, out_pos, n_in, n_out, hat_ld);
 }
 
 // ModDown tail (Reduce_rns_base polynomial.c:956-965): out = (x - out) * P^-1 mod q_i
-__global__ __launch_bounds__(256) void moddown_tail_kernel(DevCtx c, u64* __restrict__ out, const u64* __restrict__ x,
-                                                           const u64* __restrict__ pinv,
+__global__ __launch_bounds__(256) void moddown_tail_kernel(DevCtx c, u64* out, const u64* x, const u64* __restrict__ pinv,
                                                            const u64* __restrict__ pinv_prec) {
   const u32 l = blockIdx.y;
+  if (!owns(c, l)) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);
+  x = reb(c, x, c.rep0 + blockIdx.z);
   const u64 q = c.primes[l].q, w = pinv[l], wp = pinv_prec[l];
   const size_t base = (size_t)l * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -346,47 +361,50 @@ __global__ __launch_bounds__(256) void moddown_tail_kernel(DevCtx c, u64* __rest
 void launch_moddown_tail(const DevCtx& c, u64* out, const u64* x, const u64* pinv, const u64* pinv_prec, u32 level,
                          hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
-  dim3 grid((c.N / 2 + 255) / 256, level), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level, c.nrep), block(256);
   hipLaunchKernelGGL(moddown_tail_kernel, grid, block, 0, s, c, out, x, pinv, pinv_prec);
 }
 
 // Rescale (Rescale_poly polynomial.c:1132-1144): spread the iNTT'd last limb to every remaining limb.
 // blockIdx.z = polynomial (c0 / c1 of a ciphertext are rescaled together)
-__global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* __restrict__ t, size_t t_stride,
-                                                             const u64* __restrict__ last, size_t last_stride,
+__global__ __launch_bounds__(256) void rescale_spread_kernel(DevCtx c, u64* t, size_t t_stride, const u64* last, size_t last_stride,
                                                              const u64* __restrict__ c1, const u64* __restrict__ c1p,
                                                              u32 level) {
   const u32 l = blockIdx.y;
+  if (!owns(c, l)) return;
+  const RepZ rz = rep_of_z(c);  // blockIdx.z = polynomial + n_polys * replica
   const u64 q = c.primes[l].q, ql = c.primes[level - 1].q, w = c1[l], wp = c1p[l];
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
-  ulong2 v = *reinterpret_cast<const ulong2*>(last + blockIdx.z * last_stride + i);
+  ulong2 v = *reinterpret_cast<const ulong2*>(reb(c, last, rz.rep) + rz.z * last_stride + i);
   v.x = mul_shoup(switch_modulus(v.x, ql, q), w, wp, q);
   v.y = mul_shoup(switch_modulus(v.y, ql, q), w, wp, q);
-  *reinterpret_cast<ulong2*>(t + blockIdx.z * t_stride + (size_t)l * c.N + i) = v;
+  *reinterpret_cast<ulong2*>(reb(c, t, rz.rep) + rz.z * t_stride + (size_t)l * c.N + i) = v;
 }
 
 void launch_rescale_spread(const DevCtx& c, u64* t, size_t t_stride, const u64* last, size_t last_stride, const u64* c1,
                            const u64* c1p, u32 level, u32 n_polys, hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
-  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys * c.nrep), block(256);
   hipLaunchKernelGGL(rescale_spread_kernel, grid, block, 0, s, c, t, t_stride, last, last_stride, c1, c1p, level);
 }
 
 // Rescale tail (polynomial.c:1145-1158): out = x * q_l^-1 + t
 __global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __restrict__ out0, u64* __restrict__ out1,
                                                            const u64* __restrict__ x0, const u64* __restrict__ x1,
-                                                           const u64* __restrict__ t, size_t t_stride,
+                                                           const u64* t, size_t t_stride,
                                                            const u64* __restrict__ inv, const u64* __restrict__ invp) {
   const u32 l = blockIdx.y;
+  if (!owns(c, l)) return;
+  const RepZ rz = rep_of_z(c);
   const u64 q = c.primes[l].q, w = inv[l], wp = invp[l];
   const size_t base = (size_t)l * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
-  const u64* x = blockIdx.z ? x1 : x0;
-  u64* out = blockIdx.z ? out1 : out0;
+  const u64* x = reb(c, rz.z ? x1 : x0, rz.rep);
+  u64* out = reb(c, rz.z ? out1 : out0, rz.rep);
   const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
-  const ulong2 vt = *reinterpret_cast<const ulong2*>(t + blockIdx.z * t_stride + base + i);
+  const ulong2 vt = *reinterpret_cast<const ulong2*>(reb(c, t, rz.rep) + rz.z * t_stride + base + i);
   ulong2 vo;
   vo.x = add_mod(mul_shoup(vx.x, w, wp, q), vt.x, q);
   vo.y = add_mod(mul_shoup(vx.y, w, wp, q), vt.y, q);
@@ -396,17 +414,23 @@ __global__ __launch_bounds__(256) void rescale_tail_kernel(DevCtx c, u64* __rest
 void launch_rescale_tail(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t, size_t t_stride,
                          const u64* inv, const u64* invp, u32 level, u32 n_polys, hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
-  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level - 1, n_polys * c.nrep), block(256);
   hipLaunchKernelGGL(rescale_tail_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t, t_stride, inv, invp);
 }
 
 // key inner product for one digit (generated code inc:7011-7036 == Multiply_add polynomial.c:148-183)
 template <bool ACC>
-__global__ __launch_bounds__(256) void key_mac_kernel(DevCtx c, u64* __restrict__ acc0, u64* __restrict__ acc1,
-                                                      const u64* __restrict__ key0, const u64* __restrict__ key1,
-                                                      const u64* __restrict__ ext, u32 level) {
+__global__ __launch_bounds__(256) void key_mac_kernel(DevCtx c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext,
+                                                      u32 level) {
   const u32 pos = blockIdx.y;
   const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const u32 rep = c.rep0 + blockIdx.z;
+  acc0 = reb(c, acc0, rep);
+  acc1 = reb(c, acc1, rep);
+  key0 = reb(c, key0, rep);
+  key1 = reb(c, key1, rep);
+  ext = reb(c, ext, rep);
   const DevPrime P = c.primes[gi];
   const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(256) void key_mac_kernel(DevCtx c, u64* __restrict_
 void launch_key_mac(const DevCtx& c, u64* acc0, u64* acc1, const u64* key0, const u64* key1, const u64* ext, u32 level,
                     bool accumulate, hipStream_t s) {
   ACEHIP_ABLATE(ABL_KEYMAC);
-  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K, c.nrep), block(256);
   if (accumulate) hipLaunchKernelGGL(key_mac_kernel<true>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);
   else            hipLaunchKernelGGL(key_mac_kernel<false>, grid, block, 0, s, c, acc0, acc1, key0, key1, ext, level);
 }

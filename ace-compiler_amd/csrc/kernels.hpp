@@ -32,6 +32,17 @@ struct DevCtx {
   const u64* twp_fwd = nullptr;
   const u64* twp_inv = nullptr;
   u32 tw8_max_polys = 0;
+  // ---- replicas.  The caller's polynomial memory (the rt_ant shim's pool arena) may exist several times, rep_stride bytes
+  // apart: one copy per image of a batch (the GPU form of the reference's image-parallel loop, resnet_cifar.main.inc:77-116:
+  // B images run through the same launches and share every key, twiddle, bootstrap diagonal and weight plaintext), or one
+  // copy per simulated rank of limb-sharded execution.  A launch covers replicas [rep0, rep0 + nrep): every pointer that lies
+  // in [rep_lo, rep_lo + rep_span) is taken rep * rep_stride further by the workgroups of replica rep (reb() below); pointers
+  // outside (keys, tables, plaintexts shared by all images) are used as they are.  nrep = 1, rep0 = 0: the plain case.
+  u64 rep_lo = 0, rep_span = 0, rep_stride = 0;
+  u32 rep0 = 0, nrep = 1;
+  // ---- limb ownership (limb-sharded execution): the launch touches only the limbs whose prime index gi has
+  // gi % sh_world == sh_rank; polynomials keep their full layout, the other limbs are simply not this rank's business
+  u32 sh_rank = 0, sh_world = 1;
 };
 
 // prime (global index) of the limb at position pos of a polynomial extended at `level`
@@ -45,6 +56,22 @@ __host__ __device__ inline u32 limb_prime(u32 pos, u32 level, u32 L) { return po
 // across a kernel boundary, so there is nothing to gain from pinning a limb's two passes to one XCD (tried: same
 // FETCH_SIZE, worse balance).  Placement only affects speed; any mapping is correct.
 #ifdef __HIPCC__
+// pointer p as replica `rep` sees it (rep = absolute replica index)
+template <class T>
+__device__ __forceinline__ T* reb(const DevCtx& c, T* p, u32 rep) {
+  const u64 a = (u64)p;
+  return (a - c.rep_lo < c.rep_span) ? (T*)(a + (u64)rep * c.rep_stride) : p;
+}
+__device__ __forceinline__ bool owns(const DevCtx& c, u32 gi) { return c.sh_world <= 1 || gi % c.sh_world == c.sh_rank; }
+// launches that put the replica into blockIdx.z (grid.z = nz * nrep): the kernel's own z and the replica
+struct RepZ {
+  u32 z, rep;
+};
+__device__ __forceinline__ RepZ rep_of_z(const DevCtx& c) {
+  if (c.nrep == 1) return RepZ{blockIdx.z, c.rep0};
+  const u32 nz = gridDim.z / c.nrep, r = blockIdx.z / nz;
+  return RepZ{blockIdx.z - r * nz, c.rep0 + r};
+}
 struct NttBlk {
   u32 tile, y, z;
 };
@@ -152,7 +179,8 @@ void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_l
 // elementwise over limb positions
 void launch_ew(const DevCtx& c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n_limbs, hipStream_t s,
                u32 pos_off = 0);
-void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 pos0, u32 n_limbs, hipStream_t s);
+// level: the limbs are positions [pos0, pos0 + n_limbs) of a polynomial extended at `level` (ownership filter only)
+void launch_rotate(const DevCtx& c, u64* r, const u64* a, const u32* perm, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // r_z = acc_z + automorphism_k(a_z) for one (r1 == nullptr) or two polynomials, limbs [pos0, pos0 + n_limbs) at `level`
 void launch_rotate_add2(const DevCtx& c, u64* r0, u64* r1, const u64* acc0, const u64* acc1, const u64* a0, const u64* a1, u32 auto_k,
                         u32 level, u32 pos0, u32 n_limbs, hipStream_t s);

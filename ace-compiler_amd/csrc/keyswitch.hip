@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
                                                               const u64* __restrict__ in, size_t in_stride,
                                                               const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
   __shared__ uint2 s_hat[kConvMaxIn * kGroup];  // this row's constants, already split: {low half, high half}
-  const ConvDesc d = descs[blockIdx.z * desc_step];
+  const RepZ rz = rep_of_z(c);  // blockIdx.z = problem + n_problems * replica
+  const ConvDesc d = descs[rz.z * desc_step];
   const u32 j0 = blockIdx.y * kGroup;
   if (j0 >= d.n_out) return;  // uniform for the workgroup
   const u32 h = c.split_bits, mask = (1u << h) - 1u;
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
   __syncthreads();
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
-  const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + n;
-  u64* dst = (outz.p[0] ? outz.p[blockIdx.z] : out + blockIdx.z * out_stride) + n;
+  const u64* src = reb(c, in, rz.rep) + rz.z * in_stride + (size_t)d.src_pos0 * c.N + n;
+  u64* dst = reb(c, outz.p[0] ? outz.p[rz.z] : out + rz.z * out_stride, rz.rep) + n;
   const u32 chunk = h <= 30 ? 16u : (h == 31 ? 4u : 1u);  // terms whose partial products fit 64-bit sums
   unsigned __int128 tot[kGroup];
   u64 s00[kGroup], s01[kGroup], s10[kGroup], s11[kGroup];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void base_conv_batch_kernel(DevCtx c, u64* __r
 #pragma unroll
   for (int g = 0; g < kGroup; ++g) {
     const u32 j = j0 + g;
-    if (j < d.n_out) {
+    if (j < d.n_out && owns(c, d.out_gi[j])) {  // (limb-sharded: the other ranks' outputs are not stored)
       const DevPrime& P = c.primes[d.out_gi[j]];
       dst[(size_t)d.out_pos[j] * c.N] = reduce128(U128{(u64)tot[g], (u64)(tot[g] >> 64)}, P.q, P.prec128_lo, P.prec128_hi);
     }
@@ -85,14 +86,15 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
   constexpr u32 kIn = 16;
   __shared__ uint2 s_hat[kIn * kGroup];
   __shared__ u64 s_q[kGroup], s_ml[kGroup], s_mh[kGroup];
-  __shared__ u32 s_pos[kGroup];
-  const ConvDesc d = descs[blockIdx.z * desc_step];
+  __shared__ u32 s_pos[kGroup], s_own[kGroup];
+  const RepZ rz = rep_of_z(c);
+  const ConvDesc d = descs[rz.z * desc_step];
   const u32 j0 = blockIdx.y * kGroup;
   if (j0 >= d.n_out) return;  // uniform for the workgroup
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   const bool active = n < c.N;
   const u32 h = c.split_bits, mask = (1u << h) - 1u;
-  const u64* src = in + blockIdx.z * in_stride + (size_t)d.src_pos0 * c.N + (active ? n : 0);
+  const u64* src = reb(c, in, rz.rep) + rz.z * in_stride + (size_t)d.src_pos0 * c.N + (active ? n : 0);
   u64 y[kIn];
 #pragma unroll
   for (u32 i = 0; i < kIn; ++i) y[i] = i < d.n_in ? src[(size_t)i * c.N] : 0;
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
     s_ml[threadIdx.x] = P.prec128_lo;
     s_mh[threadIdx.x] = P.prec128_hi;
     s_pos[threadIdx.x] = d.out_pos[j];
+    s_own[threadIdx.x] = owns(c, d.out_gi[j]);  // (limb-sharded: the other ranks' outputs are not stored)
   }
   __syncthreads();
   if (!active) return;
@@ -129,10 +132,10 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
       s11[g] += (u64)a1 * b.y;
     }
   }
-  u64* dst = (outz.p[0] ? outz.p[blockIdx.z] : out + blockIdx.z * out_stride) + n;
+  u64* dst = reb(c, outz.p[0] ? outz.p[rz.z] : out + rz.z * out_stride, rz.rep) + n;
 #pragma unroll
   for (int g = 0; g < kGroup; ++g) {
-    if (j0 + g < d.n_out) {
+    if (j0 + g < d.n_out && s_own[g]) {
       const unsigned __int128 tot =
           (unsigned __int128)s00[g] + (((unsigned __int128)s01[g] + s10[g]) << h) + ((unsigned __int128)s11[g] << (2 * h));
       dst[(size_t)s_pos[g] * c.N] = reduce128(U128{(u64)tot, (u64)(tot >> 64)}, s_q[g], s_ml[g], s_mh[g]);
@@ -145,7 +148,7 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
                             const PtrTab8& outz) {
   ACEHIP_ABLATE(ABL_CONV);
   if (n_problems == 0 || max_n_out == 0) return;
-  dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems), block(256);
+  dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems * c.nrep), block(256);
   if (max_n_in != 0 && max_n_in <= 16 && c.split_bits <= 30)
     hipLaunchKernelGGL(base_conv_batch16_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
   else
@@ -154,12 +157,19 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
 
 // acc{0,1}[pos][n] = sum_d key{0,1}[d][gi][n] * e_d[pos][n];  key layout [nd][2][L+K][N]
 // add0 (may be null): acc0[pos] += add0[pos] * w.w[pos] on the q-limbs -- the "+ P*c0" of Fast_rotate_ext (ckks_evaluator.c:539-575)
-__global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __restrict__ acc0, u64* __restrict__ acc1,
-                                                            const u64* __restrict__ key, const u64* __restrict__ ext,
-                                                            size_t ext_stride, const u64* __restrict__ in, u32 level,
-                                                            u32 nd, u32 alpha, const u64* __restrict__ add0, LimbConsts w) {
+__global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* acc0, u64* acc1, const u64* key, const u64* ext,
+                                                            size_t ext_stride, const u64* in, u32 level, u32 nd, u32 alpha,
+                                                            const u64* add0, LimbConsts w) {
   const u32 pos = blockIdx.y;
   const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const u32 rep = c.rep0 + blockIdx.z;
+  acc0 = reb(c, acc0, rep);
+  acc1 = reb(c, acc1, rep);
+  key = reb(c, key, rep);
+  ext = reb(c, ext, rep);
+  in = reb(c, in, rep);
+  add0 = reb(c, add0, rep);
   const DevPrime P = c.primes[gi];
   const size_t T = c.L + c.K;
   const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* __res
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0, const LimbConsts* w) {
   ACEHIP_ABLATE(ABL_KEYMAC);
-  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K, c.nrep), block(256);
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0,
                      w ? *w : LimbConsts{});
 }
@@ -211,6 +221,8 @@ template <int G>
 __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u32 level) {
   const u32 pos = blockIdx.y;
   const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const u32 rep = c.rep0 + blockIdx.z;
   const DevPrime& P = c.primes[gi];
   const u64 q = P.q, ml = P.prec128_lo, mh = P.prec128_hi;
   const size_t ct_off = (size_t)pos * c.N;  // PQ-extended ciphertext: p-limbs follow the q-limbs
@@ -225,14 +237,15 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
   for (int j = 0; j < G; ++j) {
     if (j < (int)a.g) {
       const u32 k = a.in_auto[j];
+      const u64 *in0 = reb(c, a.in0[j], rep), *in1 = reb(c, a.in1[j], rep);
       if (k == 0) {
-        r0[j] = *reinterpret_cast<const ulong2*>(a.in0[j] + ct_off + i);
-        r1[j] = *reinterpret_cast<const ulong2*>(a.in1[j] + ct_off + i);
+        r0[j] = *reinterpret_cast<const ulong2*>(in0 + ct_off + i);
+        r1[j] = *reinterpret_cast<const ulong2*>(in1 + ct_off + i);
       } else {  // rotated input: in[perm_k(i)], perm_k(i) = rev(((2 rev(i) + 1) k mod 2N) / 2)  (automorphism_order_ntt)
         const u32 px = __brev((((2 * b0 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
         const u32 py = __brev((((2 * b1 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
-        r0[j] = ulong2{a.in0[j][ct_off + px], a.in0[j][ct_off + py]};
-        r1[j] = ulong2{a.in1[j][ct_off + px], a.in1[j][ct_off + py]};
+        r0[j] = ulong2{in0[ct_off + px], in0[ct_off + py]};
+        r1[j] = ulong2{in1[ct_off + px], in1[ct_off + py]};
       }
     }
   }
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
     U128 s0x{0, 0}, s0y{0, 0}, s1x{0, 0}, s1y{0, 0};
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      const u64* pt = j < (int)a.g ? a.pt[bi * a.g + j] : nullptr;
+      const u64* pt = j < (int)a.g ? reb(c, a.pt[bi * a.g + j], rep) : nullptr;
       if (pt != nullptr) {  // a missing diagonal (giant + j == num_rot) contributes nothing
         const ulong2 p = *reinterpret_cast<const ulong2*>(pt + pt_off + i);
         mac128(s0x, r0[j].x, p.x);
@@ -254,14 +267,14 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
     o0.y = reduce128(s0y, q, ml, mh);
     o1.x = reduce128(s1x, q, ml, mh);
     o1.y = reduce128(s1y, q, ml, mh);
-    *reinterpret_cast<ulong2*>(a.out0[bi] + ct_off + i) = o0;
-    *reinterpret_cast<ulong2*>(a.out1[bi] + ct_off + i) = o1;
+    *reinterpret_cast<ulong2*>(reb(c, a.out0[bi], rep) + ct_off + i) = o0;
+    *reinterpret_cast<ulong2*>(reb(c, a.out1[bi], rep) + ct_off + i) = o1;
   }
 }
 
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
   ACEHIP_ABLATE(ABL_BSGS);
-  dim3 grid((c.N / 2 + 255) / 256, level + c.K), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level + c.K, c.nrep), block(256);
   if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
   else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
   else               hipLaunchKernelGGL((bsgs_inner_kernel<16>), grid, block, 0, s, c, a, level);
@@ -273,13 +286,15 @@ __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __res
                                                             const u64* __restrict__ pinv,
                                                             const u64* __restrict__ pinv_prec) {
   const u32 l = blockIdx.y;
+  if (!owns(c, l)) return;
+  const RepZ rz = rep_of_z(c);
   const u64 q = c.primes[l].q, w = pinv[l], wp = pinv_prec[l];
   const size_t base = (size_t)l * c.N;
   const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
-  const u64* x = blockIdx.z ? x1 : x0;
-  const u64* t = blockIdx.z ? t1 : t0;
-  u64* o = blockIdx.z ? out1 : out0;
+  const u64* x = reb(c, rz.z ? x1 : x0, rz.rep);
+  const u64* t = reb(c, rz.z ? t1 : t0, rz.rep);
+  u64* o = reb(c, rz.z ? out1 : out0, rz.rep);
   const ulong2 vx = *reinterpret_cast<const ulong2*>(x + base + i);
   ulong2 vt = *reinterpret_cast<const ulong2*>(t + base + i);
   vt.x = mul_shoup(sub_mod(vx.x, vt.x, q), w, wp, q);
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __res
 void launch_moddown_tail2(const DevCtx& c, u64* out0, u64* out1, const u64* x0, const u64* x1, const u64* t0,
                           const u64* t1, const u64* pinv, const u64* pinv_prec, u32 level, hipStream_t s, u32 n_polys) {
   ACEHIP_ABLATE(ABL_OTHER);
-  dim3 grid((c.N / 2 + 255) / 256, level, n_polys), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, level, n_polys * c.nrep), block(256);
   hipLaunchKernelGGL(moddown_tail2_kernel, grid, block, 0, s, c, out0, out1, x0, x1, t0, t1, pinv, pinv_prec);
 }
 

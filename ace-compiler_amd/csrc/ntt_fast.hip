@@ -388,8 +388,8 @@ struct StridedArgs {
 // converted limbs are never written in coefficient form; 16 sources would spill registers: those take the separate kernel)
 enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV8 = 8, SRC_CONV12 = 12 };
 template <bool SMALL, int SRC>
-__device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos, u32 row, u32 z,
-                                                 u32 n_bytes, u32 split_bits) {
+__device__ __forceinline__ void strided_fwd_body(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
+                                                 u32 row, u32 z, u32 rep, u32 n_bytes, u32 split_bits) {
   constexpr bool FROM_MSG = SRC == SRC_MSG;
   const u64 q = a.q;
   const BfK bk = bf_consts<SMALL>(q);
@@ -398,7 +398,7 @@ __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const Dev
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch (no hoisting / merging across paths)
   if (FROM_MSG) {  // the signed message, reduced mod this limb's prime (and scaled): Encode_impl ckks_encoder.c:262-285
     const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
-    const LimbBuf mbuf = limb_buf(reinterpret_cast<const u64*>(f.msg + z * f.msg_stride), n_bytes);
+    const LimbBuf mbuf = limb_buf(reinterpret_cast<const u64*>(reb(c, f.msg, rep) + z * f.msg_stride), n_bytes);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int64_t v = (int64_t)bld(mbuf, (a.hg << 11) + a.col * 8, (u32)k << 15);
@@ -419,7 +419,7 @@ __device__ __forceinline__ void strided_fwd_body(const StridedArgs& a, const Dev
     const u32 n_in = d.n_in, jcol = d.col ? d.col[row] : row;
     if (d.out_pos[row] != pos) __builtin_trap();  // the launch must enumerate the limbs like the descriptor does
     const u32 h = split_bits, mask = (1u << h) - 1u;
-    const LimbBuf sbuf = limb_buf(f.conv_src + z * f.conv_src_stride, (d.src_pos0 + n_in) * n_bytes);
+    const LimbBuf sbuf = limb_buf(reb(c, f.conv_src, rep) + z * f.conv_src_stride, (d.src_pos0 + n_in) * n_bytes);
     u32 b0[NI], b1[NI], soff[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -515,7 +515,14 @@ __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulon
 // One resolved workgroup of a pass: tile of limb row y of polynomial z, the limb's position / prime
 struct NttWg {
   u32 tile, y, z, pos, gi;
+  u32 rep;  // replica (kernels.hpp DevCtx): the launch's polynomial index is z + n_polys * (rep - rep0)
 };
+// polynomial index of the launch -> polynomial of the call and replica
+__device__ __forceinline__ void ntt_split_z(NttWg& w, const DevCtx& c, u32 n_polys) {
+  const u32 r = c.nrep == 1 ? 0 : w.z / n_polys;
+  w.z -= r * n_polys;
+  w.rep = c.rep0 + r;
+}
 // limb row (y, z) of the launch -> position and prime; false: the row does not exist (a digit's own limbs, grid padding)
 __device__ __forceinline__ bool ntt_resolve(NttWg& w, const DevCtx& c, const NttFuse& f, u32 level, u32 pos0, u32 skip_alpha) {
   u32 pos, gi;
@@ -528,7 +535,7 @@ __device__ __forceinline__ bool ntt_resolve(NttWg& w, const DevCtx& c, const Ntt
   }
   w.pos = __builtin_amdgcn_readfirstlane(pos);  // wave-uniform: prime constants and base pointers live in SGPRs
   w.gi = __builtin_amdgcn_readfirstlane(gi);
-  return true;
+  return owns(c, w.gi);  // limb-sharded execution: the other ranks' limbs are skipped
 }
 
 // STRIDED pass of one workgroup.  SRC (forward only): source of the first pass' input, see strided_fwd_body.
@@ -537,14 +544,14 @@ __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ 
                                              u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
-  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(w.pos - pos_off) * c.N;
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(w.pos - pos_off) * c.N;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
   const u32 col = w.tile * 16 + cc;  // N = 2^16 only (launch_ntt_fused): constant row stride, addresses = one base + immediates
   if (!INVERSE) {
     const StridedArgs a{limb_buf(X, c.N * 8), TW, lds, cc, hg, col, q};
-    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
-    else                     strided_fwd_body<false, SRC>(a, P, f, w.pos, w.y, w.z, c.N * 8, c.split_bits);
+    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
+    else                     strided_fwd_body<false, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
   } else {
     if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, w.pos, cc, hg, col);
     else                     strided_inv_body<false>(X, TW, lds, P, f, w.pos, cc, hg, col);
@@ -559,8 +566,9 @@ __global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __r
 #if NTT_EXP & 8
   if (SRC != SRC_MSG) return;
 #endif
-  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
-  NttWg w{blk.tile, blk.y, blk.z, 0, 0};
+  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys * c.nrep);
+  NttWg w{blk.tile, blk.y, blk.z, 0, 0, 0};
+  ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   strided_pass<INVERSE, SRC>(c, poly, poly_stride, pos_off, f, lds, w);
 }
@@ -668,7 +676,7 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
   const u32 pos = w.pos;
-  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const u64* __restrict__ TP = TW8 ? (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N : nullptr;
   const u32 s8 = c.logN - 8;
@@ -684,8 +692,8 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
     __syncthreads();
     const size_t tail_off = (size_t)pos * c.N + (size_t)w.tile * 4096;  // q-limb `pos` of x_z / out_z
-    const u64* __restrict__ xin = FUSE ? (w.z ? f.x1 : f.x0) + tail_off : nullptr;
-    u64* __restrict__ dst = FUSE ? (w.z ? f.out1 : f.out0) + tail_off : X;
+    const u64* __restrict__ xin = FUSE ? reb(c, w.z ? f.x1 : f.x0, w.rep) + tail_off : nullptr;
+    u64* __restrict__ dst = FUSE ? reb(c, w.z ? f.out1 : f.out0, w.rep) + tail_off : X;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte stores
@@ -712,7 +720,7 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
     }
   } else {
     const u64* __restrict__ S =
-        FUSE ? (w.z ? f.src1 : f.src0) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
+        FUSE ? reb(c, w.z ? f.src1 : f.src0, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
     if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
     else                     contig_inv_body<false, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
   }
@@ -723,8 +731,9 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                           u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[16 * kBlkPitch];
-  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys);
-  NttWg w{blk.tile, blk.y, blk.z, 0, 0};
+  const NttBlk blk = ntt_block(c.logN - 12, n_limbs, n_polys * c.nrep);
+  NttWg w{blk.tile, blk.y, blk.z, 0, 0, 0};
+  ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   contig_pass<INVERSE, CANON_OUT, FUSE, TW8>(c, poly, poly_stride, pos_off, f, lds, w);
 }
@@ -789,7 +798,7 @@ __device__ __forceinline__ void radix4_inv(u64 (&x)[4], const Tw3& t, const BfK&
 // ---- strided narrow pass (stages 0..7).  lds: 256 * kNarrowPitch words.
 template <bool SMALL, bool INVERSE, int SRC>
 __device__ __forceinline__ void strided4_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
-                                              const NttFuse& f, u32 pos, u32 z, u32 tile, u64 q, u32 n_words) {
+                                              const NttFuse& f, const int64_t* __restrict__ M, u32 pos, u32 tile, u64 q, u32 n_words) {
   const BfK bk = bf_consts<SMALL>(q);
   const u32 t = threadIdx.x, c = t & 3, g = t >> 2;
   const u32 col = tile * 4 + c;
@@ -804,7 +813,6 @@ __device__ __forceinline__ void strided4_body(u64* __restrict__ X, const ulong2*
   if (!INVERSE) {
     if (SRC == SRC_MSG) {  // Encode_impl ckks_encoder.c:262-285, as in strided_fwd_body
       const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
-      const int64_t* __restrict__ M = f.msg + z * f.msg_stride;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t v = M[(size_t)(g + 64 * k) * 256 + col];
@@ -898,23 +906,26 @@ __global__ __launch_bounds__(256) void ntt4_strided_kernel(DevCtx c, u64* __rest
   // the 4 tiles that share the 128-byte lines of a row (tile = 4*line + r) get block ids congruent mod 8: one XCD's L2
   const u32 b = blockIdx.x, xl = b & 7u, m = b >> 3;
   const u32 tile = 4 * (xl + 8 * ((m >> 2) & 1u)) + (m & 3u), rowi = m >> 3;
-  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0};
+  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0, 0};
   w.y = __builtin_amdgcn_readfirstlane(w.y);
   w.z = __builtin_amdgcn_readfirstlane(w.z);
+  ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
-  u64* __restrict__ X = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + (size_t)(w.pos - pos_off) * c.N;
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(w.pos - pos_off) * c.N;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
-  if (q <= kSmallPrimeMax) strided4_body<true, INVERSE, SRC>(X, TW, lds, P, f, w.pos, w.z, w.tile, q, c.N);
-  else                     strided4_body<false, INVERSE, SRC>(X, TW, lds, P, f, w.pos, w.z, w.tile, q, c.N);
+  const int64_t* M = SRC == SRC_MSG ? reb(c, f.msg, w.rep) + w.z * f.msg_stride : nullptr;
+  if (q <= kSmallPrimeMax) strided4_body<true, INVERSE, SRC>(X, TW, lds, P, f, M, w.pos, w.tile, q, c.N);
+  else                     strided4_body<false, INVERSE, SRC>(X, TW, lds, P, f, M, w.pos, w.tile, q, c.N);
 }
 
 // ---- contiguous narrow pass (stages 8..15): one wave per 256-coefficient block, `wl` = the wave's 256-word LDS region
 // (+ 8 words of padding between the regions)
 template <bool SMALL, bool INVERSE, int FUSE>
 __device__ __forceinline__ void contig4_body(u64* __restrict__ Xb, const u64* __restrict__ Sb, const ulong2* __restrict__ TW, u64* wl,
-                                             const DevPrime& P, const NttFuse& f, u32 pos, u32 z, u32 o, u64 q, size_t tail_off) {
+                                             const DevPrime& P, const NttFuse& f, const u64* x_z, u64* out_z, u32 pos, u32 o, u64 q,
+                                             size_t tail_off) {
   const BfK bk = bf_consts<SMALL>(q);
   const u32 l = threadIdx.x & 63;
   const u32 c2 = l >> 4, j2 = l & 15, c3 = l >> 2, j3 = l & 3;
@@ -956,8 +967,8 @@ __device__ __forceinline__ void contig4_body(u64* __restrict__ Xb, const u64* __
 #pragma unroll
     for (int k = 0; k < 4; ++k) x[k] = canon_fwd<SMALL>(x[k], q, P.prec128_hi);
     // the lane holds 4 contiguous coefficients: 32 bytes, two 16-byte accesses (Rescale / ModDown tails as in contig_pass)
-    const u64* __restrict__ xin = FUSE ? (z ? f.x1 : f.x0) + tail_off + 4 * l : nullptr;
-    u64* __restrict__ dst = FUSE ? (z ? f.out1 : f.out0) + tail_off + 4 * l : Xb + 4 * l;
+    const u64* __restrict__ xin = FUSE ? x_z + tail_off + 4 * l : nullptr;
+    u64* __restrict__ dst = FUSE ? out_z + tail_off + 4 * l : Xb + 4 * l;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1019,29 +1030,32 @@ __global__ __launch_bounds__(256) void ntt4_contig_kernel(DevCtx c, u64* __restr
                                                        u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[4 * 264];
   const u32 b = blockIdx.x, tile = b & 63u, rowi = b >> 6;
-  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0};
+  NttWg w{tile, rowi % n_limbs, rowi / n_limbs, 0, 0, 0};
   w.y = __builtin_amdgcn_readfirstlane(w.y);
   w.z = __builtin_amdgcn_readfirstlane(w.z);
+  ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   const DevPrime& P = c.primes[w.gi];
   const u64 q = uniform64(P.q);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 o = w.tile * 4 + wave;  // 256-coefficient block of the limb
   const size_t limb_off = (size_t)(w.pos - pos_off) * c.N + (size_t)o * 256;
-  u64* __restrict__ Xb = (f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride) + limb_off;
-  const u64* __restrict__ Sb = (INVERSE && FUSE) ? (w.z ? f.src1 : f.src0) + limb_off : Xb;
+  u64* __restrict__ Xb = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + limb_off;
+  const u64* __restrict__ Sb = (INVERSE && FUSE) ? reb(c, w.z ? f.src1 : f.src0, w.rep) + limb_off : Xb;
+  const u64* xin = (!INVERSE && FUSE) ? reb(c, w.z ? f.x1 : f.x0, w.rep) : nullptr;
+  u64* xout = (!INVERSE && FUSE) ? reb(c, w.z ? f.out1 : f.out0, w.rep) : nullptr;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const size_t tail_off = (size_t)w.pos * c.N + (size_t)o * 256;
   u64* wl = lds + wave * 264;
-  if (q <= kSmallPrimeMax) contig4_body<true, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, w.pos, w.z, o, q, tail_off);
-  else                     contig4_body<false, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, w.pos, w.z, o, q, tail_off);
+  if (q <= kSmallPrimeMax) contig4_body<true, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, xin, xout, w.pos, o, q, tail_off);
+  else                     contig4_body<false, INVERSE, FUSE>(Xb, Sb, TW, wl, P, f, xin, xout, w.pos, o, q, tail_off);
 }
 
 // small launches take the narrow passes: at most c.ntt_narrow_max_rows limb rows (limbs x polynomials)
 static bool launch_ntt_narrow(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                               u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
-  if (n_limbs * n_polys > c.ntt_narrow_max_rows || f.conv != nullptr) return false;
-  dim3 block(256), grid(64 * n_limbs * n_polys);
+  if (n_limbs * n_polys * c.nrep > c.ntt_narrow_max_rows || f.conv != nullptr) return false;
+  dim3 block(256), grid(64 * n_limbs * n_polys * c.nrep);
 #define ACEHIP_N4_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg) hipLaunchKernelGGL((ntt4_strided_kernel<false, SRC_MSG>), ACEHIP_N4_ARGS);
@@ -1070,8 +1084,8 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   ACEHIP_ABLATE(ABL_NTT);
   if (n_limbs == 0) return;
   if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
-  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);  // 1-D: ntt_block() maps it XCD-aware
-  const bool tw8 = c.twp_fwd != nullptr && n_polys <= c.tw8_max_polys;  // few polynomials share the twiddles: 8-byte stream
+  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys * c.nrep);  // 1-D: ntt_block() maps it XCD-aware
+  const bool tw8 = c.twp_fwd != nullptr && n_polys * c.nrep <= c.tw8_max_polys;  // few polynomials share the twiddles: 8-byte stream
 #define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
@@ -1103,7 +1117,7 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
 void launch_ntt_contig8(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
                         u32 pos_off, u32 n_polys, size_t poly_stride, u32 skip_alpha) {
   ACEHIP_ABLATE(ABL_NTT);
-  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys);
+  dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys * c.nrep);
   const NttFuse f{};
   if (!inverse) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys);
   else          hipLaunchKernelGGL((ntt8_contig_kernel<true, true, 0>), grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys);

@@ -335,6 +335,7 @@ Precom* bootstrap_setup(u32 num_slots) {
   auto it = g_precom.find(slots);
   if (it != g_precom.end()) return it->second;
   SharedAllocScope shared_plaintexts;  // the encoded diagonals outlive this thread's pool
+  UniformScope shared_by_all_images;   // ... and serve every image of a batch: encoded once
   Precom* pre = new Precom();
   pre->slots = slots;
   u32 budget[2] = {3, 3};
@@ -410,6 +411,7 @@ void bootstrap_keygen(Precom* pre) {
   std::lock_guard<std::recursive_mutex> lk(shared_mu());
   if (pre->keys) return;
   Context& c = ctx();
+  UniformScope shared_by_all_images;
   const u32 m = 2 * c.N;
   std::set<int32_t> idx;
   find_rot_index(idx, pre, pre->slots, m, true);

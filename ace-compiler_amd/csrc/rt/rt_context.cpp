@@ -116,7 +116,9 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   auto it = prim.auto_keys.find(auto_idx);
   if (it != prim.auto_keys.end()) return it->second;
   RT_ASSERT(!(prim.keys_loaded && prim.keys_strict), "automorphism key %u is not in the loaded key file (ACEHIP_KEYS_STRICT)", auto_idx);
+  RT_ASSERT(c.sk_ntt != nullptr, "automorphism key %u is not in the loaded evaluation-only key set (it cannot be made without the secret key)", auto_idx);
   const u32 T = c.L + c.K;
+  UniformScope shared_by_all_images;  // (one key, whatever the batch: its blocks lie outside the arena)
   // k^-1 mod 2N (k odd): k^(N-1)
   u64 inv = 1, base = auto_idx, e = c.N - 1, m = 2ull * c.N;
   for (; e; e >>= 1) {
@@ -146,6 +148,67 @@ u32 ensure_rot_key(int32_t rotation) {
   return k;
 }
 
+// ACEHIP_SHARD=1: the processes of a launcher (torchrun, mpirun: RANK / WORLD_SIZE / LOCAL_RANK in the environment) are the ranks
+// of ONE limb-sharded computation: each owns the limbs gi % WORLD_SIZE == RANK on its own GPU.  Rank 0 creates the RCCL id and
+// publishes it in a file every rank of the node can read (ACEHIP_SHARD_ID_FILE, default /tmp/acehip_rccl_<MASTER_PORT>.id); a
+// caller that has its own channel passes the id with Acehip_rt_shard_connect instead.  All ranks must use the same ACEHIP_SEED
+// (keys and encryption randomness are derived per rank from the same stream); without one it is taken from the id.
+static void shard_connect(u32 rank, u32 world, const unsigned char* id) {
+  Context& c = ctx();
+  RT_ASSERT(c.batch == 1 || true, "batch");
+  const int rc = acehip_ctx_shard_rccl(c.hip, rank, world, id, 128);
+  RT_ASSERT(rc >= 0, "acehip_ctx_shard_rccl: %s", acehip_last_error());
+  c.shard_world = world;
+  c.shard_rank = rank;
+  if (getenv("ACEHIP_SEED") == nullptr) {  // the same randomness on every rank
+    u64 seed = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 128; ++i) seed = (seed ^ id[i]) * 0x100000001B3ull;
+    c.rng.seed(seed);
+    c.seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
+  }
+}
+void shard_connect_if_asked() {
+  const char* on = getenv("ACEHIP_SHARD");
+  if (on == nullptr || atoi(on) == 0) return;
+  const char* r = getenv("RANK");
+  const char* w = getenv("WORLD_SIZE");
+  RT_ASSERT(r != nullptr && w != nullptr, "ACEHIP_SHARD=1 needs RANK and WORLD_SIZE (torchrun / mpirun)");
+  const u32 rank = (u32)atoi(r), world = (u32)atoi(w);
+  RT_ASSERT(world >= 1 && rank < world, "bad RANK / WORLD_SIZE");
+  std::string path;
+  if (const char* f = getenv("ACEHIP_SHARD_ID_FILE")) path = f;
+  else path = std::string("/tmp/acehip_rccl_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+  unsigned char id[128];
+  if (rank == 0) {
+    const int n = acehip_rccl_unique_id(id, sizeof id);
+    RT_ASSERT(n == 128, "acehip_rccl_unique_id: %s", acehip_last_error());
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    RT_ASSERT(f != nullptr && fwrite(id, 1, 128, f) == 128, "cannot write %s", tmp.c_str());
+    fclose(f);
+    RT_ASSERT(rename(tmp.c_str(), path.c_str()) == 0, "cannot publish %s", path.c_str());
+  } else {
+    size_t got = 0;
+    for (int tries = 0; tries < 6000 && got != 128; ++tries) {  // up to a minute
+      FILE* f = fopen(path.c_str(), "rb");
+      if (f) {
+        got = fread(id, 1, 128, f);
+        fclose(f);
+      }
+      if (got != 128) {
+        struct timespec ts = {0, 10 * 1000 * 1000};
+        nanosleep(&ts, nullptr);
+      }
+    }
+    RT_ASSERT(got == 128, "rank %u: no RCCL id in %s", rank, path.c_str());
+  }
+  shard_connect(rank, world, id);
+  if (rank == 0 && world > 1) {
+    // (the file is removed once every rank has joined: ncclCommInitRank returns only then)
+    remove(path.c_str());
+  }
+}
+
 void generate_keys() {
   Context& c = ctx();
   const u32 T = c.L + c.K;
@@ -172,7 +235,7 @@ void generate_keys() {
   q_ew(ACEHIP_HW_SUB, c.pk0, (u64*)e._data, c.pk0, c.L, 0, c.L);
   poly_free(&e);
   // relinearisation key (Generate_relin_key :204-216): new = s^2 (q-limbs; p-limbs stay 0), old = s
-  u64* s2 = dalloc((size_t)T * N, true);
+  u64* s2 = dalloc((size_t)T * N, true, c.L);
   q_ew(ACEHIP_HW_MUL, s2, c.sk_ntt, c.sk_ntt, c.L, 0, c.L);
   SwitchKeyStore* rk = make_switch_key(s2, c.sk_ntt);
   dfree(s2);
@@ -204,6 +267,7 @@ void Prepare_context() {
   c->prm = prm;
   int dev = 0;
   if (const char* e = getenv("ACEHIP_DEVICE")) dev = atoi(e);
+  else if (getenv("ACEHIP_SHARD") && atoi(getenv("ACEHIP_SHARD")) != 0 && getenv("LOCAL_RANK")) dev = atoi(getenv("LOCAL_RANK"));  // one GPU per rank
   c->hip = acehip_ctx_create(prm->_poly_degree, (uint32_t)prm->_mul_depth + 1, (uint32_t)prm->_first_mod_size,
                              (uint32_t)prm->_scaling_mod_size, (uint32_t)prm->_num_q_parts, dev);
   RT_ASSERT(c->hip != nullptr, "acehip_ctx_create failed: %s", acehip_last_error());
@@ -247,8 +311,19 @@ void Prepare_context() {
   c->rot_group[0] = 1;
   for (size_t i = 1; i < c->N / 2; ++i) c->rot_group[i] = (u32)((5ull * c->rot_group[i - 1]) % m);
   c->profile = getenv("ACEHIP_PROFILE") != nullptr;
+  if (const char* e = getenv("ACEHIP_BATCH")) c->batch = std::max(1, atoi(e));
+  if (const char* e = getenv("ACEHIP_SHARD_SIM")) {  // G simulated ranks on this GPU (tests): rank r's limbs in replica r
+    const int g = atoi(e);
+    RT_ASSERT(g >= 1 && g <= 16, "ACEHIP_SHARD_SIM: 1..16 simulated ranks");
+    if (g > 1) {
+      c->shard_world = (u32)g;
+      c->shard_sim = true;
+      RT_ASSERT(c->batch == 1, "ACEHIP_SHARD_SIM and ACEHIP_BATCH exclude each other");
+    }
+  }
   g_ctx = c;
   g_primary = c;
+  shard_connect_if_asked();  // ACEHIP_SHARD=1: this process is rank RANK of WORLD_SIZE (RCCL over xGMI)
   // first stdout line parsed by scripts/perf.py:266-276 (context.c:49-57)
   printf("ckks_param: _provider = %d, _poly_degree = %d, _sec_level = %ld, mul_depth = %ld, _first_mod_size = %ld, "
          "_scaling_mod_size = %ld, _num_q_parts = %ld, _num_p = %ld, _num_rot_idx = %ld,_hamming_wieght = %ld\n",
@@ -264,14 +339,18 @@ void Prepare_context() {
     have_keys = rc == 0;
     if (!have_keys) c->keys_save_path = kfile;  // does not exist yet: written by Finalize_context
   }
-  if (!have_keys) generate_keys();
-  bootstrap_setup_if_needed();
-  RT_DATA_INFO* di = rt_data_info();
-  if (di != nullptr) {
-    bool ok = Pt_mgr_init(di->_file_name);
-    RT_ASSERT(ok, "Pt_mgr_init(%s) failed", di->_file_name);
+  {
+    UniformScope shared_by_all_images;  // keys, bootstrap tables, the weight file: one copy whatever the batch
+    if (!have_keys) generate_keys();
+    bootstrap_setup_if_needed();
+    RT_DATA_INFO* di = rt_data_info();
+    if (di != nullptr) {
+      bool ok = Pt_mgr_init(di->_file_name);
+      RT_ASSERT(ok, "Pt_mgr_init(%s) failed", di->_file_name);
+    }
+    sync();
   }
-  sync();
+  set_launch_mode(0, c->shard_sim ? 1 : c->batch);
 }
 
 void Finalize_context() {
@@ -300,6 +379,13 @@ void Finalize_context() {
            c.t_encode, c.t_issue, c.t_main);
     printf("[ACEHIP] %zu Bootstrap calls: %.3f s (synchronised on both sides while profiling)\n", c.n_bootstrap, c.t_bootstrap);
     printf("[ACEHIP] %zu encodes, %zu of them launched ahead of the per-limb queue\n", c.n_encode, c.n_encode_ahead);
+    printf("[ACEHIP] pool arena: peak %.1f MB per replica, batch %u, limb-sharded world %u%s\n", arena_peak_bytes() / 1048576.0, c.batch,
+           c.shard_world, c.shard_sim ? " (simulated)" : "");
+    if (c.shard_world > 1) {
+      uint64_t steps[2] = {0, 0};
+      const uint64_t b = acehip_shard_traffic(c.hip, steps, 0);
+      printf("[ACEHIP] limb exchanges: %llu steps, %llu limbs, %.3f GB received\n", (unsigned long long)steps[0], (unsigned long long)steps[1], b / 1e9);
+    }
     hw_stats_print();
     hw_flush_sites_print();
     acehip_stat st[16];
@@ -339,6 +425,30 @@ void Acehip_rt_thread_release(void) { thread_release(); }
 // pointers): hands over everything the shim still holds back and waits for the device.
 void Acehip_rt_sync(void) { sync(); }
 void Acehip_rt_next_input(void) { pt_image_boundary(); }
+
+// Extension: image batches.  B images run through every launch of this thread (Run_main_graph is called ONCE per batch): the
+// GPU form of the reference's image-parallel loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116), where the threads share
+// keys and weights (pt_mgr.c:182).  Call after Prepare_context and before the thread's first Prepare_input; then, per batch:
+// for k < B { Acehip_rt_select_image(k); Prepare_input(...); }  Run_main_graph();  for k < B { Acehip_rt_select_image(k);
+// Handle_output(...); }.  ACEHIP_BATCH=B sets the default.
+void Acehip_rt_set_batch(uint32_t b) {
+  Context& c = ctx();
+  RT_ASSERT(b >= 1 && b <= 64, "Acehip_rt_set_batch: 1..64 images");
+  RT_ASSERT(!c.shard_sim || b == 1, "simulated limb-sharded execution runs one image");
+  if (b == c.batch) return;
+  sync();
+  RT_ASSERT(arena_peak_bytes() == 0, "Acehip_rt_set_batch: call it before the thread's first input (its pool is in use already)");
+  c.batch = b;
+  set_launch_mode(0, b);
+}
+uint32_t Acehip_rt_batch(void) { return batch_size(); }
+void Acehip_rt_select_image(uint32_t k) { select_image(k); }
+// Extension: limb-sharded execution (BASELINE configs[4]).  world / rank of this process and what the exchanges moved so far.
+uint32_t Acehip_rt_shard_world(void) { return g_ctx ? g_ctx->shard_world : 1; }
+uint32_t Acehip_rt_shard_rank(void) { return g_ctx ? g_ctx->shard_rank : 0; }
+uint64_t Acehip_rt_shard_traffic(uint64_t* steps_limbs /* [2] or NULL */, int reset) {
+  return g_ctx ? acehip_shard_traffic(g_ctx->hip, steps_limbs, reset) : 0;
+}
 size_t Acehip_rt_prefetched_count(void) { return g_ctx ? g_ctx->n_encode_prefetched : 0; }
 
 // ---- key accessors (key_gen.h:28-75) ----

@@ -58,6 +58,10 @@ void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u3
   p->_sf_degree = sf_degree;
   p->_slots = slots;
   POLYNOMIAL* poly = &p->_poly;
+  // image batches: a block every image shares (a weight plaintext) and a block every image has a copy of are not
+  // interchangeable -- a shell that holds the other kind gets a fresh block (the old one stays intact for queued readers)
+  if (poly->_data != nullptr && batch_size() > 1 && (uniform_alloc_on() ? block_is_replicated((u64*)poly->_data) : block_is_uniform((u64*)poly->_data)))
+    poly_free(poly);
   if (poly->_data == nullptr || (poly->_num_primes + poly->_num_primes_p) == 0) {
     if (poly->_data) poly_free(poly);
     poly_alloc(poly, c.N, nq, np, zero);
@@ -135,6 +139,11 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
   // old one stays intact for the queued ops that read it: renaming) and the encode, which writes nothing else, is
   // launched ahead of the queue.  The taps of a whole output channel then form one accumulation chain per limb.
   const bool ahead = !hw_queue_empty();
+  // An image batch shares its weight plaintexts (the reference's threads share them too: pt_mgr.c:182): the block comes from
+  // the shared pool and the encode covers one replica.  The input image (Prepare_input: ImageScope) and everything made
+  // inside a UniformScope take the thread's current mode as it is.
+  const bool shared_pt = batch_size() > 1 && !in_image_scope() && !uniform_alloc_on();
+  UniformAlloc ua(shared_pt);
   c.n_encode++;
   c.n_encode_ahead += ahead;
   if (ahead && poly->_data != nullptr) {
@@ -145,12 +154,14 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
   init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
   if (ahead) {
     hw_pending_flush();
+  } else {
+    const Touch touch[3] = {{nullptr, 0}, {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N}};
+    hw_flush_touching(__FILE__, __LINE__, touch, 3);  // (d_vals: staging ring / weights)
+  }
+  {
+    SelectGuard one_replica(shared_pt ? 0 : current_rep0(), shared_pt ? 1 : current_nrep());
     HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
                                  level, p_cnt, nullptr));
-  } else {
-    HIPCHK_T(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree, level, p_cnt,
-                           nullptr),
-             {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N});  // (d_vals: staging ring / weights)
   }
   poly->_is_ntt = true;
   if (c.profile) c.t_encode += wall_s() - t0;
@@ -201,7 +212,7 @@ void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree) {
     for (u32 i = 0; i < level; ++i) consts[i] = mulmod(consts[i], approx[i], c.primes[i]);
   }
   // every coefficient of limb i equals consts[i] (a constant polynomial in the NTT domain)
-  fill_zero((u64*)q_limbs(&res->_poly), (size_t)level * N);
+  fill_zero((u64*)q_limbs(&res->_poly), (size_t)level * N, level);
   q_scalars(ACEHIP_HW_ADDC, q_limbs(&res->_poly), q_limbs(&res->_poly), consts.data(), level, 0, level);
   res->_poly._is_ntt = true;
 }
@@ -309,7 +320,10 @@ void decode(std::vector<cplx>& out, PLAINTEXT* plain) {
   const u32 level = (u32)poly->_num_primes, N = c.N, half_n = N / 2, slots = plain->_slots, gap = half_n / slots;
   if (poly->_is_ntt) poly_ntt(poly, true);
   std::vector<u64> host((size_t)level * N);
-  HIPCHK(acehip_memcpy_d2h(host.data(), q_limbs(poly), host.size() * 8, nullptr));
+  // (limb-sharded execution: the CRT reconstruction needs every limb -- each comes from its owner, ckks_decryptor.c:19 /
+  // ckks_encoder.c:649 are the last place where the limbs of a result meet)
+  if (c.shard_world > 1) HIPCHK(acehip_shard_gather(c.hip, q_limbs(poly), level, 0, level, nullptr));
+  HIPCHK(acehip_download(c.hip, host.data(), q_limbs(poly), host.size() * 8, nullptr));
   Crt k = make_crt(level);
   std::vector<cplx> msg(slots);
   std::vector<u64> r(level);
@@ -359,6 +373,7 @@ void encrypt(CIPHERTEXT* res, PLAINTEXT* plain) {
 void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph) {
   Context& c = ctx();
   HIPCHK(acehip_encode_status(c.hip));  // encode overflow (the reference's assert) surfaces here at the latest
+  RT_ASSERT(c.sk_ntt != nullptr, "decrypt: this context holds an evaluation-only key set (no secret key)");
   const u32 l = (u32)ciph->_c0_poly._num_primes;
   init_plaintext(res, ciph->_slots, l, ciph->_c0_poly._num_primes_p, ciph->_scaling_factor, ciph->_sf_degree);
   u64* r = q_limbs(&res->_poly);

@@ -52,8 +52,8 @@ void set_level(Ct& a, u32 level) {
     // but a single limb never overlaps its own source, and limb i is read before limb i+1's destination is written)
     Context& c = ctx();
     for (u32 i = 0; i < a.np(); ++i) {
-      copy_limbs((u64*)q_limbs(&a.c._c0_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c0_poly) + (size_t)i * c.N, c.N);
-      copy_limbs((u64*)q_limbs(&a.c._c1_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c1_poly) + (size_t)i * c.N, c.N);
+      copy_limbs((u64*)q_limbs(&a.c._c0_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c0_poly) + (size_t)i * c.N, c.N, 0, i);
+      copy_limbs((u64*)q_limbs(&a.c._c1_poly) + (size_t)(level + i) * c.N, (const u64*)p_limbs(&a.c._c1_poly) + (size_t)i * c.N, c.N, 0, i);
     }
     a.c._c0_poly._num_alloc_primes = a.c._c1_poly._num_alloc_primes = level + a.np();
   }
@@ -199,6 +199,7 @@ void mul_monomial(Ct& r, Ct& a, u32 power) {
   const u32 pr = power % (2 * c.N), index = power % c.N;
   u64*& mono = g_monomials[pr];
   if (mono == nullptr) {
+    UniformScope shared_by_all_images;
     POLYNOMIAL m{};
     poly_alloc(&m, c.N, c.L, 0);
     std::vector<int64_t> v(c.N, 0);

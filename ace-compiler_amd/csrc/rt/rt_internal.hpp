@@ -138,6 +138,14 @@ struct Context {
   size_t pt_pos = 0;                             // index into pt_trace of the next expected call
   std::deque<u64*> pt_ring;                      // encoded blocks for calls pt_pos, pt_pos + 1, ...
   size_t n_encode_prefetched = 0, n_encode_batches = 0;
+  // Image batch (Acehip_rt_set_batch / ACEHIP_BATCH): `batch` images run through every launch of this thread; each has its
+  // own replica of the pool arena, keys / bootstrap diagonals / weight plaintexts are shared (rt_poly.cpp "pool").
+  u32 batch = 1;
+  // Limb-sharded execution (BASELINE configs[4]): every rank runs the same program on the limbs it owns.  shard_sim: the
+  // ranks are simulated in this process (ACEHIP_SHARD_SIM=G: replica r of the arena holds rank r's limbs); otherwise this
+  // process is rank shard_rank of shard_world (one GPU each, RCCL; RANK / WORLD_SIZE with ACEHIP_SHARD=1).
+  u32 shard_world = 1, shard_rank = 0;
+  bool shard_sim = false;
 };
 void pt_image_boundary();                        // a new input arrives (Prepare_input): the recorded call sequence restarts
 
@@ -155,8 +163,45 @@ void thread_release();               // give back this thread's context / pool /
 Context& ctx();
 
 // ---- device memory pool (stream-ordered reuse; generated code does thousands of Alloc/Free) ----
-u64* dalloc(size_t words, bool zero);
+// nq (limb-sharded execution: who owns which limb of a zero fill / copy): the block is a polynomial of nq q-limbs (primes
+// 0..nq-1) followed by p-limbs; NQ_ANY: no such structure
+constexpr u32 NQ_ANY = 0xffffffffu;
+u64* dalloc(size_t words, bool zero, u32 nq = NQ_ANY);
 void dfree(u64* p);
+bool block_is_replicated(const u64* p);  // a pool block of which every image of the batch has its own copy
+bool block_is_uniform(const u64* p);     // a pool block shared by the images of the batch
+size_t arena_peak_bytes();
+// ---- which replicas of the arena the launches of this thread cover (image batches) ----
+u32 batch_size();
+bool uniform_alloc_on();      // allocations of this thread currently come from the shared pool
+u32 current_rep0();
+u32 current_nrep();
+bool in_image_scope();
+u32 selected_image();
+void select_image(u32 k);
+void set_launch_mode(u32 rep0, u32 nrep);
+struct UniformScope {  // work whose results every image shares (keys, bootstrap tables ...): one replica, blocks outside the arena
+  u32 rep0, nrep;
+  UniformScope();
+  ~UniformScope();
+};
+struct ImageScope {    // work on ONE image of the batch (its input, its output)
+  u32 rep0, nrep;
+  bool was;
+  explicit ImageScope(u32 k);
+  ~ImageScope();
+};
+struct UniformAlloc {  // allocations inside come from the shared (uniform) pool; launches are not affected
+  bool on;
+  explicit UniformAlloc(bool on);
+  ~UniformAlloc();
+};
+struct SelectGuard {   // a direct launch that covers other replicas than the thread's current mode; does NOT hand the queue over
+  u32 rep0, nrep;
+  bool active;
+  SelectGuard(u32 r0, u32 n);
+  ~SelectGuard();
+};
 void pool_release_all();
 size_t pool_bytes_in_use();
 
@@ -188,8 +233,9 @@ void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_
 void q_ew(u32 op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n);
 void q_scalars(u32 op, u64* r, const u64* a, const u64* scalars, u32 level, u32 pos0, u32 n);
 void q_rotate(u64* r, const u64* a, const uint32_t* perm, u32 level, u32 pos0, u32 n);
-void fill_zero(u64* p, size_t words);                    // queued when whole limbs, else memset
-void copy_limbs(u64* dst, const u64* src, size_t words); // queued when whole disjoint limbs, else d2d copy
+void fill_zero(u64* p, size_t words, u32 nq = NQ_ANY);   // queued when whole limbs, else memset
+// queued when whole disjoint limbs, else d2d copy; limb i of the copy is limb first + i of a polynomial with nq q-limbs
+void copy_limbs(u64* dst, const u64* src, size_t words, u32 nq = NQ_ANY, u32 first = 0);
 double wall_s();
 
 // ---- sampling (random_sample.c) ----
@@ -198,12 +244,14 @@ void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight);   // :99-15
 
 // ---- keys (ckks_key_generator.c) ----
 void generate_keys();
+void shard_connect_if_asked();   // rt_context.cpp: ACEHIP_SHARD=1 joins the RCCL communicator of the launcher's ranks
 SwitchKeyStore* make_switch_key(const u64* new_key_ntt /*[L+K][N]*/, const u64* old_key_ntt);
 u32 ensure_rot_key(int32_t rotation);   // Insert_rot_map :290; returns automorphism index
 SwitchKeyStore* ensure_auto_key(u32 auto_idx);
 void free_switch_key(SwitchKeyStore* k);
 int save_keys(const char* path);   // rt_serial.cpp: "ACEHKEY1" container
 int load_keys(const char* path);
+int save_eval_keys(const char* path);
 
 // ---- encode / decode (ckks_encoder.c) ----
 void embedding(std::vector<cplx>& vals);                               // ntt.c:678-711

@@ -155,14 +155,22 @@ void Tm_taken(const char* msg) {
 // ---- rtlib.c:41-87 ----
 void Prepare_input(TENSOR* input, const char* name) {
   io_init();
-  rt::pt_image_boundary();
+  // image batch (Acehip_rt_set_batch): this call fills the selected image's copy of the input ciphertext; the recorded
+  // Pt_from_msg sequence restarts with the first image of a batch
+  const rt::u32 k = rt::selected_image();
+  if (k == 0) rt::pt_image_boundary();
+  rt::ImageScope one_image(k);
   const size_t len = TENSOR_SIZE(input);
   std::vector<cplx> v(len);
   for (size_t i = 0; i < len; ++i) v[i] = cplx(input->_vals[i], 0.0);
   PLAINTEXT pt;
   memset(&pt, 0, sizeof(pt));
   encode_vector(&pt, v.data(), len, 0, 0, 1, 0);  // ENCODE: full level, default slots, sf_degree 1
-  CIPHER ct = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
+  CIPHER ct = (CIPHER)io_at(g_inputs, name, 0);
+  if (ct == nullptr || k == 0) {
+    if (ct != nullptr) Free_cipher(ct);  // an input nobody consumed
+    ct = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
+  }
   encrypt(ct, &pt);
   poly_free(&pt._poly);
   io_at(g_inputs, name, 0) = ct;
@@ -172,16 +180,23 @@ double* Handle_output(const char* name) {
   io_init();
   CIPHER ct = (CIPHER)io_at(g_outputs, name, 0);
   RT_ASSERT(ct != nullptr, "not find data");
-  PLAINTEXT pt;
-  memset(&pt, 0, sizeof(pt));
-  decrypt(&pt, ct);
-  std::vector<cplx> out;
-  decode(out, &pt);
-  double* data = (double*)malloc(out.size() * sizeof(double));
-  for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
-  poly_free(&pt._poly);
-  Free_cipher(ct);
-  io_at(g_outputs, name, 0) = nullptr;
+  const rt::u32 k = rt::selected_image();  // image batch: the selected image's result; the ciphertext goes with the last one
+  double* data;
+  {
+    rt::ImageScope one_image(k);
+    PLAINTEXT pt;
+    memset(&pt, 0, sizeof(pt));
+    decrypt(&pt, ct);
+    std::vector<cplx> out;
+    decode(out, &pt);
+    data = (double*)malloc(out.size() * sizeof(double));
+    for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
+    poly_free(&pt._poly);
+  }
+  if (k + 1 >= rt::batch_size()) {
+    Free_cipher(ct);
+    io_at(g_outputs, name, 0) = nullptr;
+  }
   return data;
 }
 
@@ -436,15 +451,20 @@ static void pt_ring_fill(rt::Context& c) {
   const void* vals[8];
   for (rt::u32 j = 0; j < n; ++j) {
     vals[j] = pt_entry_dev(c.pt_trace[c.pt_pos + j].index, h.len);
+    rt::UniformAlloc shared_pt(rt::batch_size() > 1);  // image batches share their weight plaintexts
     q[j] = rt::dalloc((size_t)h.level * c.N, false);  // the encode writes every limb
   }
   // like encode_device: the batch writes only blocks no queued op can name, so it may run ahead of the per-limb queue
   if (!rt::hw_queue_empty()) {
     rt::hw_pending_flush();
-    HIPCHK_NOFLUSH(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
   } else {
     // (fresh blocks: no fill of them can be waiting; the weights are not limbs)
-    HIPCHK_T(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
+    const rt::Touch none[1] = {{nullptr, 0}};
+    rt::hw_flush_touching(__FILE__, __LINE__, none, 1);
+  }
+  {
+    rt::SelectGuard one_replica(rt::batch_size() > 1 ? 0 : rt::current_rep0(), rt::batch_size() > 1 ? 1 : rt::current_nrep());
+    HIPCHK_NOFLUSH(acehip_encode_batch(c.hip, q, vals, n, 0, h.len, 0, c.sf, h.scale, h.level, nullptr));
   }
   for (rt::u32 j = 0; j < n; ++j) c.pt_ring.push_back(q[j]);
   c.n_encode_batches++;
@@ -456,7 +476,7 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
     return;
   }
   if (g_pt_cache_on < 0) g_pt_cache_on = getenv("ACEHIP_PT_CACHE") && atoi(getenv("ACEHIP_PT_CACHE")) != 0;
-  if (g_pt_cache_on) {
+  if (g_pt_cache_on && rt::batch_size() == 1) {  // (a batch shares each encode among its images already)
     rt::Context& c = rt::ctx();
     std::unique_lock<std::recursive_mutex> lk(rt::shared_mu());
     const uint32_t lv = level ? level : c.L;
@@ -466,13 +486,13 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
       rt::encode_device(plain, pt_entry_dev(index, len), 0, len, lv, 0, scale, 0);
       rt::u64* keep = (rt::u64*)acehip_malloc(words * 8);
       RT_ASSERT(keep, "plaintext cache: %s", acehip_last_error());
-      HIPCHK(acehip_memcpy_d2d(keep, rt::q_limbs(&plain->_poly), words * 8, nullptr));
+      HIPCHK(acehip_copy(c.hip, keep, rt::q_limbs(&plain->_poly), words * 8, nullptr));
       rt::sync();  // complete before another thread's stream may copy from it
       g_pt_cache[PtKey{index, lv, scale, len}] = keep;
     } else {
       lk.unlock();
       rt::init_plaintext(plain, c.N / 2, lv, 0, pow(c.sf, (double)scale), scale);
-      rt::copy_limbs(rt::q_limbs(&plain->_poly), it->second, words);
+      rt::copy_limbs(rt::q_limbs(&plain->_poly), it->second, words, lv);
       plain->_poly._is_ntt = true;
     }
   } else {

@@ -29,6 +29,7 @@ static void attach_thread() {
   Context* p = g_primary;
   auto* c = new Context(*p);
   c->secondary = true;
+  RT_ASSERT(p->shard_world <= 1 || p->shard_sim, "limb-sharded execution over RCCL runs one host thread per process");
   c->auto_keys.clear();  // the shared maps live in the primary context only
   c->rot2auto.clear();
   int dev = 0;
@@ -79,15 +80,162 @@ static bool shared_free(u64* p) {
 // ---- pool: exact-size free lists.  All launches go to the default stream in program order, so a
 // buffer released by Free_* can be handed out again immediately: later kernels are ordered after
 // earlier ones.  Nothing is returned to the driver before Finalize_context (hipFree synchronises).
+//
+// Two kinds of blocks.  ARENA blocks are carved out of one slab of which `nrep` copies exist, a constant stride apart
+// (acehip_ctx_set_arena): the images of a batch -- or the simulated ranks of limb-sharded execution -- each have their own
+// copy of every such block and the kernels move pointers into the slab along with the replica they work on.  UNIFORM blocks
+// are separate device allocations outside the slab: what every image shares (keys, bootstrap diagonals, weight plaintexts,
+// anything made inside a UniformScope); they are written by launches that cover one replica.
+enum BlockKind : int { BK_ARENA = 0, BK_UNIFORM = 1 };
+struct LiveBlock {
+  size_t words;
+  int kind;
+};
 static thread_local std::mutex pool_mu;
-static thread_local std::map<size_t, std::vector<u64*>> pool_free;
-static thread_local std::map<u64*, size_t> pool_live;
+static thread_local std::map<size_t, std::vector<u64*>> pool_free[2];
+static thread_local std::map<u64*, LiveBlock> pool_live;
 static thread_local size_t pool_live_bytes = 0;
 // Blocks freed while per-limb ops are still queued may be named by those ops: they wait here until the queue has been
 // handed to the device (hw_flush), and only then become reusable.  A block taken from pool_free is therefore never
 // referenced by anything still queued -- which is what lets work that only writes a fresh block (Pt_from_msg's encode)
 // be launched ahead of the queue instead of cutting it (rt_encode.cpp encode_device).
-static thread_local std::vector<std::pair<u64*, size_t>> pool_limbo;
+struct LimboBlock {
+  u64* first;
+  size_t second;
+  int kind;
+};
+static thread_local std::vector<LimboBlock> pool_limbo;
+
+namespace {
+struct Arena {
+  u64* base = nullptr;   // replica 0
+  size_t words = 0;      // per replica (= stride)
+  size_t bump = 0, peak = 0;
+  u32 nrep = 0;
+  bool exhausted_warned = false;
+};
+thread_local Arena g_arena;
+thread_local int g_uniform_depth = 0;   // UniformScope nesting
+thread_local int g_alloc_uniform = 0;   // allocations come from the uniform pool (UniformScope, shared plaintexts)
+thread_local bool g_image_scope = false;
+thread_local u32 g_mode_rep0 = 0, g_mode_nrep = 1;  // replicas the launches of this thread cover at the moment
+thread_local u32 g_image = 0;                        // image Prepare_input / Handle_output address (Acehip_rt_select_image)
+
+inline bool in_arena(const void* p) {
+  return g_arena.base != nullptr && (const u64*)p >= g_arena.base && (const u64*)p < g_arena.base + g_arena.words;
+}
+// the slab: created on the first allocation that needs it, when the batch size / the simulated world are known
+void arena_create() {
+  Context& c = ctx();
+  Arena& a = g_arena;
+  const u32 nrep = std::max<u32>(c.batch, c.shard_sim ? c.shard_world : 1);
+  size_t mb = 0;
+  if (const char* e = getenv("ACEHIP_ARENA_MB")) mb = strtoull(e, nullptr, 10);
+  if (mb == 0) {  // enough for one image stream of the generated ResNets at N = 2^16 (profile line "pool arena"), scaled down with N
+    mb = (size_t)8192 * c.N / 65536;
+    if (mb < 64) mb = 64;
+  }
+  const size_t N = c.N, guard = (size_t)(c.L + c.K) * N, ws_words = acehip_workspace_words(c.hip);
+  const size_t scratch_limbs = 512;
+  size_t words = mb * (1u << 20) / 8;
+  const size_t fixed = guard + ws_words + scratch_limbs * N;
+  if (words < 2 * fixed) words = 2 * fixed;
+  words = (words + 31) & ~(size_t)31;
+  a.base = (u64*)acehip_malloc(words * 8 * nrep);
+  RT_ASSERT(a.base != nullptr, "pool arena: %zu MB x %u replicas: %s (ACEHIP_ARENA_MB sets the size of one replica)", words * 8 >> 20, nrep,
+            acehip_last_error());
+  a.words = words;
+  a.nrep = nrep;
+  // the first limbs stay unused: kernels may form addresses a few limbs below a block (a limb position subtracted from a
+  // base) and those must still fall inside the slab to be moved with their replica
+  a.bump = guard;
+  acehip_arena_cfg cfg{};
+  cfg.base = a.base;
+  cfg.bytes = words * 8;
+  cfg.stride_bytes = words * 8;
+  cfg.n_replicas = nrep;
+  cfg.workspace = a.base + a.bump;
+  a.bump += (ws_words + 31) & ~(size_t)31;
+  cfg.hw_scratch = a.base + a.bump;
+  cfg.hw_scratch_limbs = scratch_limbs;
+  a.bump += scratch_limbs * N;
+  a.peak = a.bump;
+  const int rc = acehip_ctx_set_arena(c.hip, &cfg);
+  RT_ASSERT(rc >= 0, "acehip_ctx_set_arena: %s", acehip_last_error());
+  if (c.shard_sim) {
+    const int rs = acehip_ctx_shard_sim(c.hip, c.shard_world);
+    RT_ASSERT(rs >= 0, "acehip_ctx_shard_sim: %s", acehip_last_error());
+  }
+  if (g_uniform_depth == 0 && !g_image_scope) {
+    g_mode_rep0 = 0;
+    g_mode_nrep = c.shard_sim ? 1 : c.batch;
+  }
+  const int rsel = acehip_ctx_select(c.hip, g_mode_rep0, g_mode_nrep);
+  RT_ASSERT(rsel >= 0, "acehip_ctx_select: %s", acehip_last_error());
+}
+u64* arena_take(size_t words) {
+  Arena& a = g_arena;
+  if (a.base == nullptr) arena_create();
+  const size_t w = (words + 31) & ~(size_t)31;  // 256-byte granules
+  if (a.bump + w > a.words) return nullptr;
+  u64* p = a.base + a.bump;
+  a.bump += w;
+  a.peak = std::max(a.peak, a.bump);
+  return p;
+}
+}  // namespace
+bool in_image_scope() { return g_image_scope; }
+bool uniform_alloc_on() { return g_alloc_uniform > 0; }
+u32 current_rep0() { return g_mode_rep0; }
+u32 current_nrep() { return g_mode_nrep; }
+u32 batch_size() { return g_ctx ? g_ctx->batch : 1; }
+u32 selected_image() { return g_image; }
+void select_image(u32 k) {
+  RT_ASSERT(k < batch_size(), "image %u outside the batch of %u", k, batch_size());
+  g_image = k;
+}
+size_t arena_peak_bytes() { return g_arena.peak * 8; }
+// replicas the launches that follow cover; the queue is handed over first when the selection changes (its ops were
+// queued for the old one)
+void set_launch_mode(u32 rep0, u32 nrep) {
+  if (rep0 == g_mode_rep0 && nrep == g_mode_nrep) return;
+  hw_flush_site(__FILE__, __LINE__);
+  g_mode_rep0 = rep0;
+  g_mode_nrep = nrep;
+  if (g_ctx != nullptr && g_ctx->hip != nullptr && g_arena.base != nullptr) {
+    const int rc = acehip_ctx_select(g_ctx->hip, rep0, nrep);
+    RT_ASSERT(rc >= 0, "acehip_ctx_select(%u, %u): %s", rep0, nrep, acehip_last_error());
+  }
+}
+UniformScope::UniformScope() : rep0(g_mode_rep0), nrep(g_mode_nrep) {
+  set_launch_mode(0, 1);
+  ++g_uniform_depth;
+  ++g_alloc_uniform;
+}
+UniformScope::~UniformScope() {
+  --g_uniform_depth;
+  --g_alloc_uniform;
+  set_launch_mode(rep0, nrep);
+}
+ImageScope::ImageScope(u32 k) : rep0(g_mode_rep0), nrep(g_mode_nrep), was(g_image_scope) {
+  if (batch_size() > 1) set_launch_mode(k, 1);
+  g_image_scope = true;
+}
+ImageScope::~ImageScope() {
+  g_image_scope = was;
+  set_launch_mode(rep0, nrep);
+}
+UniformAlloc::UniformAlloc(bool on) : on(on) { g_alloc_uniform += on; }
+UniformAlloc::~UniformAlloc() { g_alloc_uniform -= on; }
+SelectGuard::SelectGuard(u32 r0, u32 n) : rep0(g_mode_rep0), nrep(g_mode_nrep), active(r0 != g_mode_rep0 || n != g_mode_nrep) {
+  if (active && g_arena.base != nullptr) {
+    const int rc = acehip_ctx_select(ctx().hip, r0, n);
+    RT_ASSERT(rc >= 0, "acehip_ctx_select: %s", acehip_last_error());
+  }
+}
+SelectGuard::~SelectGuard() {
+  if (active && g_arena.base != nullptr) acehip_ctx_select(ctx().hip, rep0, nrep);
+}
 
 // ---- deferred per-limb ops ----
 // Generated code calls Hw_modadd / Hw_modmul / Hw_rotate once per RNS limb and component inside host loops
@@ -210,7 +358,7 @@ void pending_flush() {
 static void limbo_release() {
   if (pool_limbo.empty()) return;
   std::lock_guard<std::mutex> lk(pool_mu);
-  for (auto& b : pool_limbo) pool_free[b.second].push_back(b.first);
+  for (auto& b : pool_limbo) pool_free[b.kind][b.second].push_back(b.first);
   pool_limbo.clear();
 }
 namespace {
@@ -391,7 +539,8 @@ void lazy_meet_queue(const Touch* touch, size_t n_touch, bool defer) {
 }
 void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
   static const bool lazy_on = getenv("ACEHIP_LAZY_ZERO") == nullptr || atoi(getenv("ACEHIP_LAZY_ZERO")) != 0;
-  lazy_meet_queue(touch, n_touch, defer && lazy_on);
+  // (limb-sharded execution: a deferred fill does not remember which rank owns its limb, so nothing is deferred there)
+  lazy_meet_queue(touch, n_touch, defer && lazy_on && ctx().shard_world <= 1);
   if (g_hwq.empty()) {
     limbo_release();
     return;
@@ -472,6 +621,8 @@ void hw_pending_flush() { pending_flush(); }
 void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_t n_limbs) {
   const size_t N = ctx().N;
   pending_flush();
+  // a batch of images shares what lies outside the arena: an op that covers the whole batch must not write there
+  RT_ASSERT(g_mode_nrep == 1 || in_arena(res), "a per-limb op of an image batch writes memory all images share (a weight plaintext?)");
   g_muc.written(res, n_limbs * N);
   for (size_t l = 0; l < n_limbs; ++l)
     g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
@@ -492,30 +643,52 @@ void q_rotate(u64* r, const u64* a, const uint32_t* perm, u32 level, u32 pos0, u
   const size_t N = ctx().N;
   for (u32 p = pos0; p < pos0 + n; ++p) hw_queue(ACEHIP_HW_ROTATE, limb_gi(p, level), r + p * N, a + p * N, perm);
 }
-// zero fill / copy of whole limbs through the queue (anything else goes the direct way)
-void fill_zero(u64* p, size_t words) {
+// zero fill / copy of whole limbs through the queue (anything else goes the direct way).  nq: the block holds nq q-limbs
+// (primes 0..nq-1) followed by p-limbs -- which names the owner of every limb under limb-sharded execution; NQ_ANY: not a
+// polynomial of the chain (every rank runs the op)
+static inline u32 map_gi(size_t i, u32 nq) { return nq == NQ_ANY ? ACEHIP_HW_ANY_RANK : (i < nq ? (u32)i : ctx().L + (u32)(i - nq)); }
+void fill_zero(u64* p, size_t words, u32 nq) {
   const size_t N = ctx().N;
-  if (words % N == 0) hw_queue(ACEHIP_HW_ZERO, 0, p, nullptr, nullptr, words / N);
-  else HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
+  if (words % N == 0) {
+    for (size_t i = 0; i < words / N; ++i) hw_queue(ACEHIP_HW_ZERO, map_gi(i, nq), p + i * N, nullptr, nullptr);
+  } else {
+    HIPCHK(acehip_fill(ctx().hip, p, 0, words * sizeof(u64), nullptr));
+  }
 }
-void copy_limbs(u64* dst, const u64* src, size_t words) {
+void copy_limbs(u64* dst, const u64* src, size_t words, u32 nq, u32 first) {
   const size_t N = ctx().N;
   if (dst == src) return;
   const size_t gap = dst < src ? src - dst : dst - src;
-  if (words % N == 0 && gap >= words) hw_queue(ACEHIP_HW_COPY, 0, dst, src, nullptr, words / N);
-  else HIPCHK(acehip_memcpy_d2d(dst, src, words * sizeof(u64), nullptr));
+  if (words % N == 0 && gap >= words) {
+    for (size_t i = 0; i < words / N; ++i) hw_queue(ACEHIP_HW_COPY, map_gi(first + i, nq), dst + i * N, src + i * N, nullptr);
+  } else {
+    HIPCHK(acehip_copy(ctx().hip, dst, src, words * sizeof(u64), nullptr));
+  }
 }
 
-u64* dalloc(size_t words, bool zero) {
+u64* dalloc(size_t words, bool zero, u32 nq) {
   if (g_shared_scope > 0) return shared_alloc(words, zero);
   if (words == 0) words = 1;
+  int kind = g_alloc_uniform > 0 ? BK_UNIFORM : BK_ARENA;
   u64* p = nullptr;
   {
     std::lock_guard<std::mutex> lk(pool_mu);
-    auto it = pool_free.find(words);
-    if (it != pool_free.end() && !it->second.empty()) {
+    auto it = pool_free[kind].find(words);
+    if (it != pool_free[kind].end() && !it->second.empty()) {
       p = it->second.back();
       it->second.pop_back();
+    }
+  }
+  if (!p && kind == BK_ARENA) {
+    p = arena_take(words);
+    if (!p) {
+      // the slab is full.  With one replica a block outside it works just as well (nothing moves with a replica);
+      // with several there is no way out
+      RT_ASSERT(g_arena.nrep == 1, "pool arena exhausted (%zu MB per replica): raise ACEHIP_ARENA_MB", g_arena.words * 8 >> 20);
+      if (!g_arena.exhausted_warned && ctx().profile)
+        fprintf(stderr, "[ACEHIP] pool arena of %zu MB exhausted: further blocks are separate allocations\n", g_arena.words * 8 >> 20);
+      g_arena.exhausted_warned = true;
+      kind = BK_UNIFORM;
     }
   }
   if (!p) {
@@ -524,10 +697,10 @@ u64* dalloc(size_t words, bool zero) {
   }
   {
     std::lock_guard<std::mutex> lk(pool_mu);
-    pool_live[p] = words;
+    pool_live[p] = LiveBlock{words, kind};
     pool_live_bytes += words * sizeof(u64);
   }
-  if (zero) fill_zero(p, words);
+  if (zero) fill_zero(p, words, nq);
   return p;
 }
 
@@ -535,11 +708,37 @@ u64* dalloc(size_t words, bool zero) {
 static size_t pool_block_words(u64* p) {
   std::lock_guard<std::mutex> lk(pool_mu);
   auto it = pool_live.find(p);
-  return it == pool_live.end() ? 0 : it->second;
+  return it == pool_live.end() ? 0 : it->second.words;
+}
+// every image has its own copy of the block (false: one copy shared by the batch, or not a pool block)
+bool block_is_replicated(const u64* p) {
+  std::lock_guard<std::mutex> lk(pool_mu);
+  auto it = pool_live.find(const_cast<u64*>(p));
+  return it != pool_live.end() && it->second.kind == BK_ARENA;
+}
+bool block_is_uniform(const u64* p) {
+  std::lock_guard<std::mutex> lk(pool_mu);
+  auto it = pool_live.find(const_cast<u64*>(p));
+  return it != pool_live.end() && it->second.kind == BK_UNIFORM;
 }
 
 void dfree(u64* p) {
   if (!p) return;
+  // a Mod_down / Rescale that is still held back reads or writes this block: issue it first (the queue and the deferred
+  // fills it depends on are still intact; a freed block would be handed over as dead memory)
+  if (g_pend.kind) {
+    const size_t N = ctx().N;
+    const size_t out_w = (size_t)(g_pend.kind == 1 ? g_pend.level : g_pend.level - 1) * N;
+    const size_t in_w = (size_t)(g_pend.kind == 1 ? g_pend.level + ctx().K : g_pend.level) * N;
+    size_t bw = 0;
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      auto it = pool_live.find(p);
+      if (it != pool_live.end()) bw = it->second.words;
+    }
+    const u64* e = p + bw;
+    if (bw && ((g_pend.out < e && g_pend.out + out_w > p) || (g_pend.in < e && g_pend.in + in_w > p))) pending_flush();
+  }
   if (p == g_muc.lent) {  // the caller is done with the digit it was handed last: keep it, release a valueless block instead
     g_muc.lent = nullptr;
     if (g_muc.ok)
@@ -550,20 +749,33 @@ void dfree(u64* p) {
           break;
         }
   }
+  {
+    // (shared_free hands the queue over, which takes pool_mu itself: look the block up first, call it unlocked)
+    bool mine;
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      mine = pool_live.find(p) != pool_live.end();
+    }
+    if (!mine) {
+      const bool shared = shared_free(p);
+      RT_ASSERT(shared, "free of a pointer the pool does not own");
+      return;
+    }
+  }
   std::lock_guard<std::mutex> lk(pool_mu);
   auto it = pool_live.find(p);
-  if (it == pool_live.end() && shared_free(p)) return;
-  RT_ASSERT(it != pool_live.end(), "free of a pointer the pool does not own");
-  if (g_muc.ok && g_muc.src >= p && g_muc.src < p + it->second) g_muc.forget();
-  pool_live_bytes -= it->second * sizeof(u64);
+  const size_t words = it->second.words;
+  const int kind = it->second.kind;
+  if (g_muc.ok && g_muc.src >= p && g_muc.src < p + words) g_muc.forget();
+  pool_live_bytes -= words * sizeof(u64);
   if (g_hwq.empty()) {
-    pool_free[it->second].push_back(p);
-    for (auto z = g_lazy.lower_bound(p); z != g_lazy.end() && *z < p + it->second;) {  // fills nobody waits for any more
+    pool_free[kind][words].push_back(p);
+    for (auto z = g_lazy.lower_bound(p); z != g_lazy.end() && *z < p + words;) {  // fills nobody waits for any more
       z = g_lazy.erase(z);
       g_lazy_stats.dropped++;
     }
   } else {
-    pool_limbo.emplace_back(p, it->second);  // queued ops may still name it (and deferred fills of it: queue_submit)
+    pool_limbo.push_back(LimboBlock{p, words, kind});  // queued ops may still name it (and deferred fills of it: queue_submit)
   }
   pool_live.erase(it);
 }
@@ -584,14 +796,24 @@ void pool_release_all() {
   std::lock_guard<std::mutex> lk(pool_mu);
   g_lazy.clear();
   g_muc = ModupCache{};
-  for (auto& kv : pool_free)
+  for (auto& kv : pool_free[BK_UNIFORM])
     for (u64* p : kv.second) acehip_free(p);
-  pool_free.clear();
-  for (auto& b : pool_limbo) acehip_free(b.first);
+  for (auto& b : pool_limbo)
+    if (b.kind == BK_UNIFORM) acehip_free(b.first);
+  for (auto& kv : pool_live)
+    if (kv.second.kind == BK_UNIFORM) acehip_free(kv.first);
+  pool_free[0].clear();
+  pool_free[1].clear();
   pool_limbo.clear();
-  for (auto& kv : pool_live) acehip_free(kv.first);
   pool_live.clear();
   pool_live_bytes = 0;
+  if (g_arena.base != nullptr) {  // (the context that names it goes away right after: acehip_ctx_destroy)
+    acehip_free(g_arena.base);
+    g_arena = Arena{};
+  }
+  g_mode_rep0 = 0;
+  g_mode_nrep = 1;
+  g_image = 0;
 }
 size_t pool_bytes_in_use() { return pool_live_bytes; }
 
@@ -609,7 +831,7 @@ void poly_alloc(POLYNOMIAL* p, u32 N, size_t nq, size_t np, bool zero) {
   p->_num_primes_p = np;
   p->_num_alloc_primes = nq + np;
   p->_is_ntt = false;
-  p->_data = (int64_t*)dalloc((size_t)(nq + np) * N, zero);
+  p->_data = (int64_t*)dalloc((size_t)(nq + np) * N, zero, (u32)nq);
 }
 void poly_free(POLYNOMIAL* p) {
   if (p->_data) {
@@ -629,7 +851,7 @@ void poly_init_like(POLYNOMIAL* res, POLYNOMIAL* like) {
       poly_free(res);
       poly_alloc(res, N, nq, np);
     } else {
-      fill_zero((u64*)res->_data, res->_num_alloc_primes * (size_t)res->_ring_degree);
+      fill_zero((u64*)res->_data, res->_num_alloc_primes * (size_t)res->_ring_degree, (u32)(res->_num_alloc_primes - res->_num_primes_p));
       res->_ring_degree = N;
       res->_num_primes = nq;
       res->_num_primes_p = np;
@@ -649,8 +871,8 @@ void poly_copy(POLYNOMIAL* res, POLYNOMIAL* src) {
   res->_num_primes = src->_num_primes;
   res->_num_primes_p = src->_num_primes_p;
   res->_is_ntt = src->_is_ntt;
-  if (src->_num_primes) copy_limbs(q_limbs(res), q_limbs(src), src->_num_primes * N);
-  if (src->_num_primes_p) copy_limbs(p_limbs(res), p_limbs(src), src->_num_primes_p * N);
+  if (src->_num_primes) copy_limbs(q_limbs(res), q_limbs(src), src->_num_primes * N, (u32)src->_num_primes);
+  if (src->_num_primes_p) copy_limbs(p_limbs(res), p_limbs(src), src->_num_primes_p * N, 0);
 }
 
 void poly_ew(Op op, POLYNOMIAL* res, POLYNOMIAL* a, POLYNOMIAL* b, bool with_p) {
@@ -685,7 +907,7 @@ void poly_rotate(POLYNOMIAL* res, POLYNOMIAL* a, u32 auto_idx) {
 void poly_from_small(POLYNOMIAL* p, const std::vector<int64_t>& vals) {
   Context& c = ctx();
   u64* tmp = dalloc(c.N, false);
-  HIPCHK(acehip_memcpy_h2d(tmp, vals.data(), c.N * 8, nullptr));
+  HIPCHK(acehip_upload(c.hip, tmp, vals.data(), c.N * 8, nullptr));
   const u32 l = (u32)p->_num_primes;
   if (l) HIPCHK(acehip_values_to_rns(c.hip, q_limbs(p), (const int64_t*)tmp, l, 0, l, nullptr));
   if (p->_num_primes_p) HIPCHK(acehip_values_to_rns(c.hip, p_limbs(p), (const int64_t*)tmp, 0, 0, (u32)p->_num_primes_p, nullptr));
@@ -729,7 +951,8 @@ void Copy_poly(POLY res, POLY poly) {
 void Set_coeffs(POLY dst, uint32_t level, uint32_t degree, int64_t* src) {
   int64_t* d = Coeffs(dst, level, degree);
   if (d == src) return;  // generated code does self-copies (resnet20 .inc:1546)
-  copy_limbs((u64*)d, (const u64*)src, degree);
+  const size_t nq = dst->_num_alloc_primes - dst->_num_primes_p;
+  copy_limbs((u64*)d, (const u64*)src, degree, (u32)nq, level);
 }
 size_t Num_decomp(POLY poly) { return acehip_num_decomp(ctx().hip, (uint32_t)poly->_num_primes); }
 
@@ -748,7 +971,7 @@ int64_t* Hw_rotate(int64_t* res, int64_t* a, int64_t* rot_precomp, MODULUS* m, u
   RtmScope rtm(RTM_HW_ROT, false);
   if (res == a) {  // the reference loop would read overwritten data too; keep it well defined
     u64* tmp = dalloc(degree, false);
-    copy_limbs((u64*)tmp, (const u64*)a, (size_t)degree);
+    hw_queue(ACEHIP_HW_COPY, m->_gi, tmp, (const u64*)a, nullptr);
     HIPCHK(acehip_hw_rotate(ctx().hip, (u64*)res, tmp, (const uint32_t*)rot_precomp, m->_gi, nullptr));
     dfree(tmp);
   } else {
@@ -772,7 +995,7 @@ POLY Decomp(POLY res, POLY poly, uint32_t q_part_idx) {
     res->_num_primes = n2;
     res->_num_primes_p = 0;
   }
-  copy_limbs(q_limbs(res), q_limbs(poly) + (size_t)start * c.N, (size_t)n2 * c.N);  // = acehip_decomp, queued
+  copy_limbs(q_limbs(res), q_limbs(poly) + (size_t)start * c.N, (size_t)n2 * c.N, level, start);  // = acehip_decomp, queued
   res->_is_ntt = poly->_is_ntt;
   return res;
 }
@@ -851,7 +1074,7 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
     m.lent = (u64*)res->_data;
     m.lent_digit = (int)q_part_idx;
   } else {  // res is not a pool block of its own (a view, foreign memory): copy
-    copy_limbs(q_limbs(res), m.blk[slot], E);  // (queued: counts as a write of res, which is neither the source nor a digit)
+    copy_limbs(q_limbs(res), m.blk[slot], E, level);  // (queued: counts as a write of res, which is neither the source nor a digit)
   }
   res->_is_ntt = true;
   return res;
@@ -891,7 +1114,7 @@ POLY Rescale(POLY res, POLY poly) {
   if (res == poly || res->_data == poly->_data) {
     u64* tmp = dalloc((size_t)(level - 1) * c.N, false);
     HIPCHK(acehip_rescale(c.hip, tmp, q_limbs(poly), level, nullptr));
-    copy_limbs((u64*)q_limbs(res), (const u64*)tmp, (size_t)(level - 1) * c.N);
+    copy_limbs((u64*)q_limbs(res), (const u64*)tmp, (size_t)(level - 1) * c.N, level - 1);
     dfree(tmp);
   } else {
     u64* out = q_limbs(res);

@@ -14,9 +14,18 @@
 // Formats, little endian, words are u64 residues in [0, q):
 //   "ACEHCT01": u32 n_polys, N, level, num_p, is_ntt, slots, sf_degree, 0; f64 scaling_factor;
 //               per polynomial `level` q-limbs then `num_p` p-limbs of N words
-//   "ACEHKEY1": u32 version(1), N, L, K, dnum, n_rot, n_auto, 0; u64 primes[L+K];
-//               sk (NTT domain) [L+K][N]; pk0 [L][N]; pk1 [L][N]; relin key [dnum][2][L+K][N] (b_j then a_j);
+//   "ACEHKEY1": u32 version(1), N, L, K, dnum, n_rot, n_auto, flags; u64 primes[L+K];
+//               [sk (NTT domain) [L+K][N] unless flags & 1]; pk0 [L][N]; pk1 [L][N]; relin key [dnum][2][L+K][N] (b_j then a_j);
 //               n_rot x {i32 rotation, u32 automorphism index}; n_auto x {u32 automorphism index, u32 0, key as above}
+//               flags bit 0: EVALUATION key set -- no secret key inside (what a client hands to the server that runs
+//               Main_graph: Acehip_rt_save_eval_keys).  Key files are created with mode 0600.
+// Both formats are read defensively (sizes against the header before anything is replaced, header fields and residues
+// range-checked): a truncated or corrupt file leaves the context as it was.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
 #include <cstring>
 
 #include "rt_internal.hpp"
@@ -27,7 +36,22 @@ namespace {
 struct File {
   FILE* f = nullptr;
   const char* path;
-  File(const char* p, const char* mode) : path(p) { f = fopen(p, mode); }
+  File(const char* p, const char* mode, bool secret = false) : path(p) {
+    if (secret) {  // key material: never readable by group / others, whatever the umask says
+      const int fd = open(p, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+      if (fd >= 0) {
+        (void)fchmod(fd, 0600);
+        f = fdopen(fd, mode);
+        if (!f) close(fd);
+      }
+    } else {
+      f = fopen(p, mode);
+    }
+  }
+  long size() const {
+    struct stat st;
+    return f && fstat(fileno(f), &st) == 0 ? (long)st.st_size : -1;
+  }
   ~File() {
     if (f) fclose(f);
   }
@@ -37,21 +61,35 @@ struct File {
 constexpr size_t kChunkWords = 1u << 20;  // 8 MiB staging
 thread_local std::vector<u64> g_stage;
 
-bool put_device(File& f, const u64* d, size_t words) {
+// `n_limbs` limbs at d; limb i has prime gi0 + i of a chain extended at `level` (limb-sharded execution: every limb is
+// fetched from its owner first)
+bool put_device(File& f, const u64* d, u32 n_limbs, u32 level, u32 pos0) {
+  Context& c = ctx();
+  const size_t words = (size_t)n_limbs * c.N;
+  if (c.shard_world > 1) HIPCHK(acehip_shard_gather(c.hip, const_cast<u64*>(d) - (size_t)pos0 * c.N, level, pos0, n_limbs, nullptr));
   g_stage.resize(std::min(words, kChunkWords));
   for (size_t off = 0; off < words; off += kChunkWords) {
     const size_t n = std::min(kChunkWords, words - off);
-    HIPCHK(acehip_memcpy_d2h(g_stage.data(), d + off, n * 8, nullptr));
+    HIPCHK(acehip_download(c.hip, g_stage.data(), d + off, n * 8, nullptr));
     if (!f.put(g_stage.data(), n * 8)) return false;
   }
   return true;
 }
-bool get_device(File& f, u64* d, size_t words) {
-  g_stage.resize(std::min(words, kChunkWords));
-  for (size_t off = 0; off < words; off += kChunkWords) {
-    const size_t n = std::min(kChunkWords, words - off);
-    if (!f.get(g_stage.data(), n * 8)) return false;
-    HIPCHK(acehip_memcpy_h2d(d + off, g_stage.data(), n * 8, nullptr));
+// the same limbs read back; every word must be a residue of its limb's prime.  false: short read or a word out of range
+bool get_device(File& f, u64* d, u32 n_limbs, u32 level, u32 pos0) {
+  Context& c = ctx();
+  const size_t N = c.N;
+  g_stage.resize(std::min((size_t)n_limbs * N, kChunkWords));
+  for (u32 l = 0; l < n_limbs; ++l) {
+    const u32 pos = pos0 + l;
+    const u64 q = c.primes[pos < level ? pos : c.L + (pos - level)];
+    for (size_t off = 0; off < N; off += kChunkWords) {
+      const size_t n = std::min(kChunkWords, N - off);
+      if (!f.get(g_stage.data(), n * 8)) return false;
+      for (size_t i = 0; i < n; ++i)
+        if (g_stage[i] >= q) return false;
+      HIPCHK(acehip_upload(c.hip, d + (size_t)l * N + off, g_stage.data(), n * 8, nullptr));
+    }
   }
   return true;
 }
@@ -60,14 +98,15 @@ int save_polys(const char* path, POLYNOMIAL* const* polys, u32 n_polys, u32 slot
   File f(path, "wb");
   if (!f.f) return -1;
   sync();
+  ImageScope one_image(selected_image());  // (image batches: the selected image's copy)
   const POLYNOMIAL& p0 = *polys[0];
   const u32 h[8] = {n_polys, p0._ring_degree, (u32)p0._num_primes, (u32)p0._num_primes_p, p0._is_ntt ? 1u : 0u, slots, sf_degree, 0};
   bool ok = f.put("ACEHCT01", 8) && f.put(h, sizeof(h)) && f.put(&sf, 8);
   for (u32 i = 0; ok && i < n_polys; ++i) {
     POLYNOMIAL* p = polys[i];
     RT_ASSERT(p->_num_primes == p0._num_primes && p->_num_primes_p == p0._num_primes_p, "save: polynomials of different shape");
-    ok = put_device(f, q_limbs(p), p->_num_primes * (size_t)p->_ring_degree);
-    if (ok && p->_num_primes_p) ok = put_device(f, p_limbs(p), p->_num_primes_p * (size_t)p->_ring_degree);
+    ok = put_device(f, q_limbs(p), (u32)p->_num_primes, (u32)p->_num_primes, 0);
+    if (ok && p->_num_primes_p) ok = put_device(f, p_limbs(p), (u32)p->_num_primes_p, 0, 0);
   }
   return ok ? 0 : -1;
 }
@@ -80,15 +119,31 @@ int load_polys(const char* path, POLYNOMIAL* const* polys, u32 n_polys, u32* slo
   u32 h[8];
   if (!f.get(magic, 8) || memcmp(magic, "ACEHCT01", 8) != 0 || !f.get(h, sizeof(h)) || !f.get(sf, 8)) return -2;
   if (h[0] != n_polys || h[1] != c.N || h[2] == 0 || h[2] > c.L || (h[3] != 0 && h[3] != c.K)) return -3;
+  // the header drives decode / rotate index arithmetic and the kernels' value ranges: nothing out of contract gets in
+  double sfv;
+  memcpy(&sfv, sf, 8);
+  if (h[5] == 0 || h[5] > c.N / 2 || (h[5] & (h[5] - 1)) != 0 || h[6] == 0 || h[4] > 1 || !std::isfinite(sfv) || !(sfv > 0)) return -2;
+  if (f.size() != (long)(8 + sizeof(h) + 8 + (size_t)n_polys * (h[2] + h[3]) * c.N * 8)) return -2;
+  ImageScope one_image(selected_image());
+  // into fresh blocks first: the caller's polynomials change only when the whole file was good
+  std::vector<POLYNOMIAL> fresh(n_polys);
+  bool ok = true;
+  for (u32 i = 0; i < n_polys; ++i) {
+    memset(&fresh[i], 0, sizeof(POLYNOMIAL));
+    poly_alloc(&fresh[i], c.N, h[2], h[3], false);
+    fresh[i]._is_ntt = h[4] != 0;
+    ok = ok && get_device(f, q_limbs(&fresh[i]), h[2], h[2], 0);
+    if (ok && h[3]) ok = get_device(f, p_limbs(&fresh[i]), h[3], 0, 0);
+  }
+  if (!ok) {
+    for (auto& p : fresh) poly_free(&p);
+    return -2;
+  }
   *slots = h[5];
   *sf_degree = h[6];
   for (u32 i = 0; i < n_polys; ++i) {
-    POLYNOMIAL* p = polys[i];
-    poly_free(p);
-    poly_alloc(p, c.N, h[2], h[3], false);
-    p->_is_ntt = h[4] != 0;
-    if (!get_device(f, q_limbs(p), (size_t)h[2] * c.N)) return -2;
-    if (h[3] && !get_device(f, p_limbs(p), (size_t)h[3] * c.N)) return -2;
+    poly_free(polys[i]);
+    *polys[i] = fresh[i];
   }
   return 0;
 }
@@ -116,18 +171,26 @@ void adopt_key(Context& c, SwitchKeyStore* sk) {  // SWITCH_KEY shells over sk->
 }
 }  // namespace
 
-int save_keys(const char* path) {
+static int save_keys_impl(const char* path, bool with_secret) {
   std::lock_guard<std::recursive_mutex> lk(shared_mu());
   RT_ASSERT(g_primary != nullptr, "save_keys: no prepared context");
   Context& c = *g_primary;
-  File f(path, "wb");
+  if (with_secret && c.sk_ntt == nullptr) return -1;  // an evaluation-only context has no secret to write
+  File f(path, "wb", true);
   if (!f.f) return -1;
   sync();
+  UniformScope keys_are_shared;
   const u32 T = c.L + c.K;
-  const u32 h[8] = {1, c.N, c.L, c.K, c.dnum, (u32)c.rot2auto.size(), (u32)c.auto_keys.size(), 0};
+  const u32 h[8] = {1, c.N, c.L, c.K, c.dnum, (u32)c.rot2auto.size(), (u32)c.auto_keys.size(), with_secret ? 0u : 1u};
   bool ok = f.put("ACEHKEY1", 8) && f.put(h, sizeof(h)) && f.put(c.primes.data(), (size_t)T * 8);
-  ok = ok && put_device(f, c.sk_ntt, (size_t)T * c.N) && put_device(f, c.pk0, (size_t)c.L * c.N) && put_device(f, c.pk1, (size_t)c.L * c.N);
-  ok = ok && put_device(f, c.relin.data, key_words(c));
+  auto put_key = [&](const u64* data) {  // [dnum][2] polynomials of L + K limbs
+    bool good = true;
+    for (u32 j = 0; good && j < 2 * c.dnum; ++j) good = put_device(f, data + (size_t)j * T * c.N, T, c.L, 0);
+    return good;
+  };
+  if (with_secret) ok = ok && put_device(f, c.sk_ntt, T, c.L, 0);
+  ok = ok && put_device(f, c.pk0, c.L, c.L, 0) && put_device(f, c.pk1, c.L, c.L, 0);
+  ok = ok && put_key(c.relin.data);
   for (auto& kv : c.rot2auto) {
     const int32_t rot = kv.first;
     const u32 k = kv.second;
@@ -135,13 +198,15 @@ int save_keys(const char* path) {
   }
   for (auto& kv : c.auto_keys) {
     const u32 e[2] = {kv.first, 0};
-    ok = ok && f.put(e, 8) && put_device(f, kv.second->data, key_words(c));
+    ok = ok && f.put(e, 8) && put_key(kv.second->data);
   }
   return ok ? 0 : -1;
 }
+int save_keys(const char* path) { return save_keys_impl(path, true); }
+int save_eval_keys(const char* path) { return save_keys_impl(path, false); }
 
-// Replaces (or provides) the key set of the prepared context.  Returns 0, -1 cannot open, -2 truncated / bad magic,
-// -3 the file was written for other parameters.
+// Replaces (or provides) the key set of the prepared context.  Returns 0, -1 cannot open, -2 truncated / bad magic / a word
+// that is no residue, -3 the file was written for other parameters.  The context changes only when the whole file was good.
 int load_keys(const char* path) {
   std::lock_guard<std::recursive_mutex> lk(shared_mu());
   RT_ASSERT(g_primary != nullptr && g_ctx == g_primary, "load_keys: call from the thread that prepared the context");
@@ -152,47 +217,81 @@ int load_keys(const char* path) {
   u32 h[8];
   if (!f.get(magic, 8) || memcmp(magic, "ACEHKEY1", 8) != 0 || !f.get(h, sizeof(h))) return -2;
   const u32 T = c.L + c.K;
-  if (h[0] != 1 || h[1] != c.N || h[2] != c.L || h[3] != c.K || h[4] != c.dnum) return -3;
+  if (h[0] != 1 || h[1] != c.N || h[2] != c.L || h[3] != c.K || h[4] != c.dnum || h[7] > 1) return -3;
+  const bool has_sk = (h[7] & 1) == 0;
+  {  // the size the header promises, before anything is touched
+    const size_t poly = (size_t)c.N * 8;
+    const size_t want = 8 + sizeof(h) + (size_t)T * 8 + (has_sk ? T * poly : 0) + 2 * c.L * poly + key_words(c) * 8 + (size_t)h[5] * 8 +
+                        (size_t)h[6] * (8 + key_words(c) * 8);
+    if (h[5] > (1u << 20) || h[6] > (1u << 20) || f.size() != (long)want) return -2;
+  }
   std::vector<u64> primes(T);
   if (!f.get(primes.data(), (size_t)T * 8)) return -2;
   if (primes != c.primes) return -3;
   sync();
-  // drop what is there
-  for (auto& kv : c.auto_keys) free_switch_key(kv.second);
-  c.auto_keys.clear();
-  c.rot2auto.clear();
-  if (c.relin.data) dfree(c.relin.data);
-  if (c.sk_ntt) dfree(c.sk_ntt);
-  if (c.pk0) dfree(c.pk0);
-  if (c.pk1) dfree(c.pk1);
-  c.sk_coef.clear();
-  c.sk_ntt = shared_alloc((size_t)T * c.N, false);
-  c.pk0 = shared_alloc((size_t)c.L * c.N, false);
-  c.pk1 = shared_alloc((size_t)c.L * c.N, false);
-  c.relin.data = shared_alloc(key_words(c), false);
-  bool ok = get_device(f, c.sk_ntt, (size_t)T * c.N) && get_device(f, c.pk0, (size_t)c.L * c.N) && get_device(f, c.pk1, (size_t)c.L * c.N) &&
-            get_device(f, c.relin.data, key_words(c));
-  if (!ok) return -2;
-  adopt_key(c, &c.relin);
-  for (u32 i = 0; i < h[5]; ++i) {
+  UniformScope keys_are_shared;
+  // everything into fresh buffers; the context's keys are exchanged for them at the very end
+  struct Fresh {
+    u64 *sk = nullptr, *pk0 = nullptr, *pk1 = nullptr, *relin = nullptr;
+    std::map<int32_t, u32> rot2auto;
+    std::map<u32, SwitchKeyStore*> auto_keys;
+  } n;
+  auto get_key = [&](u64* data) {
+    bool good = true;
+    for (u32 j = 0; good && j < 2 * c.dnum; ++j) good = get_device(f, data + (size_t)j * T * c.N, T, c.L, 0);
+    return good;
+  };
+  auto drop = [&](Fresh& x) {
+    for (u64* p : {x.sk, x.pk0, x.pk1, x.relin})
+      if (p) dfree(p);
+    for (auto& kv : x.auto_keys) free_switch_key(kv.second);
+  };
+  bool ok = true;
+  if (has_sk) {
+    n.sk = shared_alloc((size_t)T * c.N, false);
+    ok = get_device(f, n.sk, T, c.L, 0);
+  }
+  n.pk0 = shared_alloc((size_t)c.L * c.N, false);
+  n.pk1 = shared_alloc((size_t)c.L * c.N, false);
+  n.relin = shared_alloc(key_words(c), false);
+  ok = ok && get_device(f, n.pk0, c.L, c.L, 0) && get_device(f, n.pk1, c.L, c.L, 0) && get_key(n.relin);
+  for (u32 i = 0; ok && i < h[5]; ++i) {
     int32_t rot;
     u32 k;
-    if (!f.get(&rot, 4) || !f.get(&k, 4)) return -2;
-    c.rot2auto[rot] = k;
+    ok = f.get(&rot, 4) && f.get(&k, 4) && (k & 1) == 1 && k < 2 * c.N;
+    if (ok) n.rot2auto[rot] = k;
   }
-  for (u32 i = 0; i < h[6]; ++i) {
+  for (u32 i = 0; ok && i < h[6]; ++i) {
     u32 e[2];
-    if (!f.get(e, 8)) return -2;
+    ok = f.get(e, 8) && (e[0] & 1) == 1 && e[0] < 2 * c.N && n.auto_keys.find(e[0]) == n.auto_keys.end();
+    if (!ok) break;
     auto* sk = new SwitchKeyStore();
     sk->data = shared_alloc(key_words(c), false);
-    if (!get_device(f, sk->data, key_words(c))) {
-      free_switch_key(sk);
-      return -2;
-    }
-    adopt_key(c, sk);
-    c.auto_keys[e[0]] = sk;
+    n.auto_keys[e[0]] = sk;
+    ok = get_key(sk->data);
+    if (ok) adopt_key(c, sk);
+  }
+  if (!ok) {
+    drop(n);
+    return -2;
   }
   sync();
+  // the exchange: from here on nothing can fail
+  Fresh old;
+  old.sk = c.sk_ntt;
+  old.pk0 = c.pk0;
+  old.pk1 = c.pk1;
+  old.relin = c.relin.data;
+  old.auto_keys.swap(c.auto_keys);
+  c.rot2auto.swap(n.rot2auto);
+  c.auto_keys.swap(n.auto_keys);
+  c.sk_ntt = n.sk;
+  c.pk0 = n.pk0;
+  c.pk1 = n.pk1;
+  c.relin.data = n.relin;
+  c.sk_coef.clear();
+  adopt_key(c, &c.relin);
+  drop(old);
   c.keys_loaded = true;
   return 0;
 }
@@ -228,6 +327,8 @@ int Acehip_rt_load_plain(PLAIN c, const char* path) {
   return load_polys(path, p, 1, &c->_slots, &c->_scaling_factor, &c->_sf_degree);
 }
 int Acehip_rt_save_keys(const char* path) { return save_keys(path); }
+// the key set WITHOUT the secret key: what the party that only evaluates (Main_graph) needs; such a context cannot decrypt
+int Acehip_rt_save_eval_keys(const char* path) { return save_eval_keys(path); }
 int Acehip_rt_load_keys(const char* path) { return load_keys(path); }
 
 }  // extern "C"

@@ -5,9 +5,11 @@
 namespace acehip {
 
 // out[pos][n] = vals[n] mod q (canonical), vals signed 64-bit
-__global__ __launch_bounds__(256) void values_to_rns_kernel(DevCtx c, u64* __restrict__ out, const int64_t* __restrict__ vals,
-                                                            u32 level, u32 pos0) {
+__global__ __launch_bounds__(256) void values_to_rns_kernel(DevCtx c, u64* out, const int64_t* vals, u32 level, u32 pos0) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);
+  vals = reb(c, vals, c.rep0 + blockIdx.z);
   const DevPrime& P = c.primes[limb_prime(pos, level, c.L)];
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
@@ -19,20 +21,22 @@ __global__ __launch_bounds__(256) void values_to_rns_kernel(DevCtx c, u64* __res
 }
 
 // out[n] = centred representative of in[n] mod prime gi (as int64); in place allowed
-__global__ __launch_bounds__(256) void center_kernel(DevCtx c, int64_t* __restrict__ out, const u64* __restrict__ in, u32 gi) {
+__global__ __launch_bounds__(256) void center_kernel(DevCtx c, int64_t* out, const u64* in, u32 gi) {
   const u32 n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= c.N) return;
+  if (n >= c.N || !owns(c, gi)) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);
+  in = reb(c, in, c.rep0 + blockIdx.z);
   const u64 q = c.primes[gi].q, v = in[n];
   out[n] = (int64_t)(v > (q >> 1) ? v - q : v);
 }
 void launch_center(const DevCtx& c, int64_t* out, const u64* in, u32 gi, hipStream_t s) {
-  hipLaunchKernelGGL(center_kernel, dim3((c.N + 255) / 256), dim3(256), 0, s, c, out, in, gi);
+  hipLaunchKernelGGL(center_kernel, dim3((c.N + 255) / 256, 1, c.nrep), dim3(256), 0, s, c, out, in, gi);
 }
 
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
-  dim3 grid((c.N + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N + 255) / 256, n_limbs, c.nrep), block(256);
   hipLaunchKernelGGL(values_to_rns_kernel, grid, block, 0, s, c, out, vals, level, pos0);
 }
 
@@ -43,8 +47,10 @@ __device__ __forceinline__ u64 mix64(u64 z) {
 }
 
 // uniform in [0,q): 128 random bits reduced mod q (bias < 2^-60)
-__global__ __launch_bounds__(256) void sample_uniform_kernel(DevCtx c, u64* __restrict__ out, u32 level, u32 pos0, u64 seed) {
+__global__ __launch_bounds__(256) void sample_uniform_kernel(DevCtx c, u64* out, u32 level, u32 pos0, u64 seed) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);  // (every replica gets the same sample: a launch over several replicas is a broadcast)
   const DevPrime& P = c.primes[limb_prime(pos, level, c.L)];
   const u32 n = blockIdx.x * 256 + threadIdx.x;
   if (n >= c.N) return;
@@ -57,13 +63,15 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(DevCtx c, u64* __re
 void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s) {
   ACEHIP_ABLATE(ABL_OTHER);
   if (n_limbs == 0) return;
-  dim3 grid((c.N + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N + 255) / 256, n_limbs, c.nrep), block(256);
   hipLaunchKernelGGL(sample_uniform_kernel, grid, block, 0, s, c, out, level, pos0, seed);
 }
 
-__global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
-                                                          LimbConsts w, u32 level, u32 pos0) {
+__global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* r, const u64* a, LimbConsts w, u32 level, u32 pos0) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  r = reb(c, r, c.rep0 + blockIdx.z);
+  a = reb(c, a, c.rep0 + blockIdx.z);
   const DevPrime P = c.primes[limb_prime(pos, level, c.L)];
   const u64 wl = w.w[blockIdx.y];
   const size_t base = (size_t)pos * c.N;
@@ -75,9 +83,11 @@ __global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* __restr
   *reinterpret_cast<ulong2*>(r + base + i) = v;
 }
 
-__global__ __launch_bounds__(256) void add_scalars_kernel(DevCtx c, u64* __restrict__ r, const u64* __restrict__ a,
-                                                          LimbConsts w, u32 level, u32 pos0) {
+__global__ __launch_bounds__(256) void add_scalars_kernel(DevCtx c, u64* r, const u64* a, LimbConsts w, u32 level, u32 pos0) {
   const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  r = reb(c, r, c.rep0 + blockIdx.z);
+  a = reb(c, a, c.rep0 + blockIdx.z);
   const u64 q = c.primes[limb_prime(pos, level, c.L)].q;
   const u64 wl = w.w[blockIdx.y];
   const size_t base = (size_t)pos * c.N;
@@ -93,7 +103,7 @@ void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts&
                         hipStream_t s) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, c.nrep), block(256);
   hipLaunchKernelGGL(add_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);
 }
 
@@ -101,7 +111,7 @@ void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts&
                         hipStream_t s) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_limbs == 0) return;
-  dim3 grid((c.N / 2 + 255) / 256, n_limbs), block(256);
+  dim3 grid((c.N / 2 + 255) / 256, n_limbs, c.nrep), block(256);
   hipLaunchKernelGGL(mul_scalars_kernel, grid, block, 0, s, c, r, a, w, level, pos0);
 }
 

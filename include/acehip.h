@@ -139,9 +139,12 @@ enum {
   ACEHIP_HW_ADD = 0, ACEHIP_HW_MUL = 1, ACEHIP_HW_ROTATE = 2, ACEHIP_HW_COPY = 3, ACEHIP_HW_ZERO = 4,
   ACEHIP_HW_SUB = 5, ACEHIP_HW_MULADD = 6, ACEHIP_HW_MULC = 7, ACEHIP_HW_ADDC = 8
 };
+/* prime_gi of an op whose result is not a limb of the chain (limb-sharded execution only: every rank runs it) */
+#define ACEHIP_HW_ANY_RANK 0xffffffffu
 typedef struct acehip_hw_op {
   uint32_t        op;        /* ACEHIP_HW_* */
-  uint32_t        prime_gi;  /* ADD/MUL: global prime index (q: 0..L-1, p: L..L+K-1) */
+  uint32_t        prime_gi;  /* global prime index of the limb (q: 0..L-1, p: L..L+K-1): the modulus of the arithmetic kinds; for
+                                every kind the limb's owner under limb-sharded execution (ROTATE / COPY / ZERO ignore it otherwise) */
   uint64_t*       res;
   const uint64_t* a;
   const void*     b;         /* second operand (uint64 limb); uint32 automorphism table (ROTATE); residue (MULC/ADDC) */
@@ -285,6 +288,35 @@ int acehip_bsgs_inner_rot(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* co
                           const uint64_t* const* d_in1, const uint32_t* h_in_auto, const uint64_t* const* d_pt, uint32_t g, uint32_t b,
                           uint32_t pt_q_limbs, uint32_t level, acehip_stream stream);
 
+/* ---- replicas of the caller's polynomial memory: image batches and simulated ranks ----
+ * The reference gets throughput from one OpenMP thread per image (rtlib/ant/dataset/resnet_cifar.main.inc:77-116); all
+ * images run the same data-oblivious program on the same keys and weights.  The GPU form: the caller keeps its ciphertext
+ * polynomials in ONE arena of which n_replicas copies exist, stride_bytes apart (replica r of the block at address p is at
+ * p + r * stride_bytes), and every launch covers the selected replicas [rep0, rep0 + nrep): a device pointer argument that
+ * lies inside replica 0 of the arena is moved along with the replica by the kernels, anything else (switch keys, twiddles,
+ * automorphism tables, bootstrap diagonals, weight plaintexts) is shared by all replicas and read once per launch.  With the
+ * default selection (0, 1) every entry point behaves exactly as without an arena.
+ * workspace / hw_scratch: scratch of the pipelines (acehip_workspace_words() words) and of acehip_hw_batch (hw_scratch_limbs
+ * limbs of N words), both INSIDE replica 0 of the arena so that every replica has its own; required when n_replicas > 1. */
+typedef struct acehip_arena_cfg {
+  void*    base;          /* replica 0 (device memory) */
+  size_t   bytes;         /* size of one replica */
+  size_t   stride_bytes;  /* distance between replicas, >= bytes */
+  uint32_t n_replicas;
+  void*    workspace;
+  void*    hw_scratch;
+  size_t   hw_scratch_limbs;
+} acehip_arena_cfg;
+int    acehip_ctx_set_arena(acehip_ctx* ctx, const acehip_arena_cfg* cfg);   /* cfg == NULL: back to no arena */
+size_t acehip_workspace_words(const acehip_ctx* ctx);
+int    acehip_ctx_select(acehip_ctx* ctx, uint32_t rep0, uint32_t nrep);     /* launches that follow cover these replicas */
+/* host <-> device copies and fills that follow the selection: a destination inside the arena is written in every selected
+ * replica, a source inside the arena is read from the first selected one.  upload / download synchronise the stream. */
+int acehip_upload(acehip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, acehip_stream stream);
+int acehip_download(acehip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, acehip_stream stream);
+int acehip_fill(acehip_ctx* ctx, void* d_ptr, int value, size_t bytes, acehip_stream stream);
+int acehip_copy(acehip_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, acehip_stream stream);
+
 /* ---- limb-sharded execution (BASELINE configs[4]: RNS limbs spread over the GPUs of a node) ----
  * Rank r of `world` owns the limbs gi with gi % world == r (q_i: gi = i, p_j: gi = L + j) of every polynomial and
  * switch key, PACKED in ascending gi; ownership does not depend on the level.  One hybrid key-switch
@@ -318,6 +350,33 @@ int acehip_shard_rescale_apply(acehip_shard* shard, uint64_t* d_out0, uint64_t* 
                                const uint64_t* d_last, uint32_t level, acehip_stream stream);
 int acehip_encode_message(acehip_ctx* ctx, int64_t* d_msg, const void* d_vals, int kind, size_t len, uint32_t slots, double scaling_factor, acehip_stream stream);
 int acehip_shard_encode_limbs(acehip_shard* shard, uint64_t* d_q_own, const int64_t* d_msg, double scaling_factor, uint32_t sf_degree, uint32_t level, acehip_stream stream);
+
+/* ---- limb-sharded execution as a MODE of the context (BASELINE configs[4]: a whole generated program runs sharded) ----
+ * Once enabled, EVERY entry point above works on the limbs its rank owns (gi % world == rank; polynomials keep the full
+ * layout of the reference, the other limbs are simply not touched) and the three places where limbs have to meet -- the
+ * sources of a ModUp (Decompose_modup polynomial.c:1241-1335), the P-limbs of a ModDown (Reduce_rns_base :928-967), the last
+ * limb of a Rescale (Rescale_poly :1097-1163) / limb 0 of a ModRaise (ckks_bootstrap_context.c:1527-1551) -- exchange them
+ * inside the call: every rank runs the same call sequence (SPMD), results are bit-identical to the unsharded library.
+ *   acehip_ctx_shard_sim:  `world` simulated ranks in this process; rank r's limbs live in replica r of the arena
+ *                          (acehip_ctx_set_arena with n_replicas >= world), exchanges are device copies.  For tests on one GPU.
+ *   acehip_ctx_shard_rccl: this process is rank `rank` of `world`, one GPU each; exchanges are RCCL broadcasts from the owning
+ *                          rank on the launch stream (grouped; xGMI on a node).  unique_id: the 128 bytes of acehip_rccl_unique_id()
+ *                          of rank 0, handed to every rank by the caller (a file, torch.distributed, MPI ...).
+ * acehip_shard_gather: limbs [pos0, pos0 + n_limbs) of a polynomial become valid on every rank (decode, serialisation). */
+int      acehip_ctx_shard_sim(acehip_ctx* ctx, uint32_t world);
+int      acehip_rccl_unique_id(void* out, size_t cap);   /* returns the number of bytes written (128) or a negative error */
+int      acehip_ctx_shard_rccl(acehip_ctx* ctx, uint32_t rank, uint32_t world, const void* unique_id, size_t id_bytes);
+int      acehip_shard_gather(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);
+uint32_t acehip_shard_world(const acehip_ctx* ctx);                 /* 1: not sharded */
+uint32_t acehip_shard_rank(const acehip_ctx* ctx);                  /* first hosted rank */
+uint32_t acehip_shard_owned_limbs(const acehip_ctx* ctx, uint32_t rank);   /* limbs of the full chain (L + K) rank owns */
+/* exchange statistics of this context: steps[0] = exchange steps, steps[1] = limbs moved to this process, returns bytes moved */
+uint64_t acehip_shard_traffic(const acehip_ctx* ctx, uint64_t* steps, int reset);
+/* The exchange schedule of one operation, for checking it without a GPU (works on a host-only context): which limb positions
+ * are exchanged at each step and which rank sends them.  op: 0 ModUp of all digits, 1 ModDown, 2 Rescale, 3 ModRaise.
+ * Writes up to cap entries {step, position, root rank}; returns the number of entries. */
+int acehip_shard_schedule(const acehip_ctx* ctx, uint32_t world, int op, uint32_t level, uint32_t* out_step, uint32_t* out_pos,
+                          uint32_t* out_root, size_t cap);
 
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);

@@ -37,6 +37,34 @@ int        Acehip_rt_load_ciph3(CIPHER3 ciph, const char* path);
 int        Acehip_rt_load_plain(PLAIN plain, const char* path);
 int        Acehip_rt_save_keys(const char* path);
 int        Acehip_rt_load_keys(const char* path);                 /* replaces the keys of the prepared context */
+/* The key set without the secret key (header flag): what a client hands to the party that only runs Main_graph.  A context
+ * that loaded such a set evaluates but cannot decrypt, and cannot make further rotation keys.  Key files get mode 0600. */
+int        Acehip_rt_save_eval_keys(const char* path);
+/* Extension: image batches -- the GPU form of the reference's image-parallel loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116:
+ * one OpenMP thread per image on shared keys and weights).  After Acehip_rt_set_batch(B) (or with ACEHIP_BATCH=B in the
+ * environment) every launch of this thread carries B images: each has its own copy of every ciphertext buffer, while switch keys,
+ * twiddles, bootstrap tables and the encoded weight plaintexts are read / produced once per batch.  Per batch:
+ *     for (k = 0; k < B; k++) { Acehip_rt_select_image(k); Prepare_input(tensor_k, "input"); }
+ *     Run_main_graph();                                     // once
+ *     for (k = 0; k < B; k++) { Acehip_rt_select_image(k); out_k = Handle_output("output"); }
+ * Results are bit-identical, image by image, to B separate runs with the same keys and encryption randomness.  Call
+ * Acehip_rt_set_batch after Prepare_context and before the thread's first Prepare_input.  Acehip_rt_save_ciph / load_ciph,
+ * Get_msg & co. address the selected image. */
+void       Acehip_rt_set_batch(uint32_t n_images);
+uint32_t   Acehip_rt_batch(void);
+void       Acehip_rt_select_image(uint32_t k);
+/* Extension: limb-sharded execution (BASELINE configs[4]): the RNS limbs of every polynomial are spread over the ranks
+ * (limb gi on rank gi % world), every rank runs the SAME program (SPMD) and the limbs meet -- RCCL broadcasts over xGMI --
+ * only where the algorithm needs them together: Decomp_modup (polynomial.c:1241-1335), Mod_down (:928-967), Rescale
+ * (:1097-1163), the ModRaise of Bootstrap (ckks_bootstrap_context.c:1527-1551) and decode.  Nothing changes in the program.
+ *   ACEHIP_SHARD=1      the processes of a launcher (RANK / WORLD_SIZE / LOCAL_RANK: torchrun, mpirun) are the ranks, one GPU
+ *                       each; all need the same ACEHIP_SEED or ACEHIP_KEYS_FILE (else the seed is taken from the RCCL id)
+ *   ACEHIP_SHARD_SIM=G  G ranks simulated on one GPU (tests): exchanges are device copies between per-rank buffers
+ * Every rank's Handle_output returns the full result.  Acehip_rt_shard_traffic: bytes this process received through
+ * exchanges so far; steps_limbs[0] = exchange steps, [1] = limbs. */
+uint32_t   Acehip_rt_shard_world(void);
+uint32_t   Acehip_rt_shard_rank(void);
+uint64_t   Acehip_rt_shard_traffic(uint64_t* steps_limbs, int reset);
 #ifdef __cplusplus
 }
 #endif
