@@ -216,6 +216,19 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
   Copy_ciph(out, data);
   Free_ciph_poly(data, 1);
   io_at(g_outputs, name, idx) = out;
+  // ACEHIP_DUMP_OUTPUT=<prefix>: every output ciphertext is also written to <prefix>.<call>.<image> (ACEHCT01, rt_serial.cpp):
+  // how the tests compare an image batch, or a limb-sharded run, bit for bit with the plain run of an unchanged program
+  if (const char* prefix = getenv("ACEHIP_DUMP_OUTPUT")) {
+    static thread_local unsigned n_call = 0;
+    const rt::u32 sel = rt::selected_image();
+    for (rt::u32 k = 0; k < rt::batch_size(); ++k) {
+      rt::select_image(k);
+      const std::string path = std::string(prefix) + "." + std::to_string(n_call) + "." + std::to_string(k);
+      RT_ASSERT(Acehip_rt_save_ciph(path.c_str(), out) == 0, "cannot write %s", path.c_str());
+    }
+    rt::select_image(sel);
+    ++n_call;
+  }
 }
 
 // ---- pt_mgr.c (message mode) ----

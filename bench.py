@@ -184,9 +184,10 @@ def cpu_baseline(have_model):
     return res
 
 
-def load_model_runtime(device):
+def load_model_runtime(device, batch=1):
     """dlopen the generated ResNet-20 (+ the rt_ant drop-in it is linked against) and return (lib, step):
-    step() pushes one synthetic image through Prepare_input / Run_main_graph / Handle_output."""
+    step() pushes `batch` synthetic images through Prepare_input / Run_main_graph / Handle_output -- one Run_main_graph per
+    batch (Acehip_rt_set_batch, include/rt_ant/rt_api.h: the images share every launch, key, twiddle and weight plaintext)."""
     import numpy as np
 
     os.environ["ACEHIP_DEVICE"] = str(device)
@@ -200,19 +201,28 @@ def load_model_runtime(device):
     fhe.Free_tensor.argtypes = [C.c_void_p]
     fhe.Handle_output.restype = C.POINTER(C.c_double)
     fhe.Handle_output.argtypes = [C.c_char_p]
+    fhe.Acehip_rt_set_batch.argtypes = [C.c_uint32]
+    fhe.Acehip_rt_select_image.argtypes = [C.c_uint32]
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
     img_rng = np.random.default_rng(1)
 
     def step():
-        img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
-        t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
-        fhe.Prepare_input(t, b"input")
-        fhe.Free_tensor(t)
+        for k in range(batch):
+            img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
+            t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
+            if batch > 1:
+                fhe.Acehip_rt_select_image(k)
+            fhe.Prepare_input(t, b"input")
+            fhe.Free_tensor(t)
         fhe.Run_main_graph()
-        out = fhe.Handle_output(b"output")
-        vals = [out[i] for i in range(10)]
-        libc.free(out)
+        vals = None
+        for k in range(batch):
+            if batch > 1:
+                fhe.Acehip_rt_select_image(k)
+            out = fhe.Handle_output(b"output")
+            vals = [out[i] for i in range(10)]
+            libc.free(out)
         return vals
 
     return fhe, step
@@ -236,9 +246,12 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=2,
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="images per launch on every stream (Acehip_rt_set_batch): the images of a batch share launches, keys, "
+                         "twiddles, bootstrap tables and encoded weight plaintexts; a step = one batch per stream")
     args = ap.parse_args()
 
     if args.mode == "shard":
@@ -315,6 +328,7 @@ def main():
 
     logits = None
     n_streams = max(args.streams, 1) if use_model else 1
+    n_batch = max(args.batch, 1) if use_model else 1
     if use_model:
         import threading
 
@@ -331,8 +345,9 @@ def main():
 
         def stream_main(i):
             try:
-                _, one_image = load_model_runtime(local_rank)  # per-thread image generator on the shared library
+                _, one_image = load_model_runtime(local_rank, n_batch)  # per-thread image generator on the shared library
                 fhe.Prepare_context()                          # attaches: shared keys, own scratch / pool / queue / stream
+                fhe.Acehip_rt_set_batch(n_batch)
                 while True:
                     gate.wait()
                     op = cmd["op"]
@@ -347,6 +362,7 @@ def main():
                         fhe.Finalize_context()                 # a worker's Finalize only gives back its own state
                     elif op == "attach":
                         fhe.Prepare_context()
+                        fhe.Acehip_rt_set_batch(n_batch)
                     gate.wait()
                     if op == "quit":
                         break
@@ -374,13 +390,14 @@ def main():
         unit, metric = "images/s", "encrypted images/sec (ResNet-20 CIFAR-10, N=2^16)"
         workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
                     "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
-                    "N(0,0.05); %d concurrent image streams per GPU (host threads with one context, key set and HIP stream each "
-                    "-- the reference's own parallel axis is one OpenMP thread per image), one image per stream per step"
-                    % n_streams)
+                    "N(0,0.05); %d concurrent image stream(s) per GPU (host threads attached to one context and key set, one HIP stream "
+                    "each) x batches of %d images per launch (the reference's own parallel axis is one OpenMP thread per image on "
+                    "shared keys and weights: the images of a batch share launches, keys, twiddles and weight plaintexts); a step = "
+                    "one batch per stream" % (n_streams, n_batch))
         if r110:
             metric = "encrypted images/sec (ResNet-110 CIFAR-10, N=2^16) -- secondary measurement, not the BASELINE headline"
             workload = ("the workload of BASELINE configs[4] (ACE-compiled ResNet-110/CIFAR-10, resnet110_cifar10_train.onnx.inc: N=2^16, "
-                        "36 464 weight plaintexts) run as REPLICAS: whole images per GPU, %d concurrent image streams per GPU; "
+                        "36 464 weight plaintexts) run as REPLICAS: whole images per GPU, %d concurrent image streams per GPU x batches of " + str(n_batch) + " images; "
                         "synthetic image and weights (with N(0,0.05) weights a 110-layer network leaves the range of the bootstrap on "
                         "both runtimes, so the logits are not meaningful: only the work is measured)" % n_streams)
     elif args.roofline_only:
@@ -424,11 +441,11 @@ def main():
         stats = read_stats(reset=False)
     barrier()
     elapsed = ranks.max_over_ranks(elapsed_local)
-    value = world * n_streams * args.steps / elapsed
+    value = world * n_streams * n_batch * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
     if use_model:
-        if world == 1:
+        if world == 1 and n_batch == 1:  # (an image batch shares each encode among its images already)
             # secondary, NOT the headline: the same streams with the encoded weight plaintexts kept in HBM
             # (ACEHIP_PT_CACHE=1, 12.3 GB shared by the streams; the reference's pre-encoded DE_PLAINTEXT mode)
             run_all("release")
@@ -441,7 +458,7 @@ def main():
             step(2)
             dt = (time.perf_counter() - tc) / 2
             os.environ["ACEHIP_PT_CACHE"] = "0"
-            cache_run = {"images_per_s": round(n_streams / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
+            cache_run = {"images_per_s": round(n_streams * n_batch / dt, 6), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
                          "streams_per_gpu": n_streams,
                          "note": "ACEHIP_PT_CACHE=1: weight plaintexts encoded once and kept resident (12.3 GB, shared by the "
                                  "image streams); reported beside the headline, which encodes all weight plaintexts for every "
@@ -499,8 +516,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(value / (1.0 / 7531.12 if r110 else BASELINE_IMAGES_PER_S), 1) if use_model else None),  # ace_pre.log
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload, "N": 65536, "streams_per_gpu": n_streams, "images_per_step": world * n_streams,
-                       "parallelism": "replicas: %d GPU(s) x %d image stream(s) per GPU" % (world, n_streams)},
+            "config": {"workload": workload, "N": 65536, "streams_per_gpu": n_streams, "images_per_batch": n_batch,
+                       "images_per_step": world * n_streams * n_batch,
+                       "parallelism": "replicas: %d GPU(s) x %d image stream(s) per GPU x %d images per batch" % (world, n_streams, n_batch)},
             "roofline": {"bound": "hbm",
                          "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -517,7 +535,7 @@ def main():
         # whole-workload view: algorithmic bytes of every entry-point call of the timed region on this rank
         alg = sum(v[2] for k, v in stats.items() if k != "zero_fill_executed")  # that family is a subset of "elementwise"
         out["workload_roofline"] = {
-            "algorithmic_bytes_per_image": int(alg / args.steps),
+            "algorithmic_bytes_per_image": int(alg / args.steps / n_batch),
             "algorithmic_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
             "algorithmic_frac_of_hbm_peak": round(n_streams * alg / elapsed_local / 1e9 / HBM_PEAK_GBS, 4),
             # counter-based: L2-miss traffic of one image (FETCH_SIZE x2 + WRITE_SIZE over every dispatch of a one-stream run,

@@ -1,0 +1,92 @@
+"""Image batches and limb-sharded execution behind the rt_ant API, on the GPU (-m gpu).
+
+Both are execution modes of the runtime under UNCHANGED generated programs (the reference's checked-in example programs and
+ResNet sources, compiled by `make -C workloads`), so the check is the strongest one available: with the same keys and the same
+encryption randomness (ACEHIP_SEED) every output CIPHERTEXT must be byte-identical to the plain run's -- written by the
+ACEHIP_DUMP_OUTPUT hook of Set_output_data (csrc/rt/rt_io.cpp) in the ACEHCT01 container.
+
+  * image batches (Acehip_rt_set_batch, BASELINE configs[3] throughput): B images per launch, keys / twiddles / bootstrap tables /
+    weight plaintexts shared -- the GPU form of the reference's image loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116);
+  * limb-sharded execution (BASELINE configs[4]): ACEHIP_SHARD_SIM=G runs G ranks on one GPU with separate per-rank buffers, the
+    exchanges at Decomp_modup / Mod_down / Rescale / ModRaise / decode being device copies (RCCL broadcasts between processes
+    otherwise: same code path above the exchange primitive).
+"""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+EX_DIR = os.path.join(ROOT, "workloads", "_gen", "examples")
+
+
+def _run(exe, args, env_extra, tmp, tag, timeout=900):
+    prefix = os.path.join(str(tmp), tag)
+    env = dict(os.environ, ACEHIP_SEED="20261004", ACEHIP_DUMP_OUTPUT=prefix, **env_extra)
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    dumps = sorted(glob.glob(prefix + ".*"))
+    assert dumps, "no output ciphertext was dumped"
+    return r.stdout, {os.path.basename(p)[len(tag) + 1:]: open(p, "rb").read() for p in dumps}
+
+
+def _need(exe):
+    if not os.path.exists(exe):
+        pytest.skip("workloads/_gen/examples not built (needs /root/reference: make -C workloads)")
+
+
+@pytest.mark.parametrize("name", ["rotate", "relin", "conv2d", "bootstrap", "bootstrap_02"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_reference_example_sharded_is_bit_identical(name, world, tmp_path):
+    """eg_fhertlib_* unchanged: G simulated ranks produce the output ciphertext of the unsharded run, byte for byte."""
+    exe = os.path.join(EX_DIR, "eg_" + name)
+    _need(exe)
+    out0, plain = _run(exe, [], {}, tmp_path, "plain")
+    out1, shard = _run(exe, [], {"ACEHIP_SHARD_SIM": str(world), "ACEHIP_PROFILE": "1"}, tmp_path, "shard%d" % world)
+    assert "SUCESS!" in out0 and "SUCESS!" in out1
+    assert plain.keys() == shard.keys()
+    for k in plain:
+        assert plain[k] == shard[k], "output ciphertext %s differs between the plain and the %d-rank run" % (k, world)
+    assert "limb-sharded world %d (simulated)" % world in out1
+    if name in ("rotate", "relin", "bootstrap", "bootstrap_02"):  # a key-switch exchanges limbs
+        line = [ln for ln in out1.splitlines() if "limb exchanges:" in ln]
+        assert line and int(line[0].split("limb exchanges:")[1].split()[0]) > 0, out1[-2000:]
+
+
+def _logit_lines(stdout):
+    return [ln.split("logits:")[1].split() for ln in stdout.splitlines() if "logits:" in ln]
+
+
+def test_resnet20_image_batches_are_bit_identical(tmp_path):
+    """The ACE-generated ResNet-20 (unchanged source, tools/model_main.c): 4 images one by one, as two batches of 2 and as one
+    batch of 4 -- every image's output ciphertext byte-identical, and the printed logits with it."""
+    exe = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+    _need(exe)
+    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
+    out1, d1 = _run(exe, ["4"], env, tmp_path, "b1", timeout=1200)
+    out2, d2 = _run(exe, ["4"], dict(env, MODEL_BATCH="2"), tmp_path, "b2", timeout=1200)
+    out4, d4 = _run(exe, ["4"], dict(env, MODEL_BATCH="4"), tmp_path, "b4", timeout=1200)
+    # one by one: call i, image 0; batches of 2: call i // 2, image i % 2; one batch of 4: call 0, image i
+    for i in range(4):
+        ref = d1["%d.0" % i]
+        assert d2["%d.%d" % (i // 2, i % 2)] == ref, "image %d differs in batches of 2" % i
+        assert d4["0.%d" % i] == ref, "image %d differs in a batch of 4" % i
+    assert _logit_lines(out1) == _logit_lines(out2) == _logit_lines(out4) and len(_logit_lines(out1)) == 4
+
+
+def test_resnet110_sharded_is_bit_identical(tmp_path):
+    """BASELINE configs[4] as a workload: one image of the ACE-generated ResNet-110 (rtlib/ant/dataset/resnet110_cifar10_train.onnx.inc,
+    unchanged) with its limbs spread over 2 and over 8 simulated ranks -- output ciphertext byte-identical to the unsharded run
+    (the keys come from the same ACEHIP_SEED in every run: generated limb by limb, each rank its own)."""
+    exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
+    _need(exe)
+    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
+    _, plain = _run(exe, ["1"], env, tmp_path, "plain", timeout=1500)
+    for world in (2, 8):
+        out, shard = _run(exe, ["1"], dict(env, ACEHIP_SHARD_SIM=str(world), ACEHIP_PROFILE="1"), tmp_path, "shard%d" % world, timeout=1500)
+        assert shard["0.0"] == plain["0.0"], "ResNet-110 output differs with %d ranks" % world
+        assert "limb-sharded world %d (simulated)" % world in out

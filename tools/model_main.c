@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdint.h>
 #include <time.h>
 
 #include "common/rtlib.h"
@@ -21,28 +22,45 @@ static double now_s(void) {
 int main(int argc, char* argv[]) {
   int    n_images = argc > 1 ? atoi(argv[1]) : 1;
   size_t c = argc > 4 ? atoi(argv[2]) : 3, h = argc > 4 ? atoi(argv[3]) : 32, w = argc > 4 ? atoi(argv[4]) : 32;
+  /* MODEL_BATCH=B: B images per Run_main_graph (Acehip_rt_set_batch, include/rt_ant/rt_api.h) -- the loop below is the
+   * reference's image loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116) with its body split at the batch boundary */
+  int    batch = getenv("MODEL_BATCH") ? atoi(getenv("MODEL_BATCH")) : 1;
   double t0 = now_s();
   Prepare_context();
   double t1 = now_s();
   printf("[MODEL] Prepare_context: %.3f s\n", t1 - t0);
+  if (batch < 1) batch = 1;
+  if (batch > 1) Acehip_rt_set_batch((uint32_t)batch);
   unsigned long long z = 1;
-  for (int img = 0; img < n_images; ++img) {
-    TENSOR* in = Alloc_tensor(1, c, h, w, NULL);
-    for (size_t i = 0; i < c * h * w; ++i) { /* U(-1,1), seed 1 */
-      z ^= z << 13; z ^= z >> 7; z ^= z << 17;
-      in->_vals[i] = (double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+  for (int img0 = 0; img0 < n_images; img0 += batch) {
+    const int nb = n_images - img0 < batch ? n_images - img0 : batch;
+    double    a  = now_s();
+    for (int k = 0; k < batch; ++k) { /* (a short last batch repeats its last image: every slot of the batch holds an input) */
+      TENSOR* in = Alloc_tensor(1, c, h, w, NULL);
+      unsigned long long zk = z;
+      for (size_t i = 0; i < c * h * w; ++i) { /* U(-1,1), seed 1 */
+        zk ^= zk << 13; zk ^= zk >> 7; zk ^= zk << 17;
+        in->_vals[i] = (double)(zk >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+      }
+      if (k < nb) z = zk;
+      if (batch > 1) Acehip_rt_select_image((uint32_t)k);
+      Prepare_input(in, "input");
+      Free_tensor(in);
     }
-    double a = now_s();
-    Prepare_input(in, "input");
-    Free_tensor(in);
     double b = now_s();
     Run_main_graph();
-    double* out = Handle_output("output");
-    double  e   = now_s();
-    printf("[MODEL] image %d: encrypt %.3f s, Main_graph+decrypt %.3f s, logits:", img, b - a, e - b);
-    for (int i = 0; i < 10; ++i) printf(" %.4f", out[i]);
-    printf("\n");
-    free(out);
+    double e0 = now_s();
+    for (int k = 0; k < batch; ++k) {
+      if (batch > 1) Acehip_rt_select_image((uint32_t)k);
+      double* out = Handle_output("output");
+      if (k < nb) {
+        printf("[MODEL] image %d: encrypt %.3f s, Main_graph+decrypt %.3f s, logits:", img0 + k, (b - a) / batch, (now_s() - b) / batch);
+        for (int i = 0; i < 10; ++i) printf(" %.4f", out[i]);
+        printf("\n");
+      }
+      free(out);
+    }
+    (void)e0;
   }
   Finalize_context();
   printf("[MODEL] total %.3f s\n", now_s() - t0);
