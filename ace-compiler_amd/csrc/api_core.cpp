@@ -334,8 +334,11 @@ int acehip_copy(acehip_ctx* c, void* d, const void* src, size_t n, acehip_stream
 // ---- memory helpers ----
 void* acehip_malloc(size_t bytes) {
   void* p = nullptr;
-  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-    acehip_err_slot() = "hipMalloc failed";
+  const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    acehip_err_slot() = std::string("hipMalloc failed: ") + hipGetErrorString(e) + " (" + std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")";
     return nullptr;
   }
   return p;

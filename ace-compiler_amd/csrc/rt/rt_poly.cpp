@@ -110,7 +110,12 @@ namespace {
 struct Arena {
   u64* base = nullptr;   // replica 0
   size_t words = 0;      // per replica (= stride)
-  size_t bump = 0, peak = 0;
+  // free extents of the slab, by address: start (words) -> length.  Freed blocks wait in the exact-size lists (pool_free: the
+  // program asks for the same few hundred sizes over and over) and are merged back into extents only when a request finds
+  // neither a block of its size nor a large enough extent: the footprint stays near the live bytes instead of the sum of every
+  // size class's high-water mark
+  std::map<size_t, size_t> ext;
+  size_t peak = 0;       // highest word ever handed out
   u32 nrep = 0;
   bool exhausted_warned = false;
 };
@@ -148,18 +153,20 @@ void arena_create() {
   a.nrep = nrep;
   // the first limbs stay unused: kernels may form addresses a few limbs below a block (a limb position subtracted from a
   // base) and those must still fall inside the slab to be moved with their replica
-  a.bump = guard;
+  size_t bump = guard;
   acehip_arena_cfg cfg{};
   cfg.base = a.base;
   cfg.bytes = words * 8;
   cfg.stride_bytes = words * 8;
   cfg.n_replicas = nrep;
-  cfg.workspace = a.base + a.bump;
-  a.bump += (ws_words + 31) & ~(size_t)31;
-  cfg.hw_scratch = a.base + a.bump;
+  cfg.workspace = a.base + bump;
+  bump += (ws_words + 31) & ~(size_t)31;
+  cfg.hw_scratch = a.base + bump;
   cfg.hw_scratch_limbs = scratch_limbs;
-  a.bump += scratch_limbs * N;
-  a.peak = a.bump;
+  bump += scratch_limbs * N;
+  a.peak = bump;
+  a.ext.clear();
+  a.ext[bump] = words - bump;
   const int rc = acehip_ctx_set_arena(c.hip, &cfg);
   RT_ASSERT(rc >= 0, "acehip_ctx_set_arena: %s", acehip_last_error());
   if (c.shard_sim) {
@@ -173,15 +180,37 @@ void arena_create() {
   const int rsel = acehip_ctx_select(c.hip, g_mode_rep0, g_mode_nrep);
   RT_ASSERT(rsel >= 0, "acehip_ctx_select: %s", acehip_last_error());
 }
-u64* arena_take(size_t words) {
+inline size_t granules(size_t words) { return (words + 31) & ~(size_t)31; }  // 256 bytes
+u64* arena_take(size_t words) {  // first fit, lowest address
   Arena& a = g_arena;
   if (a.base == nullptr) arena_create();
-  const size_t w = (words + 31) & ~(size_t)31;  // 256-byte granules
-  if (a.bump + w > a.words) return nullptr;
-  u64* p = a.base + a.bump;
-  a.bump += w;
-  a.peak = std::max(a.peak, a.bump);
-  return p;
+  const size_t w = granules(words);
+  for (auto it = a.ext.begin(); it != a.ext.end(); ++it) {
+    if (it->second < w) continue;
+    const size_t off = it->first, len = it->second;
+    a.ext.erase(it);
+    if (len > w) a.ext[off + w] = len - w;
+    a.peak = std::max(a.peak, off + w);
+    return a.base + off;
+  }
+  return nullptr;
+}
+void arena_give(u64* p, size_t words) {  // back into the extents, merged with its neighbours
+  Arena& a = g_arena;
+  size_t off = (size_t)(p - a.base), len = granules(words);
+  auto nx = a.ext.lower_bound(off);
+  if (nx != a.ext.end() && off + len == nx->first) {
+    len += nx->second;
+    nx = a.ext.erase(nx);
+  }
+  if (nx != a.ext.begin()) {
+    auto pv = std::prev(nx);
+    if (pv->first + pv->second == off) {
+      pv->second += len;
+      return;
+    }
+  }
+  a.ext[off] = len;
 }
 }  // namespace
 bool in_image_scope() { return g_image_scope; }
@@ -681,6 +710,22 @@ u64* dalloc(size_t words, bool zero, u32 nq) {
   }
   if (!p && kind == BK_ARENA) {
     p = arena_take(words);
+    if (!p) {  // merge what waits in the exact-size lists back into extents and look again
+      std::lock_guard<std::mutex> lk(pool_mu);
+      for (auto& kv : pool_free[BK_ARENA])
+        for (u64* q : kv.second) arena_give(q, kv.first);
+      pool_free[BK_ARENA].clear();
+      p = arena_take(words);
+    }
+    if (!p && g_arena.nrep == 1) {  // one replica: a separate allocation serves as well; reuse those first
+      std::lock_guard<std::mutex> lk(pool_mu);
+      auto it = pool_free[BK_UNIFORM].find(words);
+      if (it != pool_free[BK_UNIFORM].end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+        kind = BK_UNIFORM;
+      }
+    }
     if (!p) {
       // the slab is full.  With one replica a block outside it works just as well (nothing moves with a replica);
       // with several there is no way out
