@@ -379,8 +379,8 @@ void Finalize_context() {
            c.t_encode, c.t_issue, c.t_main);
     printf("[ACEHIP] %zu Bootstrap calls: %.3f s (synchronised on both sides while profiling)\n", c.n_bootstrap, c.t_bootstrap);
     printf("[ACEHIP] %zu encodes, %zu of them launched ahead of the per-limb queue\n", c.n_encode, c.n_encode_ahead);
-    printf("[ACEHIP] pool arena: peak %.1f MB per replica, batch %u, limb-sharded world %u%s\n", arena_peak_bytes() / 1048576.0, c.batch,
-           c.shard_world, c.shard_sim ? " (simulated)" : "");
+    printf("[ACEHIP] pool arena: %.0f MB per replica, %.1f MB live at most; batch %u, limb-sharded world %u%s\n", arena_bytes() / 1048576.0,
+           arena_live_peak_bytes() / 1048576.0, c.batch, c.shard_world, c.shard_sim ? " (simulated)" : "");
     if (c.shard_world > 1) {
       uint64_t steps[2] = {0, 0};
       const uint64_t b = acehip_shard_traffic(c.hip, steps, 0);

@@ -170,7 +170,9 @@ u64* dalloc(size_t words, bool zero, u32 nq = NQ_ANY);
 void dfree(u64* p);
 bool block_is_replicated(const u64* p);  // a pool block of which every image of the batch has its own copy
 bool block_is_uniform(const u64* p);     // a pool block shared by the images of the batch
-size_t arena_peak_bytes();
+size_t arena_peak_bytes();        // highest address of the slab in use so far (0: no slab yet)
+size_t arena_live_peak_bytes();   // most bytes in live blocks so far
+size_t arena_bytes();
 // ---- which replicas of the arena the launches of this thread cover (image batches) ----
 u32 batch_size();
 bool uniform_alloc_on();      // allocations of this thread currently come from the shared pool

@@ -116,6 +116,7 @@ struct Arena {
   // size class's high-water mark
   std::map<size_t, size_t> ext;
   size_t peak = 0;       // highest word ever handed out
+  size_t live = 0, live_peak = 0;  // words in live blocks (now / most ever)
   u32 nrep = 0;
   bool exhausted_warned = false;
 };
@@ -224,6 +225,8 @@ void select_image(u32 k) {
   g_image = k;
 }
 size_t arena_peak_bytes() { return g_arena.peak * 8; }
+size_t arena_live_peak_bytes() { return g_arena.live_peak * 8; }
+size_t arena_bytes() { return g_arena.words * 8; }
 // replicas the launches that follow cover; the queue is handed over first when the selection changes (its ops were
 // queued for the old one)
 void set_launch_mode(u32 rep0, u32 nrep) {
@@ -744,6 +747,10 @@ u64* dalloc(size_t words, bool zero, u32 nq) {
     std::lock_guard<std::mutex> lk(pool_mu);
     pool_live[p] = LiveBlock{words, kind};
     pool_live_bytes += words * sizeof(u64);
+    if (kind == BK_ARENA) {
+      g_arena.live += granules(words);
+      g_arena.live_peak = std::max(g_arena.live_peak, g_arena.live);
+    }
   }
   if (zero) fill_zero(p, words, nq);
   return p;
@@ -813,6 +820,7 @@ void dfree(u64* p) {
   const int kind = it->second.kind;
   if (g_muc.ok && g_muc.src >= p && g_muc.src < p + words) g_muc.forget();
   pool_live_bytes -= words * sizeof(u64);
+  if (kind == BK_ARENA) g_arena.live -= granules(words);
   if (g_hwq.empty()) {
     pool_free[kind][words].push_back(p);
     for (auto z = g_lazy.lower_bound(p); z != g_lazy.end() && *z < p + words;) {  // fills nobody waits for any more
