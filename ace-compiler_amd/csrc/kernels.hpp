@@ -72,6 +72,32 @@ __device__ __forceinline__ RepZ rep_of_z(const DevCtx& c) {
   const u32 nz = gridDim.z / c.nrep, r = blockIdx.z / nz;
   return RepZ{blockIdx.z - r * nz, c.rep0 + r};
 }
+// 1-D launches of X * Y * nrep workgroups (x: coefficient tile, y: limb / chain segment) whose replicas share a large
+// read-only operand (a switch key, bootstrap diagonals, a weight plaintext): workgroups are dealt round-robin over the 8 XCDs
+// by their linear id, so the nrep workgroups of one (x, y) get ids that are congruent mod 8 -- same XCD, same L2 -- and
+// consecutive in time: the shared operand's tile comes from HBM once and from that L2 for the other replicas.  With one
+// replica the order is the plain x-fastest one.  Placement only affects speed; any mapping is correct.
+struct RepBlk {
+  u32 x, y, rep;
+};
+__device__ __forceinline__ RepBlk rep_block(const DevCtx& c, u32 X, u32 Y) {
+  const u32 b = blockIdx.x;
+  u32 x, y, r;
+  if ((X & 7u) == 0) {
+    u32 t = b >> 3;
+    r = t % c.nrep;
+    t /= c.nrep;
+    const u32 Xg = X >> 3, xg = t % Xg;
+    y = t / Xg;
+    x = xg * 8 + (b & 7u);
+  } else {
+    x = b % X;
+    const u32 t = b / X;
+    y = t % Y;
+    r = t / Y;
+  }
+  return RepBlk{(u32)__builtin_amdgcn_readfirstlane(x), (u32)__builtin_amdgcn_readfirstlane(y), c.rep0 + (u32)__builtin_amdgcn_readfirstlane(r)};
+}
 struct NttBlk {
   u32 tile, y, z;
 };

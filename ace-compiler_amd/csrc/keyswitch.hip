@@ -160,10 +160,11 @@ void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const 
 __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* acc0, u64* acc1, const u64* key, const u64* ext,
                                                             size_t ext_stride, const u64* in, u32 level, u32 nd, u32 alpha,
                                                             const u64* add0, LimbConsts w) {
-  const u32 pos = blockIdx.y;
+  const RepBlk rb = rep_block(c, (c.N / 2 + 255) / 256, level + c.K);  // replicas of a tile side by side: the key is shared
+  const u32 pos = rb.y;
   const u32 gi = limb_prime(pos, level, c.L);
   if (!owns(c, gi)) return;
-  const u32 rep = c.rep0 + blockIdx.z;
+  const u32 rep = rb.rep;
   acc0 = reb(c, acc0, rep);
   acc1 = reb(c, acc1, rep);
   key = reb(c, key, rep);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* acc0,
   const DevPrime P = c.primes[gi];
   const size_t T = c.L + c.K;
   const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
-  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const u32 i = (rb.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
   // digit whose ModUp passes this limb through (read from `in` when given; otherwise ext holds it)
   const u32 own = (in != nullptr && pos < level) ? pos / alpha : 0xffffffffu;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* acc0,
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0, const LimbConsts* w) {
   ACEHIP_ABLATE(ABL_KEYMAC);
-  dim3 grid((c.N / 2 + 255) / 256, level + c.K, c.nrep), block(256);
+  dim3 grid(((c.N / 2 + 255) / 256) * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0,
                      w ? *w : LimbConsts{});
 }
@@ -219,16 +220,17 @@ void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key,
 // ------------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u32 level) {
-  const u32 pos = blockIdx.y;
+  const RepBlk rb = rep_block(c, (c.N / 2 + 255) / 256, level + c.K);  // replicas of a tile side by side: the diagonals are shared
+  const u32 pos = rb.y;
   const u32 gi = limb_prime(pos, level, c.L);
   if (!owns(c, gi)) return;
-  const u32 rep = c.rep0 + blockIdx.z;
+  const u32 rep = rb.rep;
   const DevPrime& P = c.primes[gi];
   const u64 q = P.q, ml = P.prec128_lo, mh = P.prec128_hi;
   const size_t ct_off = (size_t)pos * c.N;  // PQ-extended ciphertext: p-limbs follow the q-limbs
   // plaintext: q-limb `pos`, or p-limb (pos - level) behind its own (possibly higher) number of q-limbs
   const size_t pt_off = pos < level ? ct_off : (size_t)(a.pt_q_alloc + (pos - level)) * c.N;
-  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const u32 i = (rb.x * 256 + threadIdx.x) * 2;
   if (i >= c.N) return;
   ulong2 r0[G], r1[G];
   const u32 sh = __builtin_clz(c.N) + 1;  // 32 - log2(N)
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u
 
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
   ACEHIP_ABLATE(ABL_BSGS);
-  dim3 grid((c.N / 2 + 255) / 256, level + c.K, c.nrep), block(256);
+  dim3 grid(((c.N / 2 + 255) / 256) * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
   else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
   else               hipLaunchKernelGGL((bsgs_inner_kernel<16>), grid, block, 0, s, c, a, level);
