@@ -53,7 +53,7 @@ __device__ __forceinline__ V4 map2(const V4& a, const V4& b, F f) {
 }
 
 template <int CAP>
-__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args, u32 n_seg) {
+__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
   __shared__ u64 s_q[kMaxPrimes], s_mu[kMaxPrimes];
   __shared__ u32 s_nb[kMaxPrimes];
   if (ACEHIP_HW_STAGE) {
@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
     }
     __syncthreads();
   }
-  const RepBlk rb = rep_block(c, (c.N / kHwLanes + 255) / 256, n_seg);  // replicas side by side: shared operands (weight plaintexts)
-  const u32 i = (rb.x * 256 + threadIdx.x) * kHwLanes;
+  // (replica = blockIdx.z, the slowest index.  Dealing the replicas of a tile side by side -- kernels.hpp rep_block(), which pays
+  // for the key inner product and the BSGS kernel -- measured 3 % slower here: the operands the replicas share, weight plaintexts, are a
+  // small part of this kernel's traffic)
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * kHwLanes;
   if (i >= c.N) return;
-  const u32 beg = args.seg_start[rb.y], end = args.seg_start[rb.y + 1];
-  const u32 rep = rb.rep;  // replica of this workgroup: operands inside the replicated arena move with it
+  const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
+  const u32 rep = c.rep0 + blockIdx.z;  // replica of this workgroup: operands inside the replicated arena move with it
   const u64* prev_res = nullptr;
   V4 vprev{{0, 0}, {0, 0}};
   for (u32 k = beg; k < end; ++k) {
@@ -163,11 +165,11 @@ static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_seg == 0) return;
-  dim3 grid(((c.N / kHwLanes + 255) / 256) * n_seg * c.nrep), block(256);  // 1-D: rep_block() maps it
+  dim3 grid((c.N / kHwLanes + 255) / 256, n_seg, c.nrep), block(256);
   const u32 n_ops = args.seg_start[n_seg];
-  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg), n_seg);
-  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg), n_seg);
-  else hipLaunchKernelGGL(hw_batch_ew_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args, n_seg);
+  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));
+  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));
+  else hipLaunchKernelGGL(hw_batch_ew_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args);
 }
 
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
