@@ -22,6 +22,8 @@
 // The last pass writes canonical residues in [0,q), so results are bit-identical to the reference (ntt.c:190-353),
 // which keeps every intermediate canonical.  Twiddles come from the interleaved {w, floor(w*2^64/q)} tables (16-byte
 // loads); workgroups that share twiddles are placed on one XCD (kernels.hpp ntt_block).
+#include <cstdlib>
+
 #include "device_arith.hpp"
 #include "kernels.hpp"
 
@@ -1086,7 +1088,11 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys * c.nrep);  // 1-D: ntt_block() maps it XCD-aware
   const bool tw8 = c.twp_fwd != nullptr && n_polys * c.nrep <= c.tw8_max_polys;  // few polynomials share the twiddles: 8-byte stream
-#define ACEHIP_NTT_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
+  // ACEHIP_NTT_LDS_PAD (bytes of unused dynamic LDS per workgroup; experiment): caps the workgroups of these VALU-bound passes
+  // per CU below the 4 their registers allow, which leaves registers for the memory-bound kernels of OTHER image streams to
+  // run beside them on the same CU (0 = off)
+  static const size_t lds_pad = [] { const char* e = getenv("ACEHIP_NTT_LDS_PAD"); return e ? (size_t)strtoul(e, nullptr, 0) : (size_t)0; }();
+#define ACEHIP_NTT_ARGS grid, block, lds_pad, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
     else if (f.conv && f.conv_max_in <= 8)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV8>), ACEHIP_NTT_ARGS);
