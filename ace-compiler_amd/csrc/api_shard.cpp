@@ -484,6 +484,11 @@ RcclApi* rccl_api() {
 struct RcclComm {
   void* comm = nullptr;
   u32 rank = 0, world = 1;
+  // RCCL gets a stream of its own: this library is built with -fgpu-default-stream=per-thread, so the NULL stream its callers pass
+  // means "the calling thread's stream" here and "the legacy stream" inside RCCL.  Every exchange is ordered after the launches
+  // issued so far, and the launches that follow after the exchange, by events (no host synchronisation).
+  hipStream_t xs = nullptr;
+  hipEvent_t before = nullptr, after = nullptr;
 };
 constexpr int kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
 }  // namespace
@@ -496,18 +501,22 @@ int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
   if (c->rccl != nullptr) {  // one process per rank: broadcast from the owner, in place, for every selected replica
     RcclComm* rc = (RcclComm*)c->rccl;
     RcclApi* api = rccl_api();
+    HIP_TRY(hipEventRecord(rc->before, s));
+    HIP_TRY(hipStreamWaitEvent(rc->xs, rc->before, 0));
     int e = api->GroupStart();
     for (size_t k = 0; k < n && e == 0; ++k) {
       const u64 a = (u64)items[k].ptr;
       const bool in_arena = a - lo < span && stride != 0;
       for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1) && e == 0; ++r) {
         void* p = (void*)(in_arena ? a + (u64)r * stride : a);
-        e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, s);
+        e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, rc->xs);
         if (items[k].root != rc->rank) c->xchg_bytes += N * 8;
       }
     }
     const int e2 = api->GroupEnd();
     if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
+    HIP_TRY(hipEventRecord(rc->after, rc->xs));
+    HIP_TRY(hipStreamWaitEvent(s, rc->after, 0));
     return ACEHIP_OK;
   }
   // simulated ranks: owner's replica -> every other hosted replica (absolute addresses: a DevCtx without rebasing)
@@ -587,6 +596,11 @@ int acehip_ctx_shard_rccl(acehip_ctx* c, uint32_t rank, uint32_t world, const vo
   if (int e = api->CommInitRank(&rc->comm, (int)world, id, (int)rank)) {
     delete rc;
     return fail(ACEHIP_EHIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  }
+  if (hipStreamCreateWithFlags(&rc->xs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rc->before, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&rc->after, hipEventDisableTiming) != hipSuccess) {
+    delete rc;
+    return fail(ACEHIP_EHIP, "acehip_ctx_shard_rccl: stream / event creation failed");
   }
   c->rccl = rc;
   if (world > 1) {

@@ -203,10 +203,7 @@ void shard_connect_if_asked() {
     RT_ASSERT(got == 128, "rank %u: no RCCL id in %s", rank, path.c_str());
   }
   shard_connect(rank, world, id);
-  if (rank == 0 && world > 1) {
-    // (the file is removed once every rank has joined: ncclCommInitRank returns only then)
-    remove(path.c_str());
-  }
+  if (rank == 0) remove(path.c_str());  // (every rank has joined: ncclCommInitRank returns only then)
 }
 
 void generate_keys() {

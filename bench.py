@@ -228,6 +228,90 @@ def load_model_runtime(device, batch=1):
     return fhe, step
 
 
+def shard_model_bench(args):
+    """BASELINE configs[4]: ONE encrypted inference job whose RNS limbs are spread over the ranks (limb gi on rank gi % world),
+    every rank running the same ACE-generated program behind the rt_ant API (SPMD; ACEHIP_SHARD=1, include/rt_ant/rt_api.h) and RCCL
+    broadcasts over xGMI where limbs meet (Decomp_modup, Mod_down, Rescale, the ModRaise of Bootstrap, decode).  Launch:
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N \
+             --mode shard --workload resnet110 [--batch B]
+    Strong scaling: the job is the same whatever N; value = images of the job / wall time (max over ranks)."""
+    global MODEL_LIB
+    r110 = args.workload != "resnet20"
+    if r110:
+        MODEL_LIB = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet110.so")
+    if not os.path.exists(MODEL_LIB):
+        raise SystemExit("bench --mode shard: %s missing (tools/build_models.py)" % MODEL_LIB)
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ["ACEHIP_SHARD"] = "1"             # the rt_ant shim joins the RCCL communicator of RANK / WORLD_SIZE in Prepare_context
+    os.environ.setdefault("ACEHIP_SEED", "1")    # every rank derives the same keys and encryption randomness
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    import ace_compiler_amd  # noqa: F401
+    from ace_compiler_amd.dist import Ranks
+
+    ranks = Ranks()  # barrier + max over ranks of the timed region (torch.distributed "nccl" = RCCL); the data path has its own communicator
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    n_batch = max(args.batch, 1) if args.batch else 1
+    fhe, step = load_model_runtime(local_rank, n_batch)
+    fhe.Acehip_rt_shard_world.restype = C.c_uint32
+    fhe.Acehip_rt_shard_rank.restype = C.c_uint32
+    fhe.Acehip_rt_shard_traffic.restype = C.c_uint64
+    fhe.Acehip_rt_shard_traffic.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    fhe.Acehip_rt_sync.restype = None
+    t_ctx = time.perf_counter()
+    fhe.Prepare_context()
+    fhe.Acehip_rt_set_batch(n_batch)
+    t_ctx = time.perf_counter() - t_ctx
+    rccl_world = fhe.Acehip_rt_shard_world()
+    assert rccl_world == world, "the runtime's RCCL communicator has %d ranks, the launcher %d" % (rccl_world, world)
+    logits = None
+    for _ in range(args.warmup):
+        logits = step()
+    fhe.Acehip_rt_sync()
+    ranks.barrier()
+    steps2 = (C.c_uint64 * 2)()
+    fhe.Acehip_rt_shard_traffic(steps2, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    fhe.Acehip_rt_sync()
+    elapsed_local = time.perf_counter() - t0
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(elapsed_local)
+    xbytes = fhe.Acehip_rt_shard_traffic(steps2, 0)
+    n_images = n_batch * args.steps
+    L_, K_ = 34, 11  # the generated ResNets: mul_depth 33, dnum 3 (SURVEY Appendix D)
+    owned = [sum(1 for gi in range(L_ + K_) if gi % world == r) for r in range(world)]
+    all_x = ranks.sum_over_ranks(float(xbytes))
+    if rank == 0:
+        value = n_images / elapsed
+        out = {
+            "metric": "encrypted images/sec (ResNet-%s CIFAR-10, N=2^16), RNS limbs sharded over the GPUs" % ("110" if r110 else "20"),
+            "value": round(value, 6), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": round(value / (1.0 / (7531.12 if r110 else 1453.96)), 1), "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: ACE-compiled ResNet-%s/CIFAR-10 encrypted inference (unchanged generated source), one job "
+                                   "whose RNS limbs are spread over %d rank(s) (limb gi on rank gi %% world), every rank running the same program "
+                                   "behind the rt_ant API; RCCL broadcasts from the owning rank at Decomp_modup / Mod_down / Rescale / ModRaise / "
+                                   "decode; synthetic image and weights; %d image(s) per batch" % ("110" if r110 else "20", world, n_batch),
+                       "N": 65536, "images_per_step": n_batch, "parallelism": "limb-sharded: %d rank(s), one GPU each" % world},
+            "shard": {"world": world, "rccl_ranks": int(rccl_world), "owned_limbs_per_rank": owned, "limbs_total": L_ + K_,
+                      "exchange_steps_per_image": round(steps2[0] / n_images, 1),
+                      "limbs_received_per_image_rank0": round(steps2[1] / n_images, 1),
+                      "bytes_received_per_image_rank0": int(xbytes / n_images),
+                      "bytes_received_per_image_all_ranks": int(all_x / n_images),
+                      "prepare_context_s": round(t_ctx, 2)},
+        }
+        if logits is not None:
+            out["config"]["last_logits"] = [round(v, 5) for v in logits]
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    fhe.Finalize_context()
+    ranks.close()
+
+
 def main():
     global MODEL_LIB
     ap = argparse.ArgumentParser()
@@ -246,7 +330,7 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     ap.add_argument("--batch", type=int, default=8,
@@ -255,10 +339,13 @@ def main():
     args = ap.parse_args()
 
     if args.mode == "shard":
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import shard_keyswitch_bench
+        if args.workload == "keyswitch":  # the building block alone: one key-switch + rescale through the packed phases
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import shard_keyswitch_bench
 
-        shard_keyswitch_bench.main(["--steps", str(max(args.steps, 20)), "--warmup", str(max(args.warmup, 3))])
+            shard_keyswitch_bench.main(["--steps", str(max(args.steps, 20)), "--warmup", str(max(args.warmup, 3))])
+            return
+        shard_model_bench(args)
         return
 
     # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues two image

@@ -93,6 +93,10 @@ def lib():
         L.orc_xorw.argtypes = [vp, C.c_size_t]
         L.orc_splitmix64.restype = u64
         L.orc_splitmix64.argtypes = [u64, u64]
+        L.orc_switch_modulus.restype = u64
+        L.orc_switch_modulus.argtypes = [u64, u64, u64]
+        L.orc_mul_mod.restype = u64
+        L.orc_mul_mod.argtypes = [u64, u64, u64]
         _lib = L
     return _lib
 

@@ -134,3 +134,165 @@ def test_limb_shard_exchange_layout_two_ranks_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 shard ok" in r.stdout and "rank 1 shard ok" in r.stdout
+
+
+SCHEDULE_WORKER = textwrap.dedent("""
+    import sys
+    sys.path.insert(0, %r)
+    sys.path.insert(0, %r)
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ace_compiler_amd as A
+    import _oracle as O
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N, L, q0, sf, dnum, level = 16, 7, 60, 51, 3, 6
+    o = O.Oracle(N, L, q0, sf, dnum)
+    K = o.K
+    rt = A.AceHip(N, L, q0, sf, dnum, host_only=True)   # the schedule comes from the product library (no GPU needed)
+    owns = lambda gi: gi %% world == rank
+    POISON = np.uint64(0xDEADBEEFDEADBEEF)
+
+    def schedule(op, lvl):
+        cap = 256
+        st, pos, root = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+        n = rt.lib.acehip_shard_schedule(rt.h, world, op, lvl, st, pos, root, cap)
+        assert 0 < n <= cap
+        return [(st[i], pos[i], root[i]) for i in range(n)]
+
+    def exchange(buf, items):          # in-place broadcast of every listed limb from its root, like the RCCL exchange
+        for _, pos, root in items:
+            t = torch.from_numpy(buf[pos].view(np.int64))
+            dist.broadcast(t, root)
+
+    def mine_only(x, gis):             # a rank's view: the limbs it does not own hold garbage
+        y = x.copy()
+        for l, gi in enumerate(gis):
+            if not owns(gi):
+                y[l] = POISON
+        return y
+
+    def check_owned(got, want, gis, what):
+        for l, gi in enumerate(gis):
+            if owns(gi):
+                assert np.array_equal(got[l], want[l]), (what, "limb", l, "rank", rank)
+
+    mulmod = lambda a, b, q: (int(a) * int(b)) %% int(q)
+    q_gis = list(range(level))
+    ext_gis = q_gis + [L + j for j in range(K)]
+    a_full = o.uniform(level, level, 3)
+
+    # ---- ModUp of every digit (Decompose_modup polynomial.c:1241-1335): exchange = the coefficient-domain q-limbs ----
+    a = mine_only(a_full, q_gis)
+    coef = a.copy()
+    for i in range(level):
+        if owns(i):
+            coef[i] = o.ntt_inv(a[i:i + 1], [i])[0]
+    items = schedule(0, level)
+    assert sorted(p for _, p, _ in items) == q_gis and all(r == p %% world for _, p, r in items)
+    exchange(coef, items)
+    for d in range(o.num_decomp(level)):
+        n2, hat_inv, compl, hat_mod = o.modup_tables(level, d)
+        start = o.alpha * d
+        out = np.full((level + K, N), POISON, dtype=np.uint64)
+        for i in range(n2):
+            if owns(start + i):
+                out[start + i] = a[start + i]                      # the digit's own limbs pass through
+        for j, gi in enumerate(compl):
+            gi = int(gi)
+            if not owns(gi):
+                continue
+            t = o.primes[gi]
+            row = np.empty(N, dtype=np.uint64)
+            for n in range(N):
+                acc = 0
+                for i in range(n2):
+                    y = mulmod(coef[start + i][n], hat_inv[i], o.primes[start + i])
+                    acc += y * int(hat_mod[i][j])                  # exact sum, one reduction: the uncorrected fast base conversion
+                row[n] = acc %% t
+            pos = gi if gi < L else level + (gi - L)
+            out[pos] = o.ntt_fwd(row[None, :], [gi])[0]
+        check_owned(out, o.decomp_modup(a_full, level, d), ext_gis, "modup digit %%d" %% d)
+
+    # ---- ModDown (Reduce_rns_base polynomial.c:928-967): exchange = the coefficient-domain P-limbs ----
+    e_full = o.uniform(level + K, level, 5)
+    e = mine_only(e_full, ext_gis)
+    pc = e.copy()
+    for j in range(K):
+        if owns(L + j):
+            pc[level + j] = o.ntt_inv(e[level + j:level + j + 1], [L + j])[0]
+    items = schedule(1, level)
+    assert sorted(p for _, p, _ in items) == [level + j for j in range(K)] and all(r == (L + p - level) %% world for _, p, r in items)
+    exchange(pc, items)
+    phat_inv = o.table("phat_inv_modp", K)
+    phat_modq = o.table("phat_modq", L * K).reshape(L, K)
+    pinv = o.table("pinv_modq", L)
+    md = np.full((level, N), POISON, dtype=np.uint64)
+    for i in range(level):
+        if not owns(i):
+            continue
+        q = o.primes[i]
+        row = np.empty(N, dtype=np.uint64)
+        for n in range(N):
+            acc = 0
+            for j in range(K):
+                acc += mulmod(pc[level + j][n], phat_inv[j], o.primes[L + j]) * int(phat_modq[i][j])
+            row[n] = acc %% q
+        conv = o.ntt_fwd(row[None, :], [i])[0]
+        md[i] = np.array([mulmod((int(e[i][n]) - int(conv[n])) %% q, pinv[i], q) for n in range(N)], dtype=np.uint64)
+    check_owned(md, o.mod_down(e_full, level), q_gis, "mod_down")
+
+    # ---- Rescale (Rescale_poly polynomial.c:1097-1163): exchange = the last limb, from its owner ----
+    items = schedule(2, level)
+    assert items == [(0, level - 1, (level - 1) %% world)]
+    last = a.copy()
+    if owns(level - 1):
+        last[level - 1] = o.ntt_inv(a[level - 1:level], [level - 1])[0]
+    exchange(last, items)
+    ql = o.primes[level - 1]
+    qlql = o.table("qlql", L * L).reshape(L, L)[level - 2]
+    ql_inv = o.table("ql_inv_modqi", L * L).reshape(L, L)[level - 2]
+    rs = np.full((level - 1, N), POISON, dtype=np.uint64)
+    for i in range(level - 1):
+        if not owns(i):
+            continue
+        q = o.primes[i]
+        t = np.empty(N, dtype=np.uint64)
+        for n in range(N):
+            t[n] = mulmod(o.lib.orc_switch_modulus(int(last[level - 1][n]), ql, q), qlql[i], q)
+        t = o.ntt_fwd(t[None, :], [i])[0]
+        rs[i] = np.array([(mulmod(a[i][n], ql_inv[i], q) + int(t[n])) %% q for n in range(N)], dtype=np.uint64)
+    check_owned(rs, o.rescale(a_full, level), list(range(level - 1)), "rescale")
+
+    # ---- ModRaise (ckks_bootstrap_context.c:1527-1551): limb 0 from rank 0 ----
+    assert schedule(3, level) == [(0, 0, 0)]
+    # ownership is a partition, and launches on a GPU-less context still fail loudly
+    assert sum(rt.lib.acehip_shard_owned_limbs(rt.h, r) for r in range(1)) == L + K     # not sharded: one rank owns all
+    rt.close()
+    o.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    import os
+    os.write(1, ("rank " + str(rank) + " schedule ok" + chr(10)).encode())
+""")
+
+
+def test_sharded_mode_exchange_schedule_two_ranks_gloo(tmp_path):
+    """Limb-sharded execution as a mode of the context (include/acehip.h acehip_ctx_shard_*): the exchange schedule the pipelines
+    follow (acehip_shard_schedule: which limb positions meet at ModUp, ModDown, Rescale, ModRaise, and who sends them) is
+    sufficient and correct -- two gloo ranks, each holding ONLY its own limbs (the others poisoned), rebuild ModUp of every digit,
+    ModDown and Rescale from the oracle's per-limb pieces, exchange exactly the listed limbs by broadcast from the listed root,
+    and find their owned limbs of the oracle's unsharded results bit for bit."""
+    script = tmp_path / "schedule_worker.py"
+    script.write_text(SCHEDULE_WORKER % (ROOT, os.path.join(ROOT, "tests")))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 schedule ok" in r.stdout and "rank 1 schedule ok" in r.stdout

@@ -90,3 +90,23 @@ def test_resnet110_sharded_is_bit_identical(tmp_path):
         out, shard = _run(exe, ["1"], dict(env, ACEHIP_SHARD_SIM=str(world), ACEHIP_PROFILE="1"), tmp_path, "shard%d" % world, timeout=1500)
         assert shard["0.0"] == plain["0.0"], "ResNet-110 output differs with %d ranks" % world
         assert "limb-sharded world %d (simulated)" % world in out
+
+
+def test_bench_shard_mode_one_rank_joins_rccl():
+    """`bench.py --mode shard` (what torchrun starts once per GPU for BASELINE configs[4]) with a single rank: the rt_ant shim
+    loads librccl, creates and joins its own communicator (ACEHIP_SHARD=1: id file, ncclCommInitRank), runs the generated
+    ResNet-20 through the API and prints the JSON line with the rank count RCCL saw, the limbs each rank owns and the
+    exchange counters (all zero: one rank owns every limb)."""
+    import json
+    import sys
+
+    lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet20.so")
+    if not os.path.exists(lib):
+        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--workload", "resnet20", "--batch", "2",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["unit"] == "images/s" and d["value"] > 0
+    assert d["shard"]["rccl_ranks"] == 1 and d["shard"]["owned_limbs_per_rank"] == [45] and d["shard"]["bytes_received_per_image_all_ranks"] == 0
