@@ -15,7 +15,14 @@
  *                          then per poly `level` q-limbs and `num_p` p-limbs of N u64
  *   keys       "ACEHKEY1": see write_keys() below
  *
- * usage: ct_parity dump|check DIR N mul_depth q0_bits sf_bits dnum hamming slots level_after [rot ...]
+ * The REVERSE direction (does the reference accept what WE generate?):
+ *   default build, mode "make": Prepare_context with OUR key generation (ACEHIP_SEED), encrypt the two messages and an all-zero
+ *                 one with OUR encryptor, run the script, write keys.bin (Acehip_rt_save_keys), the inputs and every result.
+ *   -DREF_BUILD, mode "load":  Prepare_context of the reference, then every key is REPLACED by ours from keys.bin (secret, public,
+ *                 relinearisation, rotation keys), our input ciphertexts are read, the reference runs the same script and must
+ *                 reproduce every one of our results byte for byte -- and its own decryptor must return the messages.
+ *
+ * usage: ct_parity dump|check|make|load DIR N mul_depth q0_bits sf_bits dnum hamming slots level_after [rot ...]
  */
 #include <math.h>
 #include <stdio.h>
@@ -113,6 +120,93 @@ static void write_keys(const char* path) {
   }
   fclose(f);
   printf("keys: L=%u K=%u dnum=%u rot_map=%u auto_keys=%u\n", L, K, h[4], n_rot, n_auto);
+}
+/* ---- the reverse direction: OUR containers into the reference's structures ---- */
+static void read_poly(FILE* f, POLYNOMIAL* p, const char* what) {
+  size_t n = p->_ring_degree;
+  if (fread(p->_data, 8, p->_num_primes * n, f) != p->_num_primes * n) { fprintf(stderr, "short read: %s\n", what); exit(3); }
+  if (p->_num_primes_p &&
+      fread(p->_data + (p->_num_alloc_primes - p->_num_primes_p) * n, 8, p->_num_primes_p * n, f) != p->_num_primes_p * n) {
+    fprintf(stderr, "short read: %s\n", what);
+    exit(3);
+  }
+}
+static void load_ciph_ref(const char* path, CIPHER c) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(3); }
+  char     magic[8];
+  uint32_t h[8];
+  double   sf;
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "ACEHCT01", 8) != 0 || fread(h, 4, 8, f) != 8 || fread(&sf, 8, 1, f) != 1 || h[0] != 2) {
+    fprintf(stderr, "%s: not an ACEHCT01 ciphertext\n", path);
+    exit(3);
+  }
+  memset(c, 0, sizeof(*c));
+  Alloc_poly_data(&c->_c0_poly, h[1], h[2], h[3]);
+  Alloc_poly_data(&c->_c1_poly, h[1], h[2], h[3]);
+  c->_c0_poly._is_ntt = c->_c1_poly._is_ntt = h[4] != 0;
+  c->_slots = h[5];
+  c->_sf_degree = h[6];
+  c->_scaling_factor = sf;
+  read_poly(f, &c->_c0_poly, path);
+  read_poly(f, &c->_c1_poly, path);
+  fclose(f);
+}
+static void read_swk(FILE* f, SWITCH_KEY* k, size_t dnum, const char* what) {
+  for (size_t j = 0; j < dnum; ++j) {
+    PUBLIC_KEY* pk = Get_swk_at(k, j);
+    read_poly(f, Get_pk0(pk), what);
+    read_poly(f, Get_pk1(pk), what);
+  }
+}
+/* every key of the prepared reference context is overwritten by the one OUR library generated ("ACEHKEY1" with a secret key) */
+static void read_keys(const char* path) {
+  CKKS_KEY_GENERATOR* g = (CKKS_KEY_GENERATOR*)Get_key_gen(Context);
+  CKKS_PARAMETER*     prm = (CKKS_PARAMETER*)Get_param(Context);
+  CRT_CONTEXT*        crt = prm->_crt_context;
+  uint32_t            L = Get_primes_cnt(Get_q(crt)), K = Get_primes_cnt(Get_p(crt));
+  FILE*               f = fopen(path, "rb");
+  if (!f) { perror(path); exit(3); }
+  char     magic[8];
+  uint32_t h[8];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "ACEHKEY1", 8) != 0 || fread(h, 4, 8, f) != 8) { fprintf(stderr, "%s: not a key file\n", path); exit(3); }
+  if (h[0] != 1 || h[1] != prm->_poly_degree || h[2] != L || h[3] != K || h[4] != prm->_num_q_parts || (h[7] & 1)) {
+    fprintf(stderr, "%s: written for other parameters (or without a secret key)\n", path);
+    exit(3);
+  }
+  for (uint32_t i = 0; i < L + K; ++i) {
+    int64_t q, want = i < L ? Get_modulus_val(Get_prime_at(Get_q(crt), i)) : Get_modulus_val(Get_prime_at(Get_p(crt), i - L));
+    if (fread(&q, 8, 1, f) != 1 || q != want) { fprintf(stderr, "%s: prime %u differs\n", path, i); exit(3); }
+  }
+  read_poly(f, Get_ntt_sk(Get_sk(g)), "secret key");
+  read_poly(f, Get_pk0(Get_pk(g)), "public key");
+  read_poly(f, Get_pk1(Get_pk(g)), "public key");
+  read_swk(f, Get_relin_key(g), prm->_num_q_parts, "relinearisation key");
+  uint32_t n_map = 0, n_keys = 0;
+  for (uint32_t i = 0; i < h[5]; ++i) {
+    int32_t  rot;
+    uint32_t k;
+    if (fread(&rot, 4, 1, f) != 1 || fread(&k, 4, 1, f) != 1) { fprintf(stderr, "short read: rotation map\n"); exit(3); }
+    uint32_t ours = Get_precomp_auto_idx(g, rot);  /* the reference derives the same automorphism index for the rotation */
+    if (ours != 0 && ours != k) { fprintf(stderr, "rotation %d: automorphism index %u here, %u in the file\n", rot, ours, k); exit(3); }
+    n_map += ours != 0;
+  }
+  size_t key_bytes = (size_t)prm->_num_q_parts * 2 * (L + K) * prm->_poly_degree * 8;
+  for (uint32_t i = 0; i < h[6]; ++i) {
+    uint32_t e[2];
+    if (fread(e, 4, 2, f) != 2) { fprintf(stderr, "short read: automorphism key header\n"); exit(3); }
+    SWITCH_KEY* k = Get_auto_key(g, e[0]);
+    if (k != NULL) {
+      read_swk(f, k, prm->_num_q_parts, "automorphism key");
+      n_keys++;
+    } else if (fseek(f, (long)key_bytes, SEEK_CUR) != 0) {  /* a key this context never asked for */
+      fprintf(stderr, "short read: automorphism key %u\n", e[0]);
+      exit(3);
+    }
+  }
+  fclose(f);
+  printf("keys injected into the reference: L=%u K=%u dnum=%u, %u of %u rotations known here, %u of %u automorphism keys replaced\n", L, K, h[4],
+         n_map, h[5], n_keys, h[6]);
 }
 #else
 static void save_ciph(const char* path, CIPHER c) { Acehip_rt_save_ciph(path, c); }
@@ -346,7 +440,8 @@ int main(int argc, char** argv) {
     fprintf(stderr, "usage: %s dump|check DIR N mul_depth q0_bits sf_bits dnum hamming slots level_after [rot ...]\n", argv[0]);
     return 2;
   }
-  Check = strcmp(argv[1], "check") == 0;
+  const int make_mode = strcmp(argv[1], "make") == 0, load_mode = strcmp(argv[1], "load") == 0;
+  Check = strcmp(argv[1], "check") == 0 || load_mode;  /* "load": the reference checks itself against OUR outputs */
   Dir = argv[2];
   Parm = (CKKS_PARAMS*)calloc(1, sizeof(CKKS_PARAMS) + sizeof(int32_t) * 64);
   Parm->_provider = LIB_ANT;
@@ -365,15 +460,40 @@ int main(int argc, char** argv) {
   char kpath[1024];
   path_of(kpath, "", "keys", "bin");
 #ifdef REF_BUILD
-  if (Check) { fprintf(stderr, "the reference build only dumps\n"); return 2; }
+  if (Check && !load_mode) { fprintf(stderr, "the reference build dumps, or loads what the product made\n"); return 2; }
+  if (make_mode) { fprintf(stderr, "\"make\" is the product build's mode\n"); return 2; }
 #else
-  if (!Check) { fprintf(stderr, "the product build only checks\n"); return 2; }
-  setenv("ACEHIP_KEYS_FILE", kpath, 1);
-  setenv("ACEHIP_KEYS_STRICT", "1", 1); /* a key missing from the file is an error, not a reason to generate one */
+  if (!Check && !make_mode) { fprintf(stderr, "the product build checks, or makes what the reference loads\n"); return 2; }
+  if (load_mode) { fprintf(stderr, "\"load\" is the reference build's mode\n"); return 2; }
+  if (!make_mode) {
+    setenv("ACEHIP_KEYS_FILE", kpath, 1);
+    setenv("ACEHIP_KEYS_STRICT", "1", 1); /* a key missing from the file is an error, not a reason to generate one */
+  }
 #endif
   Prepare_context();
   CIPHERTEXT a, b;
 #ifdef REF_BUILD
+  if (load_mode) {
+    char p[1024];
+    read_keys(kpath);
+    path_of(p, "", "in_a", "ct");
+    load_ciph_ref(p, &a);
+    path_of(p, "", "in_b", "ct");
+    load_ciph_ref(p, &b);
+    script(a, b);
+    /* the reference's own decryptor on a ciphertext OUR encryptor made: the message comes back */
+    double* m = Get_msg(&a);
+    double  worst = 0;
+    for (uint32_t i = 0; i < Slots; ++i) if (fabs(m[i] - sin(0.37 * i) * 0.5) > worst) worst = fabs(m[i] - sin(0.37 * i) * 0.5);
+    printf("reference decrypts our in_a: max |message error| %.3e\n", worst);
+    if (!(worst < 1e-3)) Fail++;
+    free(m);
+    Free_ciph_poly(&a, 1);
+    Free_ciph_poly(&b, 1);
+    Finalize_context();
+    printf(Fail ? "FAILED: %d mismatches\n" : "SUCESS! the reference reproduces every result of our keys and ciphertexts bit for bit (%d)\n", Fail);
+    return Fail ? 1 : 0;
+  }
   double* x = (double*)malloc(sizeof(double) * Slots);
   for (uint32_t i = 0; i < Slots; ++i) x[i] = sin(0.37 * i) * 0.5;
   TENSOR* t = Alloc_tensor(1, 1, 1, Slots, x);
@@ -393,10 +513,34 @@ int main(int argc, char** argv) {
   char p[1024];
   ZERO(a);
   ZERO(b);
-  path_of(p, "", "in_a", "ct");
-  Acehip_rt_load_ciph(&a, p);
-  path_of(p, "", "in_b", "ct");
-  Acehip_rt_load_ciph(&b, p);
+  if (make_mode) {  /* our own encryptor: the two messages of the dump mode, and an all-zero one (noise alone) */
+    double* x = (double*)calloc(Slots, sizeof(double));
+    TENSOR* t = Alloc_tensor(1, 1, 1, Slots, x);
+    Prepare_input(t, "in_a");
+    Free_tensor(t);
+    a = Get_input_data("in_a", 0);
+    path_of(p, "", "zero", "ct");
+    save_ciph(p, &a);
+    Free_ciph_poly(&a, 1);
+    for (uint32_t i = 0; i < Slots; ++i) x[i] = sin(0.37 * i) * 0.5;
+    t = Alloc_tensor(1, 1, 1, Slots, x);
+    Prepare_input(t, "in_a");
+    Free_tensor(t);
+    for (uint32_t i = 0; i < Slots; ++i) x[i] = cos(0.23 * i + 1.0) * 0.4;
+    t = Alloc_tensor(1, 1, 1, Slots, x);
+    Prepare_input(t, "in_b");
+    Free_tensor(t);
+    free(x);
+    a = Get_input_data("in_a", 0);
+    b = Get_input_data("in_b", 0);
+    path_of(p, "", "in_b", "ct");
+    save_ciph(p, &b);
+  } else {
+    path_of(p, "", "in_a", "ct");
+    Acehip_rt_load_ciph(&a, p);
+    path_of(p, "", "in_b", "ct");
+    Acehip_rt_load_ciph(&b, p);
+  }
 #endif
   script(a, b);
 #ifdef REF_BUILD
@@ -406,8 +550,10 @@ int main(int argc, char** argv) {
   Free_ciph_poly(&b, 1);
 #ifndef REF_BUILD
   if (getenv("ACEHIP_CT_PARITY_RESAVE") && Acehip_rt_save_keys(getenv("ACEHIP_CT_PARITY_RESAVE")) != 0) Fail++;
+  if (make_mode && Acehip_rt_save_keys(kpath) != 0) { fprintf(stderr, "cannot write %s\n", kpath); Fail++; }
 #endif
   Finalize_context();
   if (Check) printf(Fail ? "FAILED: %d mismatches\n" : "SUCESS! all outputs bit-identical to the reference (%d)\n", Fail);
+  if (make_mode) printf(Fail ? "FAILED\n" : "made: keys.bin, in_a.ct, in_b.ct, zero.ct and the results of the script\n");
   return Fail ? 1 : 0;
 }
