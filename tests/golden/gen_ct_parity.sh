@@ -15,3 +15,9 @@ gen() {  # name args...
 }
 gen n16_full   16 25 60 51 3 0 8 3 1 -2 5
 gen n16_sparse 16 25 60 51 2 0 4 4 1 3
+# the generated models' prime sizes (mul_depth 33, q0 51; ResNet-20: Delta = 2^50, ResNet-110: Delta = 2^48; dnum 3), bootstrap from
+# 2 limbs back to level_after 15 / 17, fully and sparsely packed: pins the bootstrap's level budget at L = 34 from a clean checkout
+gen n64_r20_full    64 33 51 50 3 16 32 15 1 -3 16
+gen n64_r20_sparse  64 33 51 50 3 16 8 15 2 -1 4
+gen n64_r110_full   64 33 51 48 3 16 32 17 1 -3 16
+gen n64_r110_sparse 64 33 51 48 3 16 8 17 2 -1 4
