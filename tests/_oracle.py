@@ -93,6 +93,8 @@ def lib():
         L.orc_xorw.argtypes = [vp, C.c_size_t]
         L.orc_splitmix64.restype = u64
         L.orc_splitmix64.argtypes = [u64, u64]
+        L.orc_ctx_create_from_primes.restype = C.POINTER(OrcCtx)
+        L.orc_ctx_create_from_primes.argtypes = [u32, P64, u32, u32]
         L.orc_switch_modulus.restype = u64
         L.orc_switch_modulus.argtypes = [u64, u64, u64]
         L.orc_mul_mod.restype = u64
@@ -141,6 +143,18 @@ class Oracle:
         c = self.h.contents
         self.N, self.L, self.K, self.dnum, self.alpha = c.N, c.L, c.K, c.dnum, c.alpha
         self.primes = [c.prime[i].q for i in range(self.L + self.K)]
+
+    @classmethod
+    def from_primes(cls, N, q_primes, dnum):
+        """a context over a GIVEN q chain (the reference's default chains of its unit tests); the p primes are derived"""
+        self = cls.__new__(cls)
+        self.lib = lib()
+        arr = (C.c_uint64 * len(q_primes))(*q_primes)
+        self.h = self.lib.orc_ctx_create_from_primes(N, arr, len(q_primes), dnum)
+        c = self.h.contents
+        self.N, self.L, self.K, self.dnum, self.alpha = c.N, c.L, c.K, c.dnum, c.alpha
+        self.primes = [c.prime[i].q for i in range(self.L + self.K)]
+        return self
 
     def close(self):
         if self.h:

@@ -298,3 +298,53 @@ def test_bsgs_inner(env, g, b, missing):
                                             arr([d.ptr for d in d_p0]), arr([d.ptr for d in d_p1]), autos, pt_tab, g, b, pt_q, level, None) < 0
     for d in d_r0 + d_r1 + d_o0 + d_o1 + d_p0 + d_p1 + list(d_pt.values()):
         d.free()
+
+
+def test_reference_polynomial_kats_on_the_gpu():
+    """rtlib/ant/unittest/ut_poly.cxx on the HIP path, N = 4, 10 primes, q0 = 60, Delta = 59, dnum = 3 (the parameters of its
+    `precompute` tests): the negacyclic product {0,1,4,5} x {1,2,4,3} = {-29,-31,-9,17} (:178-216) through acehip_ntt_forward /
+    acehip_modmul / acehip_ntt_inverse on every limb; rotation 3 of {0,1,4,59} = {0,-1,4,-59} and rotation 6 = identity (:112-143)
+    through the NTT-domain automorphism; fused and unfused Switch_key_precompute agree (:349-381): acehip_modup_digits =
+    acehip_decomp_modup per digit = acehip_decomp + acehip_mod_up."""
+    N, L, q0, sf, dnum = 4, 10, 60, 59, 3
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        K, level = o.K, L
+        primes = o.primes[:level]
+
+        def rns(vals):
+            return np.array([[v % q for v in vals] for q in primes], dtype=np.uint64)
+
+        def centred(x):
+            return [[int(v) - q if int(v) > q // 2 else int(v) for v in x[i]] for i, q in enumerate(primes)]
+
+        fa, fb = rt.ntt(rns([0, 1, 4, 5]), level), rt.ntt(rns([1, 2, 4, 3]), level)
+        prod = rt.ntt(rt.ew("modmul", fa, fb, level), level, inverse=True)
+        assert centred(prod) == [[-29, -31, -9, 17]] * level
+        assert centred(rt.ntt(rt.ew("modmul", fb, fa, level), level, inverse=True)) == [[-29, -31, -9, 17]] * level
+        c = rt.ntt(rns([0, 1, 4, 59]), level)
+        assert centred(rt.ntt(rt.rotate(c, rt.auto_index(3), level), level, inverse=True)) == [[0, -1, 4, -59]] * level
+        assert centred(rt.ntt(rt.rotate(c, rt.auto_index(6), level), level, inverse=True)) == [[0, 1, 4, 59]] * level
+        # Switch_key_precompute, fused and unfused
+        x = fa
+        nd = rt.num_decomp(level)
+        E = level + K
+        dx, dall = rt.to_device(x), rt.buf(nd * E * N)
+        rt.check(rt.lib.acehip_modup_digits(rt.h, dall.ptr, dx.ptr, level, None))
+        all_digits = dall.download((nd, E, N))
+        for d in range(nd):
+            fused = rt.decomp_modup(x, level, d)
+            assert np.array_equal(fused, o.decomp_modup(x, level, d)) and np.array_equal(all_digits[d], fused)
+            ddig, dout = rt.buf(o.alpha * N), rt.buf(E * N)
+            rt.check(rt.lib.acehip_memset(dout.ptr, 0, E * N * 8, None))
+            n2 = rt.lib.acehip_decomp(rt.h, ddig.ptr, dx.ptr, level, d, None)
+            assert n2 > 0 and rt.lib.acehip_mod_up(rt.h, dout.ptr, ddig.ptr, level, d, None) == n2
+            assert np.array_equal(dout.download((E, N)), fused), "unfused Decomp + Mod_up differs from Decomp_modup for digit %d" % d
+            ddig.free()
+            dout.free()
+        dx.free()
+        dall.free()
+    finally:
+        rt.close()
+        o.close()
