@@ -104,6 +104,7 @@ SYMBOLS = [
     ("acehip_shard_rescale_apply", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_encode_message", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _vp]),
     ("acehip_shard_encode_limbs", C.c_int, [_vp, _vp, _vp, C.c_double, _u32, _u32, _vp]),
+    ("acehip_debug_touches", C.c_size_t, [C.c_int, _vp, _vp, C.c_size_t]),
     # replicas of the caller's arena (image batches, simulated ranks)
     ("acehip_ctx_set_arena", C.c_int, [_vp, _vp]),
     ("acehip_workspace_words", C.c_size_t, [_vp]),

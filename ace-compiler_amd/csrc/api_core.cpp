@@ -9,6 +9,20 @@ acehip_stat* acehip_stat_slots() {
   static thread_local acehip_stat g[ST_COUNT];
   return g;
 }
+namespace {
+struct TouchLog {
+  bool on = false;
+  std::vector<std::pair<const void*, size_t>> v;
+};
+TouchLog& touch_log() {
+  static thread_local TouchLog t;
+  return t;
+}
+}  // namespace
+void dbg_touch(const void* p, size_t words) {
+  TouchLog& t = touch_log();
+  if (t.on && p != nullptr && words != 0) t.v.emplace_back(p, words);
+}
 u32& acehip_stat_mult() {
   static thread_local u32 m = 1;
   return m;
@@ -207,6 +221,21 @@ const uint32_t* acehip_auto_order(acehip_ctx* c, uint32_t k) {
   c->auto_tabs[k] = d;
   c->auto_tab_k[d] = k;
   return d;
+}
+
+// Debug aid of callers that defer work around launches whose operands they declare (the rt_ant shim's lazy zero fills,
+// ACEHIP_POISON=1): with logging on, the pipeline entry points (key-switch, ModUp of all digits, Mod_down, Rescale, encode) record
+// every range of caller memory they read or write; the call returns what was recorded since the last call.
+size_t acehip_debug_touches(int enable, const void** ptrs, size_t* words, size_t cap) {
+  TouchLog& t = touch_log();
+  const size_t n = t.v.size();
+  for (size_t i = 0; i < n && i < cap; ++i) {
+    ptrs[i] = t.v[i].first;
+    words[i] = t.v[i].second;
+  }
+  t.v.clear();
+  t.on = enable != 0;
+  return n;
 }
 
 // ---- replicas of the caller's arena ----

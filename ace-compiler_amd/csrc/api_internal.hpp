@@ -131,6 +131,8 @@ bool conv_fusable(const acehip_ctx* c, u32 n_in);
 // workspace carving (in limbs of N words)
 inline u64* ws_at(acehip_ctx* c, size_t limb) { return c->ws + limb * c->hp.N; }
 int ensure_embed_tables(acehip_ctx* c);
+// debug aid (acehip_debug_touches): the caller's memory a pipeline entry point reads or writes, as the entry point itself sees it
+void dbg_touch(const void* p, size_t words);
 
 // ---- replicas / limb ownership ----
 // The launch sets one call has to issue: ONE DevCtx covering the selected replicas, or -- simulated limb-sharded execution --

@@ -163,6 +163,8 @@ int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t l
   if (out == in) return fail(ACEHIP_EINVAL, "acehip_mod_down: out must not alias in");
   if (c->dc.logN == 16) return do_mod_down_n(c, out, nullptr, in, nullptr, level, (hipStream_t)s);
   stat(ST_MODDOWN, 1, 8ull * c->hp.N * (2 * level + c->hp.K));
+  dbg_touch(out, (size_t)level * c->hp.N);
+  dbg_touch(in, (size_t)(level + c->hp.K) * c->hp.N);
   return do_mod_down(c, out, in, level, ws_at(c, 0), (hipStream_t)s);
 }
 
@@ -173,6 +175,10 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
   if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
   const u32 np = in1 ? 2 : 1;
   const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N;
+  dbg_touch(out0, QL);
+  dbg_touch(out1, QL);
+  dbg_touch(in0, QL + PK);
+  dbg_touch(in1, QL + PK);
   u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
   u64* tmp = pc + 2 * PK;     // [2][level][N]
   const DcList dcs = launch_dcs(c);
@@ -365,6 +371,10 @@ static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const
   const u32 np = in1 ? 2 : 1;
   u64* last = ws_at(c, 0);   // [np][N]
   u64* t = ws_at(c, 2);      // [np][level-1][N]
+  dbg_touch(out0, (size_t)(level - 1) * N);
+  dbg_touch(out1, (size_t)(level - 1) * N);
+  dbg_touch(in0, (size_t)level * N);
+  dbg_touch(in1, (size_t)level * N);
   const size_t t_stride = (size_t)(level - 1) * N;
   const size_t row = (size_t)(level - 2) * hp.L;
   const DcList dcs = launch_dcs(c);
@@ -511,6 +521,10 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   const size_t N = hp.N, E = (size_t)(level + hp.K) * N;  // words per extended polynomial
   const u32 nd = plan->nd;
   // workspace: coef (level limbs) | ext[nd] | acc0 | acc1 | tmp[2] (level limbs each)
+  dbg_touch(out0, (size_t)level * N);
+  dbg_touch(out1, (size_t)level * N);
+  dbg_touch(in, (size_t)level * N);
+  dbg_touch(key, (size_t)nd * 2 * (hp.L + hp.K) * N);
   u64* coef = c->ws;
   u64* ext = coef + (size_t)level * N;
   u64* acc0 = ext + nd * E;
@@ -703,7 +717,10 @@ int acehip_encode_batch(acehip_ctx* c, uint64_t* const* h_q, const void* const* 
   NttFuse f;
   f.msg = c->emb_msg;
   f.msg_stride = N;
-  for (u32 b = 0; b < n_batch; ++b) f.polyz[b] = h_q[b];
+  for (u32 b = 0; b < n_batch; ++b) {
+    f.polyz[b] = h_q[b];
+    dbg_touch(h_q[b], (size_t)level * N);
+  }
   if (sf_degree > 1) {
     f.msg_scale = encode_scale_table(c, (u64)sf, sf_degree);
     if (!f.msg_scale) return fail(ACEHIP_EHIP, "acehip_encode: scale table upload failed");
@@ -723,6 +740,8 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
     return fail(ACEHIP_EINVAL, "acehip_encode: bad arguments");
   if (int e = ensure_embed_tables(c)) return e;
   hipStream_t st = (hipStream_t)s;
+  dbg_touch(d_q, (size_t)level * N);
+  dbg_touch(d_p, (size_t)n_p * N);
   launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
   const u64 sfi = (u64)sf;
   for (const DevCtx& dc : launch_dcs(c)) {
@@ -816,7 +835,9 @@ static int modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t
   for (u32 d = 0; d < nd; ++d) {
     if (!h_ext[d]) return fail(ACEHIP_EINVAL, "acehip_modup_digits: null output");
     outz.p[d] = h_ext[d];
+    dbg_touch(h_ext[d], (size_t)(level + hp.K) * N);
   }
+  dbg_touch(in, (size_t)level * N);
   u64* coef = c->ws;
   const DcList dcs = launch_dcs(c);
   for (const DevCtx& dc : dcs) {

@@ -152,17 +152,15 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
     poly_free(poly);  // into the pool's limbo until the queue has been issued
   }
   init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
-  if (ahead) {
-    hw_pending_flush();
-  } else {
-    const Touch touch[3] = {{nullptr, 0}, {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N}};
-    hw_flush_touching(__FILE__, __LINE__, touch, 3);  // (d_vals: staging ring / weights)
-  }
+  const Touch touch[3] = {{nullptr, 0}, {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N}};
+  if (ahead) hw_pending_flush();
+  else hw_flush_touching(__FILE__, __LINE__, touch, 3);  // (d_vals: staging ring / weights)
   {
     SelectGuard one_replica(shared_pt ? 0 : current_rep0(), shared_pt ? 1 : current_nrep());
     HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
                                  level, p_cnt, nullptr));
   }
+  if (!ahead) check_declared(__FILE__, __LINE__, touch, 3);
   poly->_is_ntt = true;
   if (c.profile) c.t_encode += wall_s() - t0;
 }

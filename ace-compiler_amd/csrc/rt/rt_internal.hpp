@@ -44,6 +44,8 @@ struct Touch {
   size_t words;
 };
 void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n);
+// ACEHIP_POISON=1 (debug): aborts when the launch issued since hw_flush_touching touched pool memory outside `touch`
+void check_declared(const char* file, int line, const Touch* touch, size_t n);
 }  // namespace rt
 #define HIPCHK(expr)                                                                       \
   do {                                                                                     \
@@ -68,6 +70,7 @@ void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n)
       fprintf(stderr, "%s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr, acehip_last_error()); \
       abort();                                                                             \
     }                                                                                      \
+    rt::check_declared(__FILE__, __LINE__, touch_, sizeof touch_ / sizeof touch_[0]);      \
   } while (0)
 
 // Device work that provably touches nothing the queue names (it only writes a block that was allocated, from memory

@@ -275,6 +275,24 @@ SelectGuard::~SelectGuard() {
 // device work is issued (HIPCHK), so a whole loop nest becomes a few launches; zero fills and limb copies
 // that sit between such loops ride in the same queue (one queue per host thread).
 namespace {
+// ---- ACEHIP_POISON=1: the safety net of the lazy execution below (debug mode, off by default).
+// Everything the runtime DEFERS or GIVES UP is overwritten with a value no residue can have: the limb of a zero fill that is
+// held back, every block that goes back to the pool.  A launch that reads an operand its HIPCHK_T list forgot (the fill is
+// still waiting), or memory that was freed, then computes with garbage instead of with stale data that happens to be right --
+// and the bit-exact comparisons of the test programs fail.  The declared lists themselves are checked against what the library's
+// entry points report (acehip_debug_touches): a range of pool memory a launch touches without declaring it aborts at the site.
+bool poison_on() {
+  static const bool on = [] {
+    const char* e = getenv("ACEHIP_POISON");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return on;
+}
+void poison(const u64* p, size_t words) {
+  // 0xA5A5...: above every prime of the chain (primes are below 2^61)
+  const int rc = acehip_fill(ctx().hip, const_cast<u64*>(p), 0xA5, words * sizeof(u64), nullptr);
+  RT_ASSERT(rc >= 0, "poison fill failed: %s", acehip_last_error());
+}
 thread_local std::vector<acehip_hw_op> g_hwq;
 struct HwqStats {
   size_t flushes = 0, ops = 0, by_kind[9] = {}, hist[8] = {};  // hist: <=1, <=4, <=16, <=64, <=256, <=1024, <=4096, more
@@ -382,15 +400,20 @@ void pending_flush() {
   const Touch touch[2] = {{p.out, (size_t)(p.kind == 1 ? p.level : p.level - 1) * N},
                           {p.in, (size_t)(p.kind == 1 ? p.level + ctx().K : p.level) * N}};
   queue_submit(touch, 2, true);
+  if (poison_on()) (void)acehip_debug_touches(1, nullptr, nullptr, 0);
   const int rc = p.kind == 1 ? acehip_mod_down(ctx().hip, p.out, p.in, p.level, nullptr)
                              : acehip_rescale(ctx().hip, p.out, p.in, p.level, nullptr);
   RT_ASSERT(rc >= 0, "deferred %s failed: %s", p.kind == 1 ? "Mod_down" : "Rescale", acehip_last_error());
+  check_declared(__FILE__, __LINE__, touch, 2);
 }
 }  // namespace
 static void limbo_release() {
   if (pool_limbo.empty()) return;
   std::lock_guard<std::mutex> lk(pool_mu);
-  for (auto& b : pool_limbo) pool_free[b.kind][b.second].push_back(b.first);
+  for (auto& b : pool_limbo) {
+    if (poison_on()) poison(b.first, b.second);  // (the queue that could name the block has been handed over: ordered behind it)
+    pool_free[b.kind][b.second].push_back(b.first);
+  }
   pool_limbo.clear();
 }
 namespace {
@@ -552,6 +575,7 @@ void lazy_meet_queue(const Touch* touch, size_t n_touch, bool defer) {
         } else {
           g_lazy.insert(o.res);
           g_lazy_stats.deferred++;
+          if (poison_on()) poison(o.res, N);  // (nothing queued names the limb and the launch does not touch it: safe to write now)
         }
         o.res = nullptr;  // taken out
         any = true;
@@ -619,8 +643,42 @@ void hw_flush() {
   queue_submit();
 }
 static void note_site(const char* file, int line);
+// ACEHIP_POISON=1: what the launch just issued really touched (as reported by the library) against what its site declared
+void check_declared(const char* file, int line, const Touch* touch, size_t n) {
+  if (!poison_on()) return;
+  static thread_local std::vector<const void*> ptrs(64);
+  static thread_local std::vector<size_t> words(64);
+  const size_t got = acehip_debug_touches(1, ptrs.data(), words.data(), ptrs.size());
+  for (size_t i = 0; i < got && i < ptrs.size(); ++i) {
+    const u64* p = (const u64*)ptrs[i];
+    const u64* e = p + words[i];
+    {  // only memory of this thread's pool can hold a deferred fill
+      std::lock_guard<std::mutex> lk(pool_mu);
+      auto it = pool_live.upper_bound(const_cast<u64*>(p));
+      if (it == pool_live.begin()) continue;
+      --it;
+      if (p >= it->first + it->second.words) continue;
+    }
+    // covered by the declared ranges?  (ranges may split the operand between them)
+    const u64* at = p;
+    bool progress = true;
+    while (at < e && progress) {
+      progress = false;
+      for (size_t k = 0; k < n; ++k) {
+        const u64* tp = (const u64*)touch[k].p;
+        if (tp && tp <= at && at < tp + touch[k].words) {
+          at = tp + touch[k].words;
+          progress = true;
+        }
+      }
+    }
+    RT_ASSERT(at >= e, "%s:%d: the launch touches %zu words at %p that its operand list does not declare (ACEHIP_POISON)", file, line,
+              (size_t)(e - at), (const void*)at);
+  }
+}
 void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n) {
   note_site(file, line);
+  if (poison_on()) (void)acehip_debug_touches(1, nullptr, nullptr, 0);  // start a fresh log for the launch that follows
   pending_flush();
   for (size_t i = 0; i < n; ++i) g_muc.written((const u64*)touch[i].p, touch[i].words);  // (any operand may be an output)
   queue_submit(touch, n, true);
@@ -822,6 +880,7 @@ void dfree(u64* p) {
   pool_live_bytes -= words * sizeof(u64);
   if (kind == BK_ARENA) g_arena.live -= granules(words);
   if (g_hwq.empty()) {
+    if (poison_on()) poison(p, words);
     pool_free[kind][words].push_back(p);
     for (auto z = g_lazy.lower_bound(p); z != g_lazy.end() && *z < p + words;) {  // fills nobody waits for any more
       z = g_lazy.erase(z);

@@ -288,6 +288,12 @@ int acehip_bsgs_inner_rot(acehip_ctx* ctx, uint64_t* const* d_out0, uint64_t* co
                           const uint64_t* const* d_in1, const uint32_t* h_in_auto, const uint64_t* const* d_pt, uint32_t g, uint32_t b,
                           uint32_t pt_q_limbs, uint32_t level, acehip_stream stream);
 
+/* Debug aid: with enable != 0 the pipeline entry points (acehip_key_switch, acehip_modup_digits[_to], acehip_mod_down[2],
+ * acehip_rescale[2], acehip_encode[_batch]) record every range of CALLER memory they read or write (device pointer, words);
+ * each call returns (up to cap of) what the calling thread's entry points recorded since the previous call and clears the log.
+ * The rt_ant shim checks its declared-operand lists against it under ACEHIP_POISON=1. */
+size_t acehip_debug_touches(int enable, const void** ptrs, size_t* words, size_t cap);
+
 /* ---- replicas of the caller's polynomial memory: image batches and simulated ranks ----
  * The reference gets throughput from one OpenMP thread per image (rtlib/ant/dataset/resnet_cifar.main.inc:77-116); all
  * images run the same data-oblivious program on the same keys and weights.  The GPU form: the caller keeps its ciphertext
