@@ -110,3 +110,30 @@ def test_bench_shard_mode_one_rank_joins_rccl():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["unit"] == "images/s" and d["value"] > 0
     assert d["shard"]["rccl_ranks"] == 1 and d["shard"]["owned_limbs_per_rank"] == [45] and d["shard"]["bytes_received_per_image_all_ranks"] == 0
+
+
+@pytest.mark.parametrize("name", ["rotate", "relin", "conv2d", "relu", "bootstrap"])
+def test_examples_under_poison_are_bit_identical(name, tmp_path):
+    """ACEHIP_POISON=1 (csrc/rt/rt_poly.cpp): every limb whose zero fill is deferred and every block that returns to the pool is
+    overwritten with a non-residue, and every launch with a declared operand list is checked against what the library says it
+    touched.  A launch that reads an operand its list forgot, or freed memory, would compute with garbage: the output ciphertext of
+    the unchanged reference programs must stay byte-identical to the normal run's."""
+    exe = os.path.join(EX_DIR, "eg_" + name)
+    _need(exe)
+    out0, plain = _run(exe, [], {}, tmp_path, "plain")
+    out1, pois = _run(exe, [], {"ACEHIP_POISON": "1"}, tmp_path, "poison")
+    assert "SUCESS!" in out0 and "SUCESS!" in out1
+    assert plain == pois
+
+
+def test_resnet20_under_poison_is_bit_identical(tmp_path):
+    """the same for one image of the generated ResNet-20 (every deferral path of the runtime: 170 k lazy fills, 2.5 M queued limb-ops,
+    prefetched weight plaintexts) -- and with an image batch, whose shared blocks go through the same pool"""
+    exe = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+    _need(exe)
+    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
+    _, plain = _run(exe, ["2"], env, tmp_path, "plain", timeout=1200)
+    _, pois = _run(exe, ["2"], dict(env, ACEHIP_POISON="1"), tmp_path, "poison", timeout=1200)
+    _, pois_b2 = _run(exe, ["2"], dict(env, ACEHIP_POISON="1", MODEL_BATCH="2"), tmp_path, "poisonb2", timeout=1200)
+    assert plain == pois
+    assert pois_b2["0.0"] == plain["0.0"] and pois_b2["0.1"] == plain["1.0"]
