@@ -137,3 +137,13 @@ def test_resnet20_under_poison_is_bit_identical(tmp_path):
     _, pois_b2 = _run(exe, ["2"], dict(env, ACEHIP_POISON="1", MODEL_BATCH="2"), tmp_path, "poisonb2", timeout=1200)
     assert plain == pois
     assert pois_b2["0.0"] == plain["0.0"] and pois_b2["0.1"] == plain["1.0"]
+
+
+def test_poison_mode_catches_an_undeclared_operand(tmp_path):
+    """the check itself: with ACEHIP_POISON_SELFTEST=1 the paired Mod_down of a rotation leaves one input out of its declared list
+    (csrc/rt/rt_poly.cpp Mod_down) -- under ACEHIP_POISON=1 the program must stop at that site instead of running on"""
+    exe = os.path.join(EX_DIR, "eg_rotate")
+    _need(exe)
+    env = dict(os.environ, ACEHIP_POISON="1", ACEHIP_POISON_SELFTEST="1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "does not declare" in r.stderr and "rt_poly.cpp" in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
