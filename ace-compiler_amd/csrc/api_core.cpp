@@ -23,12 +23,20 @@ void dbg_touch(const void* p, size_t words) {
   TouchLog& t = touch_log();
   if (t.on && p != nullptr && words != 0) t.v.emplace_back(p, words);
 }
+namespace acehip {
+void ntt_count(u64 limbs) {  // (launchers are called once per replica set: the multiplier is the launch's own)
+  acehip_stat* g = acehip_stat_slots();
+  g[ST_NTT_ALL].calls++;
+  g[ST_NTT_ALL].units += limbs;
+  g[ST_NTT_ALL].bytes += limbs * 16ull;  // x N below would need the ring size: bench.py multiplies
+}
+}  // namespace acehip
 u32& acehip_stat_mult() {
   static thread_local u32 m = 1;
   return m;
 }
 static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
-                                                "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed"};
+                                                "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed", "elementwise_mul", "ntt_launched"};
 
 extern "C" {
 

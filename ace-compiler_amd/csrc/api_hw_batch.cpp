@@ -633,12 +633,13 @@ static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hi
   const u64 span = (u64)c->hp.N * 8;
   // limbs moved per op (24N per add/mul, 16N per rotate; copy 16N, zero 8N, muladd 32N, scalar forms 16N)
   static const u64 kHwWords[9] = {3, 3, 2, 2, 1, 3, 4, 2, 2};
-  u64 alg_words = 0, n_rot = 0;
+  u64 alg_words = 0, n_rot = 0, n_mul = 0;
   for (size_t k = 0; k < n; ++k) {
     const acehip_hw_op& o = ops[k];
     if (o.op > ACEHIP_HW_ADDC) return fail(ACEHIP_EINVAL, "acehip_hw_batch: unknown op");
     alg_words += kHwWords[o.op];
     n_rot += o.op == ACEHIP_HW_ROTATE;
+    n_mul += o.op == ACEHIP_HW_MUL || o.op == ACEHIP_HW_MULADD || o.op == ACEHIP_HW_MULC;
     if (!o.res || (hw_has_a(o.op) && !o.a) || ((hw_has_b(o.op) || o.op == ACEHIP_HW_ROTATE) && !o.b))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: null operand");
     if (hw_uses_prime(o.op) && o.prime_gi >= T) return fail(ACEHIP_EINVAL, "prime index out of range");
@@ -727,6 +728,10 @@ static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hi
   }
   if (!g_plan) {
     stat(ST_EW, n - n_rot, (alg_words - 2 * n_rot) * span);
+    if (n_mul) {
+      stat(ST_EW_MUL, n_mul, 3 * n_mul * span);
+      acehip_stat_slots()[ST_EW_MUL].calls--;  // (a subset of "elementwise": the limb-ops that multiply)
+    }
     if (n_rot) {
       stat(ST_ROTATE, n_rot, 2 * n_rot * span);
       acehip_stat_slots()[ST_ROTATE].calls--;  // one entry point call, counted under elementwise

@@ -110,7 +110,7 @@ struct acehip_ctx {
 };
 
 // ---- call statistics: algorithmic bytes of SURVEY 8(d) per entry point (tables and scratch excluded) ----
-enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_COUNT };
+enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_EW_MUL, ST_NTT_ALL, ST_COUNT };
 acehip_stat* acehip_stat_slots();  // this thread's counters [ST_COUNT] (one host thread = one image stream)
 u32& acehip_stat_mult();  // replicas the current call covers (set by check_dev): an op on B images counts B times
 inline void stat(int k, u64 units, u64 bytes) {

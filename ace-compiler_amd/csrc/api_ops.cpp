@@ -95,6 +95,10 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
 
 static int ew(acehip_ctx* c, EwOp op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n, acehip_stream s) {
   if (c) stat(ST_EW, n, (op == EwOp::MulAdd ? 32ull : 24ull) * c->hp.N * n);
+  if (c && (op == EwOp::Mul || op == EwOp::MulAdd)) {
+    stat(ST_EW_MUL, n, 24ull * c->hp.N * n);
+    acehip_stat_slots()[ST_EW_MUL].calls--;
+  }
   if (int e = check_range(c, level, pos0, n)) return e;
   for (const DevCtx& dc : launch_dcs(c)) launch_ew(dc, op, r, a, b, level, pos0, n, (hipStream_t)s);
   return post_launch();
@@ -977,6 +981,8 @@ int acehip_bsgs_inner_rot(acehip_ctx* c, uint64_t* const* out0, uint64_t* const*
   for (const DevCtx& dc : launch_dcs(c)) launch_bsgs_inner(dc, a, level, (hipStream_t)s);
   const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
   stat(ST_EW, n_pt, 8ull * E * (2ull * g + n_pt + 2ull * b));
+  stat(ST_EW_MUL, 2ull * n_pt * (level + c->hp.K), 2ull * n_pt * 24ull * E);  // (c0 and c1 of every product: limb-multiplications)
+  acehip_stat_slots()[ST_EW_MUL].calls--;
   return post_launch();
 }
 

@@ -136,6 +136,7 @@ void launch_ntt(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bo
                 u32 n_polys, size_t poly_stride, u32 skip_alpha) {
   if (n_limbs == 0) return;
   const u32 logN = c.logN;
+  if (logN != 16) ntt_count((u64)n_limbs * n_polys * c.nrep);  // (N = 2^16: counted by launch_ntt_fused)
   if (logN <= 12) {  // whole limb in LDS (<= 32 KiB): one pass
     if (!inverse) launch_pass<true, false>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s, skip_alpha);
     else          launch_pass<true, true>(c, poly, poly_stride, n_polys, level, pos0, pos_off, n_limbs, 0, logN, 0, s, skip_alpha);

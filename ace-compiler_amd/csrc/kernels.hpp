@@ -189,6 +189,8 @@ struct NttFuse {
   const u64* w = nullptr;
   const u64* wp = nullptr;
 };
+// statistics hook (api_core.cpp): `limbs` limb-transforms were just launched (direct calls and the ones inside the pipelines alike)
+void ntt_count(u64 limbs);
 // NTT over limb positions [pos0, pos0+n) of poly at `level`
 // the limb at position pos lives at poly + (pos - pos_off)*N
 // n_polys polynomials poly_stride words apart are transformed in the same launch

@@ -1085,6 +1085,7 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
                       u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
   ACEHIP_ABLATE(ABL_NTT);
   if (n_limbs == 0) return;
+  ntt_count((u64)n_limbs * n_polys * c.nrep);
   if (launch_ntt_narrow(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f)) return;
   dim3 block(256), grid((c.N >> 12) * n_limbs * n_polys * c.nrep);  // 1-D: ntt_block() maps it XCD-aware
   const bool tw8 = c.twp_fwd != nullptr && n_polys * c.nrep <= c.tw8_max_polys;  // few polynomials share the twiddles: 8-byte stream

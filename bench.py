@@ -104,6 +104,51 @@ def _ref_bench(ref, cpus, ks_reps, ntt_reps):
     return res
 
 
+MIX = (65536, 34, 51, 50, 3, 20)   # the generated ResNets' parameter set (N, L, q0, Delta, dnum) and a mid-range level for the samples
+
+
+def _ref_mix(ref, cpus, reps):
+    """`ref_dump mix` (seconds per call of every primitive family of the reference at the workload's parameter set), one pinned
+    child per entry of cpus, started together."""
+    procs = [subprocess.Popen([ref, "mix"] + [str(x) for x in MIX] + [str(reps)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              preexec_fn=(lambda c=cpu: os.sched_setaffinity(0, {c}))) for cpu in cpus]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError("ref_dump mix exited with %d" % p.returncode)
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    return res
+
+
+def price_image(mix, st):
+    """Seconds ONE core of this host needs for one image: the per-image call statistics of the run (st: family -> (calls, units,
+    algorithmic bytes); the same data-oblivious program makes the same calls on the reference runtime) priced family by family with
+    the reference's own primitives as timed by `ref_dump mix` at level 20 (costs scale with the limbs a call touches, i.e. with its
+    algorithmic bytes)."""
+    N, L, _, _, _, l = MIX
+    K, nd = mix["K"], mix["num_decomp"]
+    limb = 8.0 * N
+    t_mul, t_add, t_rot = mix["hw_modmul_s"], mix["hw_modadd_s"], mix["hw_rotate_s"]
+    t_ntt = 0.5 * (mix["ntt_fwd_s"] + mix["ntt_inv_s"])
+    pair = 2 * t_mul + 2 * t_add                                   # one (limb, digit) of a key inner product: polynomial.c:148-183
+    t_ks = mix["decomp_modup_all_digits_s"] + (l + K) * nd * pair + 2 * mix["mod_down_s"]
+    by = lambda k: st.get(k, (0, 0, 0))[2]
+    n_mul = st.get("elementwise_mul", (0, 0, 0))[1]
+    parts = {
+        "ntt": by("ntt") / (2 * limb) * t_ntt,
+        "elementwise": n_mul * t_mul + max(0.0, by("elementwise") - 3 * limb * n_mul) / (3 * limb) * t_add,
+        "rotate": by("rotate") / (2 * limb) * t_rot,
+        "decomp_modup": by("decomp_modup") / (limb * (l + nd * (l + K))) * mix["decomp_modup_all_digits_s"],
+        "key_inner_product": by("key_inner_product") / (limb * (l + K) * (3 * nd + 2)) * (l + K) * nd * pair,
+        "mod_down": by("mod_down") / (limb * (2 * l + K)) * mix["mod_down_s"],
+        "rescale": by("rescale") / (limb * (2 * l - 1)) * mix["rescale_s"],
+        "key_switch": by("key_switch") / (limb * (l + 2 * nd * (l + K) + 2 * l)) * t_ks,
+        "encode": by("encode") / (limb * l + 4.0 * N / 4) * mix["encode_s"],
+    }
+    return sum(parts.values()), parts
+
+
 def cpu_baseline(have_model):
     """Reference rtlib (oracle/_ref/ref_dump, built from /root/reference by oracle/Makefile) timed on this host BEFORE the
     GPU is touched: (1) one process on one core, (2) one process per usable physical core of one socket, all at once
@@ -118,6 +163,9 @@ def cpu_baseline(have_model):
             one = _ref_bench(ref, topo["pin_cpus"][:1], 8, 3000)[0]
             many = _ref_bench(ref, topo["pin_cpus"], 8, 3000) if len(topo["pin_cpus"]) > 1 else [one]
             c = len(many)
+            if have_model:  # the primitives of the reference at the workload's own parameter set (L=34, dnum=3), alone and under load
+                mix_one = _ref_mix(ref, topo["pin_cpus"][:1], 6)[0]
+                mix_many = _ref_mix(ref, topo["pin_cpus"], 6) if len(topo["pin_cpus"]) > 1 else [mix_one]
             agg_ks = sum(1.0 / r["key_switch_s"] for r in many)
             agg_ntt = sum(2 * 16 * N / (r["ntt_fwd_s"] + r["ntt_inv_s"]) for r in many) / 1e9
             res = {"cores": c, "kind": "reference", "cpu_model": topo["cpu_model"], "sockets": topo["sockets"],
@@ -130,6 +178,9 @@ def cpu_baseline(have_model):
                    "sample": "reference rtlib (gcc -O3): per process 3000 Ftt_fwd + 3000 Ftt_inv of one limb (N=2^16) and 8 full "
                              "key-switches (L=25, dnum=4); first 1 process alone, then %d processes at once, one pinned to each "
                              "usable physical core of socket 0" % c}
+            if have_model:
+                res["mix_one_core"] = mix_one
+                res["mix_loaded"] = mix_many
             if topo["cgroup_cpu_quota"] is not None and c < topo["cores_per_socket"]:
                 res["sample"] += (" (the container's cgroup allows %.0f CPUs of the socket's %d cores: the full socket cannot be "
                                   "loaded here; socket_extrapolated assumes ideal scaling from the measured %d)"
@@ -161,27 +212,61 @@ def cpu_baseline(have_model):
                "key_switch_per_s": round(1.0 / ks_s, 4), "ntt_GBs": round(2 * 16 * N * reps / (t2 - t0) / 1e9, 4),
                "key_switch_s_per_core_loaded": round(ks_s, 4),
                "sample": "3000 fwd + 3000 inv NTTs of one limb (N=2^16) and 4 key-switches by oracle/ckks_oracle.c, 1 thread"}
-    if have_model:
-        # scale to images/s: (full CPU ResNet-20 seconds / key-switch seconds) measured once on the dev box
+    if have_model and "mix_loaded" in res:
+        res["unit"] = "images/s"
+        res["value"] = None  # priced by finish_cpu_baseline() once the run's per-image call statistics are known
+    elif have_model:
+        # no reference build on this host: the port's key-switch scaled by the dev-box ratio (a fallback, labelled as such)
         dev = os.path.join(ROOT, "profiles", "cpu_resnet20_devbox.json")
-        ratio, src = None, None
+        ratio, src = 1453.96 / 0.58, "BASELINE.md (published 1453.96 s/image; 0.58 s key-switch)"
         if os.path.exists(dev):
             d = json.load(open(dev))
             if d.get("image_s") and d.get("key_switch_s"):
                 ratio, src = d["image_s"] / d["key_switch_s"], "profiles/cpu_resnet20_devbox.json"
-        if ratio is None:  # published: 1453.96 s/image (ace_pre.log:28); key-switch 0.58 s on the survey box
-            ratio, src = 1453.96 / 0.58, "BASELINE.md (published 1453.96 s/image; 0.58 s key-switch)"
         res["value"] = round(res["key_switch_per_s"] / ratio, 8)
         res["unit"] = "images/s"
-        if "one_core" in res:
-            res["one_core"]["images_per_s"] = round(res["one_core"]["key_switch_per_s"] / ratio, 8)
         res["sample"] += "; scaled to images/s by (CPU ResNet-20 s/image) / (CPU key-switch s) = %.1f from %s" % (ratio, src)
     else:
         res["value"], res["unit"] = res["key_switch_per_s"], "key-switches/s"
+    if res.get("value") is not None:
+        _extrapolate_socket(res)
+    return res
+
+
+def _extrapolate_socket(res):
     if res["cores"] < res["cores_per_socket"]:
         res["socket_extrapolated"] = {"cores": res["cores_per_socket"], "value": round(res["value"] * res["cores_per_socket"] / res["cores"], 8),
-                                      "unit": res["unit"], "note": "ideal linear scaling of the measured aggregate; an upper bound for the CPU"}
-    return res
+                                      "unit": res["unit"], "note": "EXTRAPOLATED, not measured: ideal linear scaling of the measured aggregate to the "
+                                                                   "whole socket; an upper bound for the CPU"}
+
+
+def finish_cpu_baseline(res, stats_per_image):
+    """images/s of the measured cores: every loaded core's `ref_dump mix` rates price one image of THIS run's call statistics
+    (price_image); the aggregate is the sum over the cores that were loaded at once.  Also: the same model with the dev container's
+    rates against the full reference run measured there (profiles/cpu_resnet20_devbox.json) -- how far the pricing is off."""
+    if res is None or "mix_loaded" not in res:
+        return
+    per_core = [price_image(m, stats_per_image)[0] for m in res["mix_loaded"]]
+    s1, parts = price_image(res["mix_one_core"], stats_per_image)
+    res["value"] = round(sum(1.0 / t for t in per_core), 8)
+    res["image_s_per_core_loaded"] = round(sum(per_core) / len(per_core), 2)
+    res["one_core"]["image_s"] = round(s1, 2)
+    res["one_core"]["images_per_s"] = round(1.0 / s1, 8)
+    res["one_core"]["image_s_by_family"] = {k: round(v, 2) for k, v in parts.items()}
+    res["sample"] += ("; images/s: `ref_dump mix 65536 34 51 50 3 20` (the reference's NTT, Hw_modmul / Hw_modadd / Hw_rotate, Decompose_modup, "
+                      "Reduce_rns_base, Rescale_poly and encode at the workload's own parameter set; ~10 s per process, alone and on all "
+                      "measured cores at once) pricing the per-image call statistics of this run family by family")
+    dev = os.path.join(ROOT, "profiles", "cpu_resnet20_devbox.json")
+    if os.path.exists(dev):
+        d = json.load(open(dev))
+        if d.get("mix_level20") and d.get("image_s"):
+            pred = price_image(d["mix_level20"], stats_per_image)[0]
+            res["model_check"] = {"host": d.get("cpu"), "predicted_image_s": round(pred, 1), "measured_image_s": d["image_s"],
+                                  "predicted_over_measured": round(pred / d["image_s"], 3),
+                                  "note": "the same pricing with the dev container's primitive timings against the full reference run of the "
+                                          "unchanged generated ResNet-20 measured there"}
+    _extrapolate_socket(res)
+
 
 
 def load_model_runtime(device, batch=1):
@@ -592,12 +677,28 @@ def main():
 
     if rank == 0:
         achieved = bytes_per_dir / (fwd_ms * 1e-3) / 1e9
-        traffic = image_traffic = None
+        traffic = image_traffic = ntt_kernel_s = None
+        traffic_src = {"file": "profiles/traffic.json", "status": "absent"}
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):  # PMC passes (tools/pmc_roofline.sh, tools/pmc_image.sh) recorded under profiles/
+            # counters are collected in separate rocprofv3 --pmc runs, not in this process: the file says which sources it was
+            # measured on (tools/csrc_fingerprint.py) and for which batch; figures of other sources are NOT reported as measured
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import csrc_fingerprint
+
             tr = json.load(open(tr_path))
-            traffic = tr.get("ntt_forward_bytes_per_launch")
-            image_traffic = None if r110 else tr.get("resnet20_bytes_per_image")
+            now_fp = csrc_fingerprint.fingerprint()
+            fresh = tr.get("csrc_fingerprint") == now_fp
+            traffic_src = {"file": "profiles/traffic.json", "measured_on_csrc": tr.get("csrc_fingerprint"), "csrc_now": now_fp,
+                           "measured_at_commit": tr.get("git_commit"), "images_per_batch_measured": tr.get("images_per_batch"),
+                           "status": "current" if fresh else "stale: kernel / runtime sources changed since the counters were collected (figures withheld)"}
+            if fresh:
+                traffic = tr.get("ntt_forward_bytes_per_launch")
+                if not r110 and tr.get("images_per_batch") == n_batch:
+                    image_traffic = tr.get("resnet20_bytes_per_image")
+                    ntt_kernel_s = (tr.get("resnet20_kernel_seconds_per_image") or {}).get("ntt")
+                elif not r110:
+                    traffic_src["status"] += "; whole-image traffic was measured with %s images per batch, this run uses %d" % (tr.get("images_per_batch"), n_batch)
         out = {
             "metric": metric, "value": round(value, 6), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -609,7 +710,7 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "ntt8_strided_kernel<fwd> + ntt8_contig_kernel<fwd> (one forward NTT launch = 2 passes of 8 radix-2 stages)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(fwd_ms, 4), "inverse_launch_ms": round(inv_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_dir,
                          "ntt_fwd_inv_GBs": round(2 * bytes_per_dir / ((fwd_ms + inv_ms) * 1e-3) / 1e9, 2),
@@ -620,7 +721,7 @@ def main():
                            "frac_of_hbm_peak": round(ks_bytes / (ks_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         # whole-workload view: algorithmic bytes of every entry-point call of the timed region on this rank
-        alg = sum(v[2] for k, v in stats.items() if k != "zero_fill_executed")  # that family is a subset of "elementwise"
+        alg = sum(v[2] for k, v in stats.items() if k not in ("zero_fill_executed", "elementwise_mul", "ntt_launched"))  # (subsets / a launch counter)
         out["workload_roofline"] = {
             "algorithmic_bytes_per_image": int(alg / args.steps / n_batch),
             "algorithmic_GBs": round(n_streams * alg / elapsed_local / 1e9, 2),
@@ -635,6 +736,17 @@ def main():
             "note": "algorithmic_*: sum over acehip_* calls of the SURVEY 8(d) per-call bytes (tables, scratch, re-reads excluded) of one "
                     "stream, times the streams of the GPU, / wall time -- NOT a memory-traffic figure (chains of per-limb ops keep "
                     "intermediates in registers, dead fills are dropped); measured_*: hardware counters"}
+        if use_model:
+            # the same kernels inside the workload: every limb-transform the library launched for one image (direct calls and the
+            # ones inside ModUp / ModDown / Rescale / key-switch / encode), against their summed kernel time from the rocprofv3
+            # --kernel-trace --stats run recorded in profiles/traffic.json (one stream; withheld when the sources changed since)
+            n_lt = stats.get("ntt_launched", (0, 0, 0))[1] / (args.steps * n_batch)
+            out["roofline"]["in_workload"] = {
+                "limb_transforms_per_image": round(n_lt, 1),
+                "kernel_seconds_per_image": ntt_kernel_s,
+                "us_per_limb_transform": (round(ntt_kernel_s / n_lt * 1e6, 4) if (ntt_kernel_s and n_lt) else None),
+                "best_case_batch_us_per_limb_transform": round((fwd_ms + inv_ms) / 2 * 1e3 / limbs, 4),
+                "GBs_algorithmic": (round(n_lt * 16 * N / ntt_kernel_s / 1e9, 1) if (ntt_kernel_s and n_lt) else None)}
         if cache_run is not None:
             out["with_plaintext_cache"] = cache_run
         if logits is not None:
@@ -643,6 +755,9 @@ def main():
             out.pop("key_switch")
             out.pop("workload_roofline")
         if cpu_res is not None:
+            if use_model:
+                # (the images of a batch share their weight-plaintext encodes here; the reference encodes them for every image)
+                finish_cpu_baseline(cpu_res, {k: tuple(x / (args.steps * (1 if k == "encode" else n_batch)) for x in v) for k, v in stats.items()})
             out["cpu_baseline"] = cpu_res
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             ref_v = cpu_res.get("socket_extrapolated", cpu_res)["value"]

@@ -213,8 +213,11 @@ int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const
  * digits, key-switches ...) and the ALGORITHMIC bytes of SURVEY 8(d) (tables, scratch and re-reads excluded).
  * bench.py divides the per-image sum by the wall time for the whole-workload roofline.  Returns the number of
  * families; acehip_stat_name(i) names family i ("ntt", "elementwise", "rotate", "decomp_modup",
- * "key_inner_product", "mod_down", "rescale", "key_switch", "encode", and "zero_fill_executed": the zero fills of
- * "elementwise" that were actually executed, i.e. not proven dead inside their batch). */
+ * "key_inner_product", "mod_down", "rescale", "key_switch", "encode"; two subsets of "elementwise": "zero_fill_executed", the zero
+ * fills that were actually executed, i.e. not proven dead inside their batch, and "elementwise_mul", the limb-ops that contain a
+ * modular multiplication (units = limb multiplications): what a CPU spends its elementwise time on); and "ntt_launched": every
+ * limb-transform the library launched, the ones inside the pipelines (ModUp, ModDown, Rescale, key-switch, encode) included -- "ntt"
+ * only counts the direct entry points (units = limb-transforms, bytes = 16 per coefficient index: multiply by N). */
 typedef struct acehip_stat {
   uint64_t calls, units, bytes;
 } acehip_stat;

@@ -9,6 +9,7 @@
  *   ref_dump ops    N L q0 sf dnum level seed -> per-op input/output vectors (full if N<=64,
  *                                                checksums otherwise)
  *   ref_dump bench  N L q0 sf dnum level ks_reps ntt_reps -> timings of the reference ops (JSON)
+ *   ref_dump mix    N L q0 sf dnum level reps            -> seconds per call of every primitive family at this parameter set (JSON)
  *   ref_dump ptfile N L q0 sf dnum level out n_entries sc_degree seed -> a DE_PLAINTEXT data file ("!ANTFHE" container of
  *                   rt_data_def.h:90-111 whose entries are PLAINTEXT_BUFFERs made by the reference's Encode_plain_buffer,
  *                   plain_eval.c:107-130): the fixture of the pre-encoded weight path (Pt_get, pt_mgr.c:128-159)
@@ -431,6 +432,92 @@ static int do_bench(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, siz
   return 0;
 }
 
+/* CPU baseline at the WORKLOAD's parameter set: seconds per call of every primitive family the generated ResNets spend their time
+ * in (single thread), so that bench.py can price one image on this host from the per-image call statistics of the run
+ * (acehip_stats: the same data-oblivious program makes the same calls on either runtime) instead of scaling one micro-op by a
+ * constant measured elsewhere.  Families as in include/acehip.h acehip_stat_name(). */
+static int do_mix(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_t level, int reps) {
+  CKKS_PARAMETER* p = make_param(N, L, q0, sf, dnum);
+  CRT_CONTEXT*    crt = p->_crt_context;
+  size_t          K = p->_num_p_primes;
+  dnum = p->_num_q_parts;
+  Set_rtlib_config(CONF_OP_FUSION_DECOMP_MODUP, 1);
+  POLYNOMIAL a, b, r, ext, md, rs;
+  Alloc_poly_data(&a, N, level, 0);
+  Alloc_poly_data(&b, N, level, 0);
+  Alloc_poly_data(&r, N, level, 0);
+  fill_uniform(crt, a._data, level, level, N, 1);
+  fill_uniform(crt, b._data, level, level, N, 2);
+  Set_is_ntt(&a, TRUE);
+  Set_is_ntt(&b, TRUE);
+  Alloc_poly_data(&ext, N, level, K);
+  Set_is_ntt(&ext, TRUE);
+  Alloc_poly_data(&md, N, level, 0);
+  Alloc_poly_data(&rs, N, level, 0);
+  double t0;
+  /* NTT / iNTT of one limb */
+  VALUE_LIST vl;
+  int64_t*   buf = malloc(sizeof(int64_t) * N);
+  memcpy(buf, a._data, sizeof(int64_t) * N);
+  Init_i64_value_list_no_copy(&vl, N, buf);
+  int ntt_reps = reps * 100;
+  t0 = now_s();
+  for (int i = 0; i < ntt_reps; i++) Ftt_fwd(&vl, Get_ntt(prime_at(crt, 1)), &vl);
+  double t_fwd = (now_s() - t0) / ntt_reps;
+  t0 = now_s();
+  for (int i = 0; i < ntt_reps; i++) Ftt_inv(&vl, Get_ntt(prime_at(crt, 1)), &vl);
+  double t_inv = (now_s() - t0) / ntt_reps;
+  /* Hw_modmul / Hw_modadd / Hw_rotate of one limb (poly_arith.c:14-56) */
+  MODULUS* m1 = Get_q_modulus_head(crt) + 1;
+  int      ew_reps = reps * 200;
+  t0 = now_s();
+  for (int i = 0; i < ew_reps; i++) Hw_modmul(r._data + N, a._data + N, b._data + N, m1, N);
+  double t_mul = (now_s() - t0) / ew_reps;
+  t0 = now_s();
+  for (int i = 0; i < ew_reps; i++) Hw_modadd(r._data + N, a._data + N, b._data + N, m1, N);
+  double t_add = (now_s() - t0) / ew_reps;
+  MODULUS two_n_mod;
+  Init_modulus(&two_n_mod, 2 * (int64_t)N);
+  VALUE_LIST* order = Alloc_value_list(I64_TYPE, N);
+  Precompute_automorphism_order(order, Find_automorphism_index(5, &two_n_mod), N, TRUE);
+  t0 = now_s();
+  for (int i = 0; i < ew_reps; i++) Hw_rotate(r._data + N, a._data + N, Get_i64_values(order), m1, N);
+  double t_rot = (now_s() - t0) / ew_reps;
+  /* Decompose_modup of every digit (polynomial.c:1241-1335), Reduce_rns_base (:928-967), Rescale_poly (:1097-1163) */
+  size_t nd = Get_num_decomp_poly(&a, crt);
+  t0 = now_s();
+  for (int i = 0; i < reps; i++)
+    for (size_t part = 0; part < nd; part++) Decompose_modup(&ext, &a, crt, nd, part);
+  double t_modup = (now_s() - t0) / reps;
+  fill_uniform(crt, ext._data, level + K, level, N, 3);
+  t0 = now_s();
+  for (int i = 0; i < reps; i++) Reduce_rns_base(&md, &ext, crt);
+  double t_md = (now_s() - t0) / reps;
+  t0 = now_s();
+  for (int i = 0; i < reps; i++) {
+    Set_poly_level(&rs, level);
+    Rescale_poly(&rs, &a, crt);
+  }
+  double t_rs = (now_s() - t0) / reps;
+  /* Encode_at_level_with_sf of N/4 floats (the common weight-plaintext shape: Pt_from_msg, pt_mgr.c:182) */
+  CKKS_ENCODER* enc = Alloc_ckks_encoder(p);
+  size_t        len = N / 4;
+  VALUE_LIST*   vals = Alloc_value_list(DCMPLX_TYPE, len);
+  for (size_t i = 0; i < len; i++) DCMPLX_VALUE_AT(vals, i) = (double)((float)((int)((i * 7 + 3) % 17) - 8) / 16.0f);
+  t0 = now_s();
+  for (int i = 0; i < reps; i++) {
+    PLAINTEXT* pt = Alloc_plaintext();
+    Encode_at_level_with_sf(pt, enc, vals, level, 0, 1);
+    Free_plaintext(pt);
+  }
+  double t_enc = (now_s() - t0) / reps;
+  printf("{\"kind\": \"reference\", \"N\": %u, \"L\": %zu, \"dnum\": %zu, \"K\": %zu, \"level\": %zu, \"num_decomp\": %zu, \"reps\": %d, "
+         "\"ntt_fwd_s\": %.9f, \"ntt_inv_s\": %.9f, \"hw_modmul_s\": %.9f, \"hw_modadd_s\": %.9f, \"hw_rotate_s\": %.9f, "
+         "\"decomp_modup_all_digits_s\": %.9f, \"mod_down_s\": %.9f, \"rescale_s\": %.9f, \"encode_s\": %.9f}\n",
+         N, L, dnum, K, level, nd, reps, t_fwd, t_inv, t_mul, t_add, t_rot, t_modup, t_md, t_rs, t_enc);
+  return 0;
+}
+
 /* DE_PLAINTEXT data file written the way the compiler's RT_DATA_WRITER lays it out: header page, entries aligned to
  * 4096 bytes, lookup table at the end.  Entry e holds the message m[i] = ((splitmix64(seed + e, i) % 2001) - 1000) / 1024
  * (N/2 floats, exactly representable) encoded at `level` with scale degree sc_degree by the reference. */
@@ -497,6 +584,7 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[1], "encode")) return do_encode(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? strtoull(argv[8], 0, 10) : 1);
   if (!strcmp(argv[1], "ptfile") && argc >= 12)
     return do_ptfile(N, L, q0, sf, dnum, atoi(argv[7]), argv[8], atoi(argv[9]), (uint32_t)atoi(argv[10]), strtoull(argv[11], 0, 10));
+  if (!strcmp(argv[1], "mix")) return do_mix(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 2);
   if (!strcmp(argv[1], "bench")) return do_bench(N, L, q0, sf, dnum, argc > 7 ? atoi(argv[7]) : L, argc > 8 ? atoi(argv[8]) : 1, argc > 9 ? atoi(argv[9]) : 20);
   return 2;
 }
