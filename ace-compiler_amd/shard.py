@@ -176,7 +176,23 @@ class RankRunner:
         self.t_last = torch.zeros((2, N), dtype=torch.int64, device=dev)
 
     def _stream(self):
-        return self.torch.cuda.current_stream().cuda_stream if self.comm.device != "cpu" else None
+        """The stream launches and collectives share.  It must be an EXPLICIT stream: libacehip is built with
+        -fgpu-default-stream=per-thread, so handle 0 would mean "the calling thread's own stream" inside the library while torch
+        (and RCCL) mean the legacy stream by it -- two different queues ordered only by implicit legacy-stream synchronisation.
+        The runner therefore works under a stream of its own (see run()) and refuses a null handle."""
+        if self.comm.device == "cpu":
+            return None
+        h = self.torch.cuda.current_stream().cuda_stream
+        if h == 0:
+            raise RuntimeError("RankRunner needs an explicit torch.cuda.Stream (use `with runner.stream():`): the default stream "
+                               "is not the stream the library launches on")
+        return h
+
+    def stream(self):
+        """context manager: the runner's own stream becomes torch's current stream (collectives and C-ABI launches go there)"""
+        if getattr(self, "_own_stream", None) is None:
+            self._own_stream = self.torch.cuda.Stream()
+        return self.torch.cuda.stream(self._own_stream)
 
     def key_switch(self, x_own_ptr, key_own_ptr, out0_ptr, out1_ptr, level):
         rt, lib, st = self.rt, self.rt.lib, self._stream()

@@ -129,11 +129,18 @@ d_key, d_x, d_y = rt.to_device(key), rt.to_device(x), rt.to_device(y)
 o0, o1 = rt.buf(level * N), rt.buf(level * N)
 comm = shard.TorchComm(dist, torch.device("cuda", 0))
 rr = shard.RankRunner(rt, comm, 0)
-keep = rr.key_switch(d_x.ptr, d_key.ptr, o0.ptr, o1.ptr, level)
-torch.cuda.synchronize()
-assert np.array_equal(o0.download((level, N)), e0) and np.array_equal(o1.download((level, N)), e1)
-rr.rescale(d_x.ptr, d_y.ptr, o0.ptr, o1.ptr, level)
-torch.cuda.synchronize()
+try:
+    rr.key_switch(d_x.ptr, d_key.ptr, o0.ptr, o1.ptr, level)   # on torch's default stream: refused (not the library's stream)
+    raise SystemExit("the default stream was accepted")
+except RuntimeError:
+    pass
+torch.cuda.synchronize()   # the uploads above went through the library's own stream
+with rr.stream():
+    keep = rr.key_switch(d_x.ptr, d_key.ptr, o0.ptr, o1.ptr, level)
+    torch.cuda.synchronize()
+    assert np.array_equal(o0.download((level, N)), e0) and np.array_equal(o1.download((level, N)), e1)
+    rr.rescale(d_x.ptr, d_y.ptr, o0.ptr, o1.ptr, level)
+    torch.cuda.synchronize()
 assert np.array_equal(o0.download((level, N))[:level - 1], o.rescale(x, level))
 assert np.array_equal(o1.download((level, N))[:level - 1], o.rescale(y, level))
 rr.close()

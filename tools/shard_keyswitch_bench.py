@@ -62,14 +62,15 @@ def main(argv=None):
         if len(keep) > 4:
             keep.pop(0)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    with rr.stream():  # launches and collectives on one explicit stream (not the default one: see RankRunner._stream)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms = float(el.item()) / args.steps * 1e3
