@@ -35,7 +35,8 @@ struct Tw {
 
 #ifndef NTT_EXP
 #define NTT_EXP 0  // timing experiments only (results are wrong): 1 no butterflies, 2 no data loads/stores, 4 no twiddle loads,
-                   // 8 no strided pass at all (what a one-pass transform would save)
+                   // 8 no strided pass at all (what a one-pass transform would save), 16 the forward contiguous pass does not load its
+                   // input (what reading the first pass' output out of the XCD's L2 could save at most)
 #endif
 // SMALL: the companion is used as floor(w*2^63/q) = floor(w*2^64/q) >> 1 (see shoup5_add)
 template <bool SMALL>
@@ -593,7 +594,7 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
 #pragma unroll
-#if NTT_EXP & 2
+#if NTT_EXP & (2 | 16)
   for (int k = 0; k < 16; ++k) x[k] = (u64)(b * 256 + 16 * k + lo4) * 0x9E3779B97F4A7C15ull + o;
 #else
   for (int k = 0; k < 16; ++k) x[k] = ntld(&X[b * 256 + 16 * k + lo4]);

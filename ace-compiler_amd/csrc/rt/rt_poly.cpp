@@ -138,7 +138,7 @@ void arena_create() {
   size_t mb = 0;
   if (const char* e = getenv("ACEHIP_ARENA_MB")) mb = strtoull(e, nullptr, 10);
   if (mb == 0) {  // enough for one image stream of the generated ResNets at N = 2^16 (profile line "pool arena"), scaled down with N
-    mb = (size_t)8192 * c.N / 65536;
+    mb = (size_t)4096 * c.N / 65536;  // live peak of a ResNet-20 / -110 image: 1.1 GB
     if (mb < 64) mb = 64;
   }
   const size_t N = c.N, guard = (size_t)(c.L + c.K) * N, ws_words = acehip_workspace_words(c.hip);
