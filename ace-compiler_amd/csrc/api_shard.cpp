@@ -445,6 +445,7 @@ int acehip_shard_encode_limbs(acehip_shard* sh, uint64_t* d_q_own, const int64_t
 // on the launch stream.  RCCL is loaded with dlopen when first needed: unsharded programs never map it.
 // ------------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <cstdlib>
 
 struct Id128 {  // ncclUniqueId (rccl.h): passed by value to ncclCommInitRank
   char b[128];
@@ -464,9 +465,16 @@ RcclApi* rccl_api() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.lib) break;
+    // ACEHIP_RCCL_LIB: another library with RCCL's entry points (tests/c/mock_rccl.c lets the processes of a one-GPU test box act as
+    // ranks); when set it is the only candidate, so a typo cannot silently fall back to the real library
+    const char* forced = getenv("ACEHIP_RCCL_LIB");
+    if (forced != nullptr && *forced) {
+      api.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+      }
     }
     if (!api.lib) return;
     auto sym = [&](const char* n) { return dlsym(api.lib, n); };

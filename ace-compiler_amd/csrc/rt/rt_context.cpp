@@ -7,6 +7,9 @@
 
 #include "rt_internal.hpp"
 
+#include <sys/stat.h>
+#include <ctime>
+
 // Programs generated for the CKKS-level provider interface (rt_seal examples) do not define this callback: it is an
 // optional (weak) reference here, a missing definition means "no weight data file".
 extern "C" RT_DATA_INFO* Get_rt_data_info() __attribute__((weak));
@@ -180,6 +183,7 @@ void shard_connect_if_asked() {
   else path = std::string("/tmp/acehip_rccl_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
   unsigned char id[128];
   if (rank == 0) {
+    remove(path.c_str());  // (left behind by a run that died between publishing and joining)
     const int n = acehip_rccl_unique_id(id, sizeof id);
     RT_ASSERT(n == 128, "acehip_rccl_unique_id: %s", acehip_last_error());
     const std::string tmp = path + ".tmp";
@@ -190,9 +194,10 @@ void shard_connect_if_asked() {
   } else {
     size_t got = 0;
     for (int tries = 0; tries < 6000 && got != 128; ++tries) {  // up to a minute
+      struct stat st;
       FILE* f = fopen(path.c_str(), "rb");
-      if (f) {
-        got = fread(id, 1, 128, f);
+      if (f) {  // an id older than a few minutes belongs to an earlier run that never removed it: keep waiting for this run's
+        if (fstat(fileno(f), &st) == 0 && time(nullptr) - st.st_mtime < 300) got = fread(id, 1, 128, f);
         fclose(f);
       }
       if (got != 128) {

@@ -92,6 +92,76 @@ def test_resnet110_sharded_is_bit_identical(tmp_path):
         assert "limb-sharded world %d (simulated)" % world in out
 
 
+def _mock_rccl(tmp):
+    """tests/c/mock_rccl.c: RCCL's entry points on shared memory, so that the processes of a one-GPU box can be ranks"""
+    so = os.path.join(str(tmp), "libmock_rccl.so")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c", "mock_rccl.c"),
+                           "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", so])
+    return so
+
+
+def _run_ranks(exe, args, world, env_extra, tmp, tag, timeout=1500):
+    """the program once per rank, concurrently, as a launcher would start it (ACEHIP_SHARD=1 + RANK / WORLD_SIZE / LOCAL_RANK);
+    every process uses GPU 0 and exchanges limbs through the library named by ACEHIP_RCCL_LIB"""
+    port = str(29600 + os.getpid() % 300)
+    id_file = os.path.join(str(tmp), tag + ".rccl_id")
+    procs = []
+    for r in range(world):
+        prefix = os.path.join(str(tmp), "%s_r%d" % (tag, r))
+        env = dict(os.environ, ACEHIP_SEED="20261004", ACEHIP_DUMP_OUTPUT=prefix, ACEHIP_SHARD="1", RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_RANK="0", MASTER_PORT=port, ACEHIP_SHARD_ID_FILE=id_file, ACEHIP_PROFILE="1", **env_extra)
+        procs.append((prefix, subprocess.Popen([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
+    outs = []
+    for prefix, p in procs:
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for _, q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, so[-3000:] + se[-3000:]
+        tagr = os.path.basename(prefix)
+        dumps = sorted(glob.glob(prefix + ".*"))
+        assert dumps, "rank wrote no output ciphertext"
+        outs.append((so, {os.path.basename(d)[len(tagr) + 1:]: open(d, "rb").read() for d in dumps}))
+    return outs
+
+
+@pytest.mark.parametrize("name,world", [("rotate", 2), ("relin", 3), ("bootstrap", 2), ("bootstrap_02", 3)])
+def test_reference_example_sharded_over_processes_is_bit_identical(name, world, tmp_path):
+    """The multi-process form (one rank per process, what `torchrun` starts per GPU): ACEHIP_SHARD=1, rank 0 publishes the
+    communicator id, every rank joins and the exchanges of Decomp_modup / Mod_down / Rescale / ModRaise / decode go through the
+    RCCL entry points (ncclGroupStart, ncclBroadcast from the owner, ncclGroupEnd on the exchange stream).  A test box has one
+    GPU and RCCL refuses two ranks on one device, so the entry points are served by tests/c/mock_rccl.c (shared memory; ranks
+    must issue identical sequences or the run fails).  Every rank's output ciphertext equals the unsharded run's, byte for byte."""
+    exe = os.path.join(EX_DIR, "eg_" + name)
+    _need(exe)
+    mock = _mock_rccl(tmp_path)
+    out0, plain = _run(exe, [], {}, tmp_path, "plain")
+    ranks = _run_ranks(exe, [], world, {"ACEHIP_RCCL_LIB": mock}, tmp_path, "mp%d" % world)
+    for r, (out, dumps) in enumerate(ranks):
+        assert "SUCESS!" in out, out[-2000:]
+        assert dumps.keys() == plain.keys()
+        for k in plain:
+            assert dumps[k] == plain[k], "rank %d of %d: output ciphertext %s differs from the unsharded run" % (r, world, k)
+        assert "limb-sharded world %d" % world in out and "(simulated)" not in out
+        line = [ln for ln in out.splitlines() if "limb exchanges:" in ln]
+        assert line and int(line[0].split("limb exchanges:")[1].split()[0]) > 0, out[-2000:]
+
+
+def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
+    """One image of the ACE-generated ResNet-20 with its limbs spread over two PROCESSES (see above for the exchange library):
+    both ranks' output ciphertexts equal the unsharded run's."""
+    exe = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+    _need(exe)
+    mock = _mock_rccl(tmp_path)
+    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
+    _, plain = _run(exe, ["1"], env, tmp_path, "plain", timeout=1200)
+    ranks = _run_ranks(exe, ["1"], 2, dict(env, ACEHIP_RCCL_LIB=mock), tmp_path, "mp2")
+    for r, (out, dumps) in enumerate(ranks):
+        assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 output differs from the unsharded run" % r
+
+
 def test_bench_shard_mode_one_rank_joins_rccl():
     """`bench.py --mode shard` (what torchrun starts once per GPU for BASELINE configs[4]) with a single rank: the rt_ant shim
     loads librccl, creates and joins its own communicator (ACEHIP_SHARD=1: id file, ncclCommInitRank), runs the generated
