@@ -397,6 +397,71 @@ def shard_model_bench(args):
     ranks.close()
 
 
+def limb_sharded_leg(ranks, timeout_s=420):
+    """Secondary measurement of a multi-GPU run (N > 1), NOT the headline: after the replica measurement the same ranks run ONE
+    ResNet-20 image with its RNS limbs spread over them (BASELINE configs[4]'s execution mode on the headline's network) --
+    `bench.py --mode shard` as a child process per rank with its own rendezvous port and RCCL id file, so that a failure or a
+    hang of this leg (bounded by a timeout) cannot take the headline line with it.  Reports images/s of the sharded job, the bytes
+    every rank received over xGMI, and whether all ranks ended with the same output ciphertext (SHA-256 of the ACEHCT01 dumps)."""
+    import glob
+    import hashlib
+    import subprocess
+    import tempfile
+
+    rank, world = ranks.rank, ranks.world
+    nonce = int(ranks.max_over_ranks(float(int.from_bytes(os.urandom(3), "little")) if rank == 0 else 0.0))
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + nonce % 200
+    if port > 65000:
+        port -= 2000
+    prefix = os.path.join(tempfile.gettempdir(), "acehip_shardleg_%d_r%d" % (nonce, rank))
+    # (the launcher's agent store lives on the launcher's port: the children make their own rendezvous, rank 0 hosting it)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and not k.startswith("ACEHIP_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ACEHIP_SEED="1", ACEHIP_DUMP_OUTPUT=prefix,
+               ACEHIP_SHARD_ID_FILE=os.path.join(tempfile.gettempdir(), "acehip_rccl_%d_%d.id" % (port, nonce)))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--mode", "shard", "--workload", "resnet20", "--batch", "1",
+           "--steps", "1", "--warmup", "1"]
+    res, ok = None, 0.0
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode == 0:
+            ok = 1.0
+            if rank == 0:
+                res = json.loads(r.stdout.strip().splitlines()[-1])
+        elif rank == 0:
+            res = {"error": "rank 0 exited with %d: %s" % (r.returncode, r.stderr[-400:])}
+    except subprocess.TimeoutExpired:
+        if rank == 0:
+            res = {"error": "timed out after %d s" % timeout_s}
+    except Exception as e:  # noqa: BLE001 -- a secondary measurement never fails the run
+        if rank == 0:
+            res = {"error": repr(e)}
+    wall = time.perf_counter() - t0
+    digest = 0.0
+    dumps = sorted(glob.glob(prefix + ".*"))
+    if ok and dumps:
+        hsh = hashlib.sha256()
+        for d in dumps:
+            hsh.update(open(d, "rb").read())
+        digest = float(int.from_bytes(hsh.digest()[:6], "little"))  # 48 bits: exact in a float64
+    for d in dumps:
+        os.remove(d)
+    all_ok = -ranks.max_over_ranks(-ok)
+    hi, lo = ranks.max_over_ranks(digest), -ranks.max_over_ranks(-digest)
+    if rank != 0:
+        return None
+    out = {"what": "ONE ResNet-20 image, RNS limbs spread over the %d ranks (limb gi on rank gi %% %d), every rank running the unchanged "
+                   "generated program; child processes of this run, RCCL broadcasts from the owning rank (DESIGN 6)" % (world, world),
+           "ranks_succeeded": bool(all_ok), "leg_wall_s": round(wall, 1)}
+    if isinstance(res, dict) and "error" in res:
+        out["error"] = res["error"]
+    elif isinstance(res, dict):
+        out.update({"images_per_s": res["value"], "ms_per_image": res["ms_per_step"], "scaling": "strong", "shard": res.get("shard"),
+                    "last_logits": res.get("config", {}).get("last_logits"),
+                    "output_ciphertexts_identical_on_all_ranks": bool(all_ok and digest != 0.0 and hi == lo)})
+    return out
+
+
 def main():
     global MODEL_LIB
     ap = argparse.ArgumentParser()
@@ -418,6 +483,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
+    ap.add_argument("--no-shard-leg", action="store_true",
+                    help="with --gpus N > 1: skip the secondary limb-sharded ResNet-20 image the ranks run after the headline")
     ap.add_argument("--batch", type=int, default=8,
                     help="images per launch on every stream (Acehip_rt_set_batch): the images of a batch share launches, keys, "
                          "twiddles, bootstrap tables and encoded weight plaintexts; a step = one batch per stream")
@@ -639,6 +706,10 @@ def main():
         for t in threads:
             t.join()
         fhe.Finalize_context()
+    shard_leg = None
+    force_leg = os.environ.get("ACEHIP_BENCH_FORCE_SHARD_LEG") == "1"  # test hook: exercise the leg's plumbing with one rank
+    if (world > 1 or force_leg) and use_model and not r110 and not args.no_shard_leg:
+        shard_leg = limb_sharded_leg(ranks)  # (after the timed region; the model context above has released its memory)
 
     # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
     n_polys = 2 * N_CT
@@ -749,6 +820,8 @@ def main():
                 "GBs_algorithmic": (round(n_lt * 16 * N / ntt_kernel_s / 1e9, 1) if (ntt_kernel_s and n_lt) else None)}
         if cache_run is not None:
             out["with_plaintext_cache"] = cache_run
+        if shard_leg is not None:
+            out["limb_sharded"] = shard_leg
         if logits is not None:
             out["config"]["last_logits"] = [round(v, 5) for v in logits]
         if args.roofline_only:

@@ -296,3 +296,38 @@ def test_sharded_mode_exchange_schedule_two_ranks_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 schedule ok" in r.stdout and "rank 1 schedule ok" in r.stdout
+
+
+LEG_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import ace_compiler_amd
+    from ace_compiler_amd.dist import Ranks
+    import bench
+    r = Ranks(backend="gloo")
+    out = bench.limb_sharded_leg(r, timeout_s=240)     # no GPU here: every child fails; the leg must report that, not raise or hang
+    if r.rank == 0:
+        assert out is not None and out["ranks_succeeded"] is False and "error" in out, out
+    else:
+        assert out is None
+    r.barrier()
+    r.close()
+    os.write(1, ("rank " + str(r.rank) + " leg ok" + chr(10)).encode())
+""")
+
+
+def test_limb_sharded_leg_of_the_bench_survives_failing_children_two_ranks_gloo(tmp_path):
+    """bench.py's secondary limb-sharded leg (multi-GPU runs) starts one child per rank and then agrees on the outcome with three
+    reductions: with children that cannot run (no GPU in this container) both ranks must still pass the same collectives and rank 0
+    must get an object that says so -- the headline line of a node run never depends on this leg."""
+    script = tmp_path / "leg_worker.py"
+    script.write_text(LEG_WORKER % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 leg ok" in r.stdout and "rank 1 leg ok" in r.stdout

@@ -182,6 +182,28 @@ def test_bench_shard_mode_one_rank_joins_rccl():
     assert d["shard"]["rccl_ranks"] == 1 and d["shard"]["owned_limbs_per_rank"] == [45] and d["shard"]["bytes_received_per_image_all_ranks"] == 0
 
 
+def test_bench_multi_gpu_line_carries_a_limb_sharded_leg():
+    """`bench.py --gpus N` (N > 1, the driver's scaling run) adds a `limb_sharded` object: the ranks run one ResNet-20 image
+    limb-sharded as child processes after the headline.  One GPU here, so the leg is forced with a single rank
+    (ACEHIP_BENCH_FORCE_SHARD_LEG=1): child start, environment, JSON hand-over, output digest and clean-up are the same code."""
+    import json
+    import sys
+
+    lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet20.so")
+    if not os.path.exists(lib):
+        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["ACEHIP_BENCH_FORCE_SHARD_LEG"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--streams", "1", "--batch", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    leg = d["limb_sharded"]
+    assert "error" not in leg, leg
+    assert leg["ranks_succeeded"] and leg["output_ciphertexts_identical_on_all_ranks"] and leg["images_per_s"] > 0
+    assert leg["shard"]["rccl_ranks"] == 1 and len(leg["last_logits"]) == 10
+
+
 @pytest.mark.parametrize("name", ["rotate", "relin", "conv2d", "relu", "bootstrap"])
 def test_examples_under_poison_are_bit_identical(name, tmp_path):
     """ACEHIP_POISON=1 (csrc/rt/rt_poly.cpp): every limb whose zero fill is deferred and every block that returns to the pool is
