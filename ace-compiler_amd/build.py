@@ -27,6 +27,9 @@ LIB = os.path.join(LIBDIR, "libacehip.so")
 SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "rt_kernels.hip", "embed.hip", "hw_batch.hip", "shard.hip", "api_core.cpp", "api_hw_batch.cpp", "api_ops.cpp", "api_shard.cpp", "host_params.cpp"]
 HEADERS = ["kernels.hpp", "api_internal.hpp", "device_arith.hpp", "host_params.hpp", "rou_table.inc", os.path.join("..", "..", "include", "acehip.h")]
 ROCM_LIB = "/opt/rocm/lib"
+# keyswitch.hip: the matrix-core base conversion reads its MFMA results with VALU instructions right away; with the results in
+# VGPRs (instead of the accumulator half of the register file) that needs no v_accvgpr_read per value
+PER_FILE_FLAGS = {"keyswitch.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def hipcc():
@@ -62,7 +65,7 @@ def _hip_objects(force, verbose):
         s, o = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".", "_") + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc()] + flags + ["-c", s, "-o", o])
+            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(lambda c: _run(c, verbose), jobs))

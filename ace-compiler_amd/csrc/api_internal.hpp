@@ -59,6 +59,8 @@ struct KsPlan {
   // N = 2^16: the pre-factors of both base conversions ride in the last stage of the inverse NTT (NttFuse::inv_scale)
   u64* inv_up = nullptr;    // [level][4]
   u64* inv_down = nullptr;  // [K][4]
+  // k-steps of the matrix-core conversion (ConvDesc::bfrag) prepared for the ModUp / the ModDown problems; 0: not prepared
+  u32 mfma_up = 0, mfma_down = 0;
 };
 
 struct acehip_ctx {

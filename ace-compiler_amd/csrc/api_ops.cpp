@@ -208,7 +208,7 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
   // (descriptor nd + 1: the ModDown problem with its K sources at limb positions 0.. of `pc`)
   const bool conv_in_ntt = conv_fusable(c, hp.K);
   for (const DevCtx& dc : dcs) {
-    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, QL, pc, PK, plan->d_descs + plan->nd + 1, 0, np, level, s, hp.K);
+    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, QL, pc, PK, plan->d_descs + plan->nd + 1, 0, np, level, s, hp.K, PtrTab8{}, plan->mfma_down);
     if (dc.logN == 16) {
       NttFuse fo;
       if (conv_in_ntt) {  // the conversion P -> Q rides in the first pass of the NTT
@@ -438,6 +438,33 @@ int acehip_rescale2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_
 }
 
 }  // extern "C"
+// B fragments and accumulator offsets of the matrix-core base conversion (keyswitch.hip base_conv_mfma_kernel) for one problem:
+// hat(i, j) = constant of source i and output j, t(j) = output prime.  Layout [tile][step][digit][lane][16 bytes]; byte e of
+// lane (r = lane & 15, g = lane >> 4) belongs to source limb i = 8*step + 2g + (e >> 3), byte a = e & 7 of its residue, and to
+// output j = 16*tile + r: digit b of  hat(i, j) * 2^(8a) mod t(j).
+template <class Hat, class Prime>
+static void conv_mfma_tables(u32 n_in, u32 n_out, u32 steps, Hat hat, Prime t, std::vector<uint8_t>& frag, std::vector<u32>& off) {
+  const u32 tiles = (n_out + 15) / 16, NB = kConvMfmaDigits;
+  frag.assign((size_t)tiles * steps * NB * 64 * 16, 0);
+  off.assign((size_t)tiles * 16 * NB, 0);
+  for (u32 j = 0; j < n_out; ++j) {
+    const u64 tj = t(j);
+    const u32 tile = j / 16, r = j % 16;
+    for (u32 i = 0; i < n_in; ++i) {
+      u64 gv = hat(i, j) % tj;
+      for (u32 a = 0; a < 8; ++a) {
+        const u32 step = i / 8, g = (i % 8) / 2, e = (i % 2) * 8 + a, lane = g * 16 + r;
+        for (u32 b = 0; b < NB; ++b) {
+          const u32 dig = (u32)(gv >> (7 * b)) & 127u;
+          frag[((((size_t)tile * steps + step) * NB + b) * 64 + lane) * 16 + e] = (uint8_t)dig;
+          off[(size_t)j * NB + b] += 128u * dig;
+        }
+        gv = (u64)(((unsigned __int128)gv << 8) % tj);
+      }
+    }
+  }
+}
+
 const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -448,6 +475,16 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   KsPlan plan;
   plan.nd = hp.num_decomp(level);
   const bool fold = c->dc.logN == 16;
+  // matrix-core base conversion (keyswitch.hip base_conv_mfma_kernel): whole workgroups of 1024 coefficients, digits / K of at
+  // most 16 limbs, primes between 2^32 and 2^63 (nine 7-bit digits; keyswitch.hip reduce80).  ACEHIP_CONV_MFMA=0 keeps the multiply-add kernels (measurement).
+  static const bool mfma_on = [] { const char* e = getenv("ACEHIP_CONV_MFMA"); return !e || atoi(e) != 0; }();
+  const u32 steps_up = (hp.alpha + 7) / 8, steps_down = (hp.K + 7) / 8;
+  bool mfma = mfma_on && c->on_device && hp.N % 1024 == 0 && hp.alpha <= 16 && hp.K <= 16;
+  for (u32 i = 0; i < hp.L + hp.K && mfma; ++i) mfma = (hp.primes[i].q >> 63) == 0 && (hp.primes[i].q >> 32) != 0;  // (reduce80)
+  if (mfma) {
+    plan.mfma_up = steps_up;
+    plan.mfma_down = steps_down;
+  }
   std::vector<u64> inv_up(4 * (size_t)level, 0), inv_down(4 * (size_t)hp.K, 0);
   std::vector<ConvDesc> descs;
   for (u32 d = 0; d < plan.nd; ++d) {
@@ -477,6 +514,17 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
     cd.n_out = t->nc;
     cd.hat_ld = t->nc;
     plan.max_nc = std::max(plan.max_nc, t->nc);
+    if (mfma) {
+      HostParams::ModUp hm = hp.modup(level, d);
+      std::vector<uint8_t> frag;
+      std::vector<u32> off;
+      conv_mfma_tables(hm.n2, hm.nc, steps_up, [&](u32 i, u32 j) { return hm.hat_mod[(size_t)i * hm.nc + j]; },
+                       [&](u32 j) { return hp.primes[hm.compl_idx[j]].q; }, frag, off);
+      std::lock_guard<std::mutex> lk(c->mu);
+      cd.bfrag = c->up(frag);
+      cd.boff = c->up(off);
+      if (!cd.bfrag || !cd.boff) return nullptr;
+    }
     descs.push_back(cd);
   }
   ConvDesc md{};  // ModDown: K p-limbs at positions level.. -> level q-limbs (polynomial.c:755-807)
@@ -499,6 +547,16 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   md.n_in = hp.K;
   md.n_out = level;
   md.hat_ld = hp.L;
+  if (mfma) {
+    std::vector<uint8_t> frag;
+    std::vector<u32> off;
+    conv_mfma_tables(hp.K, level, steps_down, [&](u32 i, u32 j) { return hp.phat_modq[(size_t)j * hp.K + i]; },
+                     [&](u32 j) { return hp.primes[j].q; }, frag, off);
+    std::lock_guard<std::mutex> lk(c->mu);
+    md.bfrag = c->up(frag);
+    md.boff = c->up(off);
+    if (!md.bfrag || !md.boff) return nullptr;
+  }
   descs.push_back(md);
   md.src_pos0 = 0;  // [nd + 1]: the same problem with the K sources at limb positions 0.. (Mod_down: the P-limbs sit in a scratch of their own)
   descs.push_back(md);
@@ -567,7 +625,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
       fc.conv_src_stride = 0;
       launch_ntt_fused(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
     } else {
-      launch_base_conv_batch(dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha);
+      launch_base_conv_batch(dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, PtrTab8{}, plan->mfma_up);
       launch_ntt(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
     }
     // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
@@ -589,7 +647,7 @@ int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint6
   }
   const bool conv_in_ntt = fused && conv_fusable(c, hp.K);
   for (const DevCtx& dc : dcs) {
-    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K);
+    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K, PtrTab8{}, plan->mfma_down);
     if (fused) {  // the ModDown tail rides in the last NTT pass, the conversion P -> Q in the first
       NttFuse fo;
       if (conv_in_ntt) {
@@ -872,7 +930,7 @@ static int modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t
       for (u32 d = 0; d < nd; ++d) fc.polyz[d] = outz.p[d];
       launch_ntt_fused(dc, outz.p[0], level, 0, n_ext_rows, false, s, 0, nd, 0, hp.alpha, fc);
     } else {
-      launch_base_conv_batch(dc, outz.p[0], 0, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, outz);
+      launch_base_conv_batch(dc, outz.p[0], 0, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, outz, plan->mfma_up);
       if (dc.logN == 16) {
         NttFuse fz;
         for (u32 d = 0; d < nd; ++d) fz.polyz[d] = outz.p[d];

@@ -143,7 +143,12 @@ struct ConvDesc {
   const u32* col;         // [n_out] column of `hat` for each output (nullptr: column j for output j)
   u32 src_pos0;           // first source limb position in the input polynomial
   u32 n_in, n_out, hat_ld;
+  // matrix-core form (keyswitch.hip base_conv_mfma_kernel; nullptr: not prepared): the constants as int8 B fragments
+  // [tile of 16 outputs][k-step][digit b < 9][lane] (16 bytes each) and, per output column, 9 accumulator offsets
+  const void* bfrag = nullptr;
+  const u32* boff = nullptr;  // [16 * tiles][9]
 };
+constexpr u32 kConvMfmaDigits = 9;  // 7-bit digits of a constant below 2^63
 
 enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 
@@ -225,7 +230,8 @@ struct PtrTab8 {  // up to 8 per-problem output polynomials as a kernel argument
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
                             const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s,
                             u32 max_n_in = 0,  // max_n_in: largest n_in of the problems when known (selects the <= 16 kernel)
-                            const PtrTab8& outz = PtrTab8{});
+                            const PtrTab8& outz = PtrTab8{},
+                            u32 mfma_steps = 0);  // 1 / 2: every problem carries B fragments of that many k-steps (ConvDesc::bfrag)
 // fused key inner product over all digits (generated code inc:7011-7036 for every part):
 //   acc{0,1}[pos] = sum_d key{0,1}[d][gi(pos)] * (pos in digit d ? in[pos] : ext[d][pos])
 struct LimbConsts;

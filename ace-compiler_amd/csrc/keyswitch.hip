@@ -143,11 +143,171 @@ __global__ __launch_bounds__(256, 4) void base_conv_batch16_kernel(DevCtx c, u64
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same conversion on the matrix cores.  out[j][n] = (sum_i y_i[n] * hat[i][j]) mod t_j is a matrix product
+// [coefficients x sources] * [sources x outputs] over the integers followed by one reduction per entry, and the multiply-adds
+// are the cost of the kernels above (4 v_mad_u64_u32 per term and output).  v_mfma_i32_16x16x64_i8 does 16 384 byte products per
+// instruction, so the product is taken apart into bytes:
+//   y_i = sum_a u_{i,a} 2^(8a)  (a < 8: the eight BYTES of the stored residue, no extraction needed),
+//   G_{(i,a),j} = hat[i][j] * 2^(8a) mod t_j = sum_b g_{(i,a),j,b} 2^(7b)  (b < 9 seven-bit digits, host, once per level),
+//   sum_i y_i hat[i][j]  ==  sum_b 2^(7b) C_b[n][j]   (mod t_j),      C_b[n][j] = sum_{k=(i,a)} u_k[n] * g_{k,j,b}:
+// nine int8 matrix products with K = 8 * n_in.  The instruction multiplies SIGNED bytes: the A operand is the residue's bytes
+// with the top bit flipped (u - 128, one XOR per register) and the accumulator starts at 128 * sum_k g_{k,j,b} (ConvDesc::boff),
+// so it ends at exactly C_b >= 0 (below 2^23 for n_in <= 16).  The digits are put together in 128 bits (below 2^79) and reduced
+// once, like the sums of the kernels above: the result is the canonical residue of an integer congruent to the reference's
+// sum (Reduce_rns_base polynomial.c:928-967), i.e. the same bits.
+// Layout: lane l = (r = l & 15, g = l >> 4).  A: row r = coefficient n0 + r, the 16 bytes of source limbs 8s + 2g, 8s + 2g + 1 of
+// k-step s.  B: column r = output 16*tile + r, the same 16 (limb, byte) pairs (element order inside a lane group is the same
+// for A and B whatever the hardware's k numbering, and a sum over k does not depend on it).  D: column r, rows 4g + reg.
+// One wave keeps the B fragments of its output tile in registers and walks 256 coefficients in blocks of 16.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// (v1:v0) mod q for v below 2^80 (v1 < 2^16) and a prime above 2^32, i.e. m = floor(2^128/q) >> 64 below 2^32: reduce128()'s
+// quotient (device_arith.hpp: three partial products, at most 4 below the true one) without the branches and the zero terms
+__device__ __forceinline__ u64 reduce80(u64 v0, u32 v1, u64 q, u64 ml, u32 m) {
+  const u64 A = (u64)v1 * m;                                      // v1 * mh (exact, < 2^48)
+  const u64 Bq = ((u64)v1 * (u32)(ml >> 32) + (((u64)v1 * (u32)ml) >> 32)) >> 32;  // hi64(v1 * ml)
+  const u64 t1 = (u64)(u32)v0 * m;
+  const u64 t2 = (u64)(u32)(v0 >> 32) * m + (t1 >> 32);           // hi64(v0 * mh) = t2 >> 32
+  const u64 qhat = A + Bq + (t2 >> 32);
+  u64 r = v0 - qhat * q;
+  const u64 q4 = 4 * q, q2 = 2 * q;
+  r = r >= q4 ? r - q4 : r;
+  r = r >= q2 ? r - q2 : r;
+  return r >= q ? r - q : r;
+}
+constexpr u32 kMfmaWaveCoeffs = 256, kMfmaWgCoeffs = 4 * kMfmaWaveCoeffs;
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void base_conv_mfma_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
+                                                             const u64* __restrict__ in, size_t in_stride,
+                                                             const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
+  constexpr int NB = (int)kConvMfmaDigits;
+  __shared__ v4i_t sB[STEPS * NB * 64];  // the B fragments of this workgroup's output tile (its four waves share them)
+  const RepZ rz = rep_of_z(c);  // blockIdx.z = problem + n_problems * replica
+  const ConvDesc d = descs[rz.z * desc_step];
+  const u32 tile = blockIdx.y;
+  if (tile * 16 >= d.n_out) return;  // uniform for the workgroup
+  {
+    const v4i_t* bf = reinterpret_cast<const v4i_t*>(d.bfrag) + (size_t)tile * (STEPS * NB * 64);
+    for (u32 t = threadIdx.x; t < STEPS * NB * 64; t += 256) sB[t] = bf[t];
+  }
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 r = lane & 15u, g = lane >> 4;
+  const u32 j = tile * 16 + r, jc = min(j, d.n_out - 1);  // this lane's output column (columns past n_out: zero constants, not stored)
+  const u32 gi_out = d.out_gi[jc];
+  const DevPrime& P = c.primes[gi_out];
+  const u64 q = P.q, ml = P.prec128_lo;
+  const u32 mh = (u32)P.prec128_hi;
+  const bool store = j < d.n_out && owns(c, gi_out);  // (limb-sharded: the other ranks' outputs are not stored)
+  // accumulator offsets of the column (128 * sum_k g_kb, see above), already weighted: the accumulators start at zero and the
+  // digit sums below start from these two constants, which makes them the non-negative C_b sums
+  u64 off_lo = 0, off_hi = 0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) off_lo += (u64)d.boff[(size_t)j * NB + b] << (7 * b);
+#pragma unroll
+  for (int b = 5; b < NB; ++b) off_hi += (u64)d.boff[(size_t)j * NB + b] << (7 * (b - 5));
+  // this lane's source limbs of every k-step (past n_in: any valid limb, its constants are zero)
+  u32 li[STEPS][2];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    li[s][0] = min((u32)(8 * s) + 2 * g, d.n_in - 1);
+    li[s][1] = min((u32)(8 * s) + 2 * g + 1, d.n_in - 1);
+  }
+  const u64* src = reb(c, in, rz.rep) + rz.z * in_stride + (size_t)d.src_pos0 * c.N;
+  u64* dst = reb(c, outz.p[0] ? outz.p[rz.z] : out + rz.z * out_stride, rz.rep) + (size_t)d.out_pos[jc] * c.N;
+  typedef const __attribute__((address_space(1))) u64* gcptr_t;
+  typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) u64x2_t* gptr2_t;
+  const gcptr_t gsrc = (gcptr_t)(uintptr_t)src;
+  const u32 n_base = (blockIdx.x * 4 + wave) * kMfmaWaveCoeffs;
+  int w0 = 1, w7 = 1 << 7, w14 = 1 << 14, w21 = 1 << 21, w28 = 1 << 28;
+  asm volatile("" : "+s"(w0), "+s"(w7), "+s"(w14), "+s"(w21), "+s"(w28));  // opaque: each digit term stays ONE v_mad_i64_i32
+  // loads of a block are only requested here; scaling and the sign flip happen when the block is consumed (finish_a), so that
+  // the next block's loads stay in flight while this block is multiplied and reduced
+  auto load_raw = [&](u32 n0, u64 (&raw)[STEPS][2]) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      // (global address space spelled out: as FLAT loads they would count on lgkmcnt too and every wait for an LDS fragment
+      // would wait for the prefetch of the next block)
+      raw[s][0] = gsrc[(size_t)li[s][0] * c.N + n0 + r];
+      raw[s][1] = gsrc[(size_t)li[s][1] * c.N + n0 + r];
+    }
+  };
+  auto finish_a = [&](const u64 (&raw)[STEPS][2], v4i_t (&a)[STEPS]) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      u64 v0 = raw[s][0], v1 = raw[s][1];
+      if (d.scale) {  // pre-factor applied on load where the inverse NTT did not fold it in (N != 2^16)
+        v0 = mul_shoup(v0, d.scale[li[s][0]], d.scale_prec[li[s][0]], c.primes[d.src_gi[li[s][0]]].q);
+        v1 = mul_shoup(v1, d.scale[li[s][1]], d.scale_prec[li[s][1]], c.primes[d.src_gi[li[s][1]]].q);
+      }
+      a[s] = v4i_t{(int)((u32)v0 ^ 0x80808080u), (int)((u32)(v0 >> 32) ^ 0x80808080u), (int)((u32)v1 ^ 0x80808080u),
+                   (int)((u32)(v1 >> 32) ^ 0x80808080u)};
+    }
+  };
+  __syncthreads();
+  constexpr u32 kBlocks = kMfmaWaveCoeffs / 16;
+  u64 raw[2][STEPS][2];  // two blocks ahead: block rb + 2 is requested while block rb is multiplied and reduced
+  load_raw(n_base, raw[0]);
+  load_raw(n_base + 16, raw[1]);
+#pragma unroll 2
+  for (u32 rb = 0; rb < kBlocks; ++rb) {
+    const u32 n0 = n_base + rb * 16;
+    v4i_t a[STEPS];
+    finish_a(raw[rb & 1], a);
+    if (rb + 2 < kBlocks) load_raw(n0 + 32, raw[rb & 1]);
+    v4i_t acc[NB];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      // the nine fragments of a step are requested together (one LDS latency per step, not one per multiply)
+      v4i_t Bs[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) Bs[b] = sB[(s * NB + b) * 64 + lane];
+      static_assert(NB == 9, "the operand list below names nine fragments");
+      asm volatile("s_waitcnt lgkmcnt(0)"  // (all nine live here: otherwise the scheduler requests them in pairs to save registers)
+                   : "+v"(Bs[0]), "+v"(Bs[1]), "+v"(Bs[2]), "+v"(Bs[3]), "+v"(Bs[4]), "+v"(Bs[5]), "+v"(Bs[6]), "+v"(Bs[7]), "+v"(Bs[8]));
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s], Bs[b], s == 0 ? v4i_t{0, 0, 0, 0} : acc[b], 0, 0, 0);
+    }
+    u64 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // coefficient n0 + 4g + t
+      int64_t lo = (int64_t)off_lo;
+      lo += (int64_t)acc[0][t] * w0;
+      lo += (int64_t)acc[1][t] * w7;
+      lo += (int64_t)acc[2][t] * w14;
+      lo += (int64_t)acc[3][t] * w21;
+      lo += (int64_t)acc[4][t] * w28;  // in [0, 2^52)
+      int64_t hs = (int64_t)off_hi;
+      hs += (int64_t)acc[5][t] * w0;
+      hs += (int64_t)acc[6][t] * w7;
+      hs += (int64_t)acc[7][t] * w14;
+      hs += (int64_t)acc[8][t] * w21;  // in [0, 2^45), weight 2^35
+      const u64 hi = (u64)hs;
+      const u64 v0 = (u64)lo + (hi << 35);
+      const u64 v1 = (hi >> 29) + (v0 < (u64)lo ? 1u : 0u);  // < 2^16
+      o[t] = reduce80(v0, (u32)v1, q, ml, mh);
+    }
+    if (store) {
+      *(gptr2_t)(uintptr_t)(dst + n0 + 4 * g) = u64x2_t{o[0], o[1]};
+      *(gptr2_t)(uintptr_t)(dst + n0 + 4 * g + 2) = u64x2_t{o[2], o[3]};
+    }
+  }
+}
+
 void launch_base_conv_batch(const DevCtx& c, u64* out, size_t out_stride, const u64* in, size_t in_stride,
                             const ConvDesc* descs, u32 desc_step, u32 n_problems, u32 max_n_out, hipStream_t s, u32 max_n_in,
-                            const PtrTab8& outz) {
+                            const PtrTab8& outz, u32 mfma_steps) {
   ACEHIP_ABLATE(ABL_CONV);
   if (n_problems == 0 || max_n_out == 0) return;
+  if (mfma_steps != 0 && c.N % kMfmaWgCoeffs == 0) {
+    dim3 grid(c.N / kMfmaWgCoeffs, (max_n_out + 15) / 16, n_problems * c.nrep), block(256);
+    if (mfma_steps == 1) hipLaunchKernelGGL((base_conv_mfma_kernel<1>), grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
+    else                 hipLaunchKernelGGL((base_conv_mfma_kernel<2>), grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
+    return;
+  }
   dim3 grid((c.N + 255) / 256, (max_n_out + kGroup - 1) / kGroup, n_problems * c.nrep), block(256);
   if (max_n_in != 0 && max_n_in <= 16 && c.split_bits <= 30)
     hipLaunchKernelGGL(base_conv_batch16_kernel, grid, block, 0, s, c, out, out_stride, in, in_stride, descs, desc_step, outz);
