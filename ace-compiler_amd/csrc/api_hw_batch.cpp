@@ -14,6 +14,7 @@ struct HwScratch {  // reused across calls: the shim flushes ~10k batches per Re
   std::vector<u32> parent, comp_of_node, ord, cnt, n_res, n_a, n_b, cur, last_pure;
   std::vector<u64> node_ptr;  // address of every node (limb)
   std::vector<char> written, dead, state, need, nostore;
+  std::vector<uint8_t> from_mem;
   std::vector<u32> pos;  // place of every live op in the emission order
   std::vector<acehip_hw_op> sops;  // the list with ops on known-zero operands simplified
   std::vector<char> zero;
@@ -90,7 +91,7 @@ static void plan_append(const HwBatchOp& o, u32 seg) {
 }
 // ACEHIP_HW_TRAFFIC=1: limb loads / stores the elementwise launches actually perform, per op kind (the kernel's forwarding
 // rules replayed on the host), printed at exit -- where the bytes of the generated per-limb code go
-static std::atomic<u64> g_hw_traffic[9][4];  // [kind][ops, limb loads, limb stores, segments started]
+static std::atomic<u64> g_hw_traffic[9][4];  // [kind][ops, limb loads, limb stores, loads of memory all replicas share]
 static bool hw_traffic_on() {
   static const bool on = [] {
     const bool v = getenv("ACEHIP_HW_TRAFFIC") != nullptr;
@@ -100,8 +101,8 @@ static bool hw_traffic_on() {
         u64 tl = 0, ts = 0;
         for (int k = 0; k < 9; ++k) {
           const u64 o = g_hw_traffic[k][0], l = g_hw_traffic[k][1], w = g_hw_traffic[k][2];
-          if (o) fprintf(stderr, "[hw traffic] %-7s ops %10llu  limb loads %10llu  limb stores %10llu\n", kn[k], (unsigned long long)o,
-                         (unsigned long long)l, (unsigned long long)w);
+          if (o) fprintf(stderr, "[hw traffic] %-7s ops %10llu  limb loads %10llu (shared by the replicas: %llu)  limb stores %10llu\n", kn[k],
+                         (unsigned long long)o, (unsigned long long)l, (unsigned long long)g_hw_traffic[k][3], (unsigned long long)w);
           tl += l;
           ts += w;
         }
@@ -111,7 +112,8 @@ static bool hw_traffic_on() {
   }();
   return on;
 }
-static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg) {
+static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg, const DevCtx& dc) {
+  auto shared = [&](const void* p) { return !((u64)p - dc.rep_lo < dc.rep_span); };  // outside the replicated arena
   static std::atomic<u64> n_launch{0};
   static const u64 every = getenv("ACEHIP_HW_DUMP_EVERY") ? strtoull(getenv("ACEHIP_HW_DUMP_EVERY"), nullptr, 0) : 0;
   if (every && n_launch++ % every == 0) {  // a sample of launches, limbs numbered in order of appearance
@@ -168,27 +170,34 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg) {
     }
   }
   for (u32 sgm = 0; sgm < n_seg; ++sgm) {
-    const u64* prev = nullptr;
+    const u64 *r0 = nullptr, *r1 = nullptr;  // the kernel's two register entries
     const u32 beg = args.seg_start[sgm], end = args.seg_start[sgm + 1];
     for (u32 k = beg; k < end; ++k) {
       const HwBatchOp& o = args.op[k];
       const u32 kind = o.kind & HW_OP_KIND_MASK;
-      u64 loads = 0;
+      auto miss = [&](const u64* x) { return x != r0 && x != r1; };
+      u64 loads = 0, sh = 0;
       if (kind != HW_OP_ZERO) {
-        loads += o.a != prev;
-        if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) loads += o.b != prev;
-        if (kind == HW_OP_MULADD) loads += o.res != prev;
+        loads += miss(o.a);
+        sh += miss(o.a) && shared(o.a);
+        if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) {
+          loads += miss(o.b);
+          sh += miss(o.b) && shared(o.b);
+        }
+        if (kind == HW_OP_MULADD) loads += miss(o.res);
       }
+      g_hw_traffic[kind][3] += sh;
       const bool keep = (o.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == o.res);
       g_hw_traffic[kind][0] += 1;
       g_hw_traffic[kind][1] += loads;
       g_hw_traffic[kind][2] += !keep;
-      prev = o.res;
+      if (o.res != r0) r1 = r0;
+      r0 = o.res;
     }
   }
 }
 static void emit_ew(acehip_ctx* c, const HwBatchArgs& args, u32 n_seg, hipStream_t st) {
-  if (hw_traffic_on()) hw_traffic_count(args, n_seg);
+  if (hw_traffic_on()) hw_traffic_count(args, n_seg, *g_dc);
   if (!g_plan) {
     launch_hw_batch_ew(*g_dc, args, n_seg, st);
     return;
@@ -424,7 +433,9 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
       if (hw_has_a(op)) h.state[h.n_a[k]] = 1;
       if (hw_has_b(op)) h.state[h.n_b[k]] = 1;
       if (pure) {
-        if (h.last_pure[nr0] != k && h.state[nr0] && n_scratch < scratch_cap) {
+        // (the first version too, although nothing earlier in the list can collide with it: a private version is what the
+        // product + accumulate fusions below look for)
+        if (h.last_pure[nr0] != k && n_scratch < scratch_cap) {
           h.cur[nr0] = (u32)h.parent.size();
           h.parent.push_back(h.cur[nr0]);
           h.node_ptr.push_back(n_scratch++);  // index into the scratch arena, resolved below
@@ -516,6 +527,43 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
   for (size_t k = 0; k < m; ++k)
     if (!h.dead[k]) h.ord[h.cnt[h.comp_of_node[uf_find(h.parent, h.n_res[k])]]++] = (u32)k;
   // after the scatter cnt[j] = end offset of chain j
+  // The product + accumulate fusion again, this time on neighbours WITHIN a chain: generated code multiplies both polynomials of
+  // a ciphertext before it accumulates them (mul c0, mul c1, add c0, add c1 per limb: Mul_plain + Add_ciph of a convolution
+  // tap), so in list order a product is never next to its accumulation, but in its chain it is.  Between two neighbours of a
+  // chain no other op touches a limb the chain writes, and every limb written in the list belongs to the chain of its
+  // readers, so the product's operands are the same at the accumulation's place.  Runs of taps then keep the accumulator in
+  // registers (hw_batch_ew_kernel) instead of storing and reloading it per tap.
+  static const bool chain_fuse = [] { const char* e = getenv("ACEHIP_HW_CHAIN_FUSE"); return !e || atoi(e) != 0; }();  // (measurement knob)
+  if (n_nodes > n_base && chain_fuse) {
+    bool fused_any = false;
+    u32 ch = 0;
+    for (size_t t = 1; t < live; ++t) {
+      while (t >= h.cnt[ch]) ++ch;
+      const size_t beg = ch ? h.cnt[ch - 1] : 0;
+      if (t == beg) continue;  // first op of its chain
+      const u32 k = h.ord[t], p = h.ord[t - 1];
+      if (h.dead[p] || h.kind[k] != ACEHIP_HW_ADD || h.kind[p] != ACEHIP_HW_MUL) continue;
+      const u32 tv = h.n_res[p], acc = h.n_res[k];
+      if (tv < n_base || h.readers[tv] != 1 || ops[p].prime_gi != ops[k].prime_gi) continue;
+      const bool acc_a = h.n_a[k] == acc && h.n_b[k] == tv, acc_b = h.n_b[k] == acc && h.n_a[k] == tv;
+      if (!(acc_a || acc_b) || acc == tv) continue;
+      h.kind[k] = ACEHIP_HW_MULADD;
+      h.n_a[k] = h.n_a[p];
+      h.n_b[k] = h.n_b[p];
+      h.dead[p] = 1;
+      fused_any = true;
+    }
+    if (fused_any) {  // drop the absorbed products from the emission order
+      size_t w = 0, t = 0;
+      for (size_t j = 0; j < h.cnt.size(); ++j) {
+        for (; t < h.cnt[j]; ++t)
+          if (!h.dead[h.ord[t]]) h.ord[w++] = h.ord[t];
+        h.cnt[j] = (u32)w;
+      }
+      live = w;
+      h.ord.resize(live);
+    }
+  }
   // Which results have to reach memory: walking the list backwards, need[x] = the version of limb x that is current here is
   // loaded by a later op (an operand is taken from registers only when the op right before its reader, in the same
   // chain and launch, produced it: hw_batch_ew_kernel) or outlives the list.
@@ -528,23 +576,40 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
   }
   h.nostore.assign(m, 0);
   {
-    std::vector<u32>& chain_of = h.cur;  // reused: chain of every emission place
-    chain_of.resize(live);
-    u32 ch = 0;
-    for (size_t t = 0; t < live; ++t) {
-      while (t >= h.cnt[ch]) ++ch;
-      chain_of[t] = ch;
+    // Forwards: the kernel's register cache (hw_batch_ew_kernel: the two most recent results of a segment, keyed by limb; a
+    // result replaces its own limb's entry, otherwise the newer entry becomes the older one), replayed per segment -- a
+    // segment is a chain's run inside one launch -- to know which operand reads come from memory.  Entries are compared by
+    // address, as the kernel does.
+    std::vector<uint8_t>& from_mem = h.from_mem;  // per op: bit 0 operand a, bit 1 operand b, bit 2 the accumulator of a multiply-add
+    from_mem.assign(m, 0);
+    {
+      u32 ch = 0;
+      u64 r0 = 0, r1 = 0;
+      for (size_t t = 0; t < live; ++t) {
+        const u32 before = ch;
+        while (t >= h.cnt[ch]) ++ch;
+        if (t == 0 || ch != before || t % HW_BATCH_MAX == 0) r0 = r1 = 0;  // a new segment starts with empty registers
+        const u32 k = h.ord[t], kind = h.kind[k];
+        auto cached = [&](u32 node) { const u64 a = h.node_ptr[node]; return a == r0 || a == r1; };
+        uint8_t f = 0;
+        if (hw_has_a(kind) && !cached(h.n_a[k])) f |= 1;
+        if (hw_has_b(kind) && !cached(h.n_b[k])) f |= 2;
+        if (kind == ACEHIP_HW_MULADD && !cached(h.n_res[k])) f |= 4;
+        from_mem[k] = f;
+        const u64 res = h.node_ptr[h.n_res[k]];
+        if (res != r0) r1 = r0;
+        r0 = res;
+      }
     }
+    // Backwards: need[x] = the version of limb x that is current here is loaded from memory by a later op or outlives the list
     for (size_t k = m; k-- > 0;) {
       if (h.dead[k]) continue;
-      const u32 kind = h.kind[k], nr = h.n_res[k], t = h.pos[k];
+      const u32 kind = h.kind[k], nr = h.n_res[k];
       h.nostore[k] = !h.need[nr];
       h.need[nr] = 0;
-      const bool fwd = t > 0 && t % HW_BATCH_MAX != 0 && chain_of[t - 1] == chain_of[t];
-      const u32 prev_res = fwd ? h.n_res[h.ord[t - 1]] : UINT32_MAX;
-      if (hw_has_a(kind) && h.n_a[k] != prev_res) h.need[h.n_a[k]] = 1;
-      if (hw_has_b(kind) && h.n_b[k] != prev_res) h.need[h.n_b[k]] = 1;
-      if (kind == ACEHIP_HW_MULADD && nr != prev_res) h.need[nr] = 1;
+      if (hw_has_a(kind) && (h.from_mem[k] & 1)) h.need[h.n_a[k]] = 1;
+      if (hw_has_b(kind) && (h.from_mem[k] & 2)) h.need[h.n_b[k]] = 1;
+      if (kind == ACEHIP_HW_MULADD && (h.from_mem[k] & 4)) h.need[nr] = 1;
     }
   }
   HwBatchArgs args;

@@ -11,8 +11,8 @@
 namespace acehip {
 
 // Every lane owns ACEHIP_HW_LANES (2 or 4) consecutive coefficients of all limbs of its segment: read-after-write between ops of a chain goes
-// through the lane itself.  The previous result stays in registers: an operand that is the previous op's result
-// limb is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
+// through the lane itself.  The two most recent results stay in registers (see the kernel): an operand that is one of them
+// is not reloaded, and a result is not stored when the next op of the segment writes the same limb again
 // (accumulation runs res += a_j * b_j keep the accumulator in registers; the last op of a run stores, so every
 // later reader -- in this segment, another launch or the host -- finds the final value in memory), nor when the host
 // analysis found that only the next op of the segment reads it (HW_OP_NOSTORE: temporaries of blocks the caller has freed).
@@ -73,8 +73,14 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   if (i >= c.N) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
   const u32 rep = c.rep0 + blockIdx.z;  // replica of this workgroup: operands inside the replicated arena move with it
-  const u64* prev_res = nullptr;
-  V4 vprev{{0, 0}, {0, 0}};
+  // The two most recent results of the segment stay in registers, keyed by their limb (the list's own addresses): slot 0 the
+  // last result, slot 1 the last result of ANOTHER limb before it.  A chain that alternates between a temporary and an
+  // accumulator (t = x * c; acc = acc + t; ... -- polynomial evaluation, convolution taps) then reads neither from memory.
+  // A result replaces its own limb's entry; otherwise slot 0 moves to slot 1.  (The host analysis replays exactly this rule to
+  // decide which results have to reach memory: api_hw_batch.cpp RegCache.)
+  const u64 *r0 = nullptr, *r1 = nullptr;
+  V4 v0{{0, 0}, {0, 0}}, v1{{0, 0}, {0, 0}};
+  auto fetch = [&](const u64* list_addr, const u64* real_addr) { return list_addr == r0 ? v0 : (list_addr == r1 ? v1 : ld4(real_addr + i)); };
   for (u32 k = beg; k < end; ++k) {
     HwBatchOp op = args.op[k];
     const u32 kind = op.kind & HW_OP_KIND_MASK;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
     if (kind == HW_OP_ZERO) {
       vr = V4{{0, 0}, {0, 0}};
     } else {
-      const V4 va = a0 == prev_res ? vprev : ld4(op.a + i);
+      const V4 va = fetch(a0, op.a);
       if (kind == HW_OP_COPY) {
         vr = va;
       } else {
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
           const u64 imm = (u64)(uintptr_t)op.b;
           vb = V4{{imm, imm}, {imm, imm}};
         } else {
-          vb = b0 == prev_res ? vprev : ld4(op.b + i);
+          vb = fetch(b0, op.b);
         }
         switch (kind) {
           case HW_OP_ADD:
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
             vr = map2(va, vb, [q](u64 x, u64 y) { return sub_mod(x, y, q); });
             break;
           case HW_OP_MULADD: {
-            const V4 acc = res0 == prev_res ? vprev : ld4(op.res + i);
+            const V4 acc = fetch(res0, op.res);
             const V4 pr = map2(va, vb, [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
             vr = map2(acc, pr, [q](u64 x, u64 y) { return add_mod(x, y, q); });
             break;
@@ -122,8 +128,12 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
       }
     }
     if (!keep_in_regs) st4(op.res + i, vr);
-    prev_res = res0;
-    vprev = vr;
+    if (res0 != r0) {  // another limb than the last result's: that one becomes the older entry
+      r1 = r0;
+      v1 = v0;
+    }
+    r0 = res0;
+    v0 = vr;
   }
 }
 

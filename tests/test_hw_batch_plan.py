@@ -66,14 +66,18 @@ def _plan(rt, prog, dead=()):
 
 
 class _Lane:
-    """what one op of a segment sees: the result of the previous op of the segment comes from registers (as in
-    hw_batch_ew_kernel), everything else from memory; the op's own result is caught instead of stored"""
+    """what one op of a segment sees: the two most recent results of the segment come from registers (hw_batch_ew_kernel: keyed by
+    limb; a result replaces its own limb's entry, otherwise the newer entry becomes the older one), everything else from memory;
+    the op's own result is caught instead of stored"""
 
-    def __init__(self, mem, prev_res, vprev):
-        self.mem, self.prev_res, self.vprev, self.out = mem, prev_res, vprev, None
+    def __init__(self, mem, regs):
+        self.mem, self.regs, self.out = mem, regs, None
 
     def __getitem__(self, p):
-        return self.vprev if p == self.prev_res else self.mem[p]
+        for addr, val in self.regs:
+            if addr == p:
+                return val
+        return self.mem[p]
 
     def __setitem__(self, p, v):
         self.out = v
@@ -87,18 +91,21 @@ def _replay(plan, mem, primes, perms, rng):
         segs = list(by_launch[la].values())
         rng.shuffle(segs)                       # concurrent chains: any order must do
         for ops in segs:
-            prev_res, vprev = None, None
+            regs = []                           # [(limb, value)], most recent first, at most two
             for opf, gi, res, a, b in ops:
                 op = opf & 0xFF
                 for p in (res, a if op != B.HW_ZERO else None, b if op in (B.HW_ADD, B.HW_SUB, B.HW_MUL, B.HW_MULADD) else None):
                     if p is not None and p not in mem:
                         assert p >= SCRATCH, "plan names an address outside the caller's limbs and the scratch arena"
                         mem[p] = ["uninitialised"] * N   # reading it before a write would poison the result
-                lane = _Lane(mem, None if op == B.HW_ROTATE else prev_res, vprev)
+                lane = _Lane(mem, [] if op == B.HW_ROTATE else regs)
                 _exec(lane, primes, perms, op, gi, res, a, b)
                 # ACEHIP_HW_NOSTORE: the result exists in registers only; memory keeps something a later load must not use
                 mem[res] = ["not stored"] * N if opf & B.HW_NOSTORE else lane.out
-                prev_res, vprev = res, lane.out
+                if regs and regs[0][0] == res:
+                    regs = [(res, lane.out)] + regs[1:]
+                else:
+                    regs = [(res, lane.out)] + regs[:1]
 
 
 def _random_program(rt, rng, n_limbs, n_ops, with_rot):
@@ -170,14 +177,60 @@ def test_generated_key_inner_product_is_split_into_independent_chains(rt):
     assert len({(la, sg) for *_, la, sg in plan}) >= 2 * T - 1      # independent chains
     assert sum(1 for p in plan if p[2] >= SCRATCH) == 0             # no private version is ever written
     assert B.HW_ZERO not in kinds                                   # every fill met its first addend
-    # digit 0: 2T products, all but the very first (which stays in the caller's scratch limb: product + copy) written into
-    # their accumulator directly; digit 1: 2T multiply-adds but the very last (product in the scratch limb + add)
+    # digit 0: 2T products written into their accumulator directly; digit 1: 2T multiply-adds but the very last (product in the
+    # scratch limb + add)
     assert kinds.count(B.HW_MUL) == 2 * T + 1 and kinds.count(B.HW_MULADD) == 2 * T - 1
-    assert kinds.count(B.HW_COPY) == 1 and kinds.count(B.HW_ADD) == 1
-    # the first product is overwritten later and read by the op right behind it only: not stored; the last one is what
-    # the caller finds in its scratch limb afterwards
+    assert kinds.count(B.HW_COPY) == 0 and kinds.count(B.HW_ADD) == 1
+    # only the last product is what the caller finds in its scratch limb afterwards
     in_tmp = [p[0] for p in plan if p[2] == tmp]
-    assert sorted(in_tmp) == [B.HW_MUL, B.HW_MUL | B.HW_NOSTORE]
+    assert in_tmp == [B.HW_MUL]
+
+
+def test_convolution_taps_keep_the_accumulator_in_registers(rt):
+    """The tap loop of a generated convolution (resnet20_cifar10_pre.onnx.inc:1486-1502): per tap and limb  mul tmp.c0, mul tmp.c1,
+    add acc.c0, add acc.c1  -- both products BEFORE both accumulations, through one temporary ciphertext.  A product is never
+    next to its accumulation in list order, only in its chain: every tap but the last must still become a multiply-add on the
+    accumulator (no product stored, the accumulator neither stored nor reloaded between taps)."""
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    taps, n_limbs = 5, 3
+    # rows: 0/1 acc c0/c1, 2/3 tmp c0/c1, 4+2k / 5+2k the rotated input of tap k (c0 / c1), 20+k the plaintext of tap k
+    prog = []
+    for k in range(taps):
+        for g in range(n_limbs):
+            prog += [(B.HW_MUL, g, at(2, g), at(4 + 2 * k, g), at(20 + k, g)), (B.HW_MUL, g, at(3, g), at(5 + 2 * k, g), at(20 + k, g)),
+                     (B.HW_ADD, g, at(0, g), at(0, g), at(2, g)), (B.HW_ADD, g, at(1, g), at(1, g), at(3, g))]
+    plan = _check(rt, prog, 26 * T, 11)
+    kinds = [p[0] & 0xFF for p in plan]
+    chains = 2 * n_limbs
+    assert kinds.count(B.HW_MULADD) == chains * (taps - 1)           # every tap but the last, for both polynomials of every limb
+    assert kinds.count(B.HW_MUL) == chains and kinds.count(B.HW_ADD) == chains   # the last tap: its product stays visible in tmp
+    assert sum(1 for p in plan if p[2] >= SCRATCH) == 0              # no private version of tmp is ever written
+    for g in range(n_limbs):                                         # one store of each accumulator limb: the final one
+        for row in (0, 1):
+            stores = [p for p in plan if p[2] == at(row, g) and not (p[0] & B.HW_NOSTORE)]
+            assert len(stores) <= 2, stores  # (the multiply-add that hands over to the last tap's plain add, and that add)
+
+
+def test_scalar_term_sums_keep_the_accumulator_in_registers(rt):
+    """Sums of scalar multiples as the generated activation polynomials and the bootstrap spell them: per term  t = copy(x_k);
+    t = t * c_k; acc = acc + t  through one temporary.  The kernel keeps its two most recent results in registers (the temporary
+    and the accumulator alternate), so no term may store the temporary and the accumulator reaches memory once."""
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    terms = 7
+    prog = []
+    for g in range(2):
+        for k in range(terms):
+            prog += [(B.HW_COPY, g, at(1, g), at(4 + k, g), 0), (B.HW_MULC, g, at(1, g), at(1, g), 3 + k),
+                     (B.HW_ADD, g, at(0, g), at(0, g), at(1, g))]
+    plan = _check(rt, prog, 12 * T, 13)
+    for g in range(2):
+        acc_stores = [p for p in plan if p[2] == at(0, g) and not (p[0] & B.HW_NOSTORE)]
+        assert len(acc_stores) == 1, acc_stores
+        # the temporary is visible to the caller afterwards: its last version is stored, nothing else
+        tmp_stores = [p for p in plan if (p[2] == at(1, g) or p[2] >= SCRATCH) and not (p[0] & B.HW_NOSTORE)]
+        assert len(tmp_stores) <= 2, tmp_stores
 
 
 def test_dead_zero_fills_and_copies_are_dropped(rt):
