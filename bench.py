@@ -636,9 +636,9 @@ def main():
         if r110:
             metric = "encrypted images/sec (ResNet-110 CIFAR-10, N=2^16) -- secondary measurement, not the BASELINE headline"
             workload = ("the workload of BASELINE configs[4] (ACE-compiled ResNet-110/CIFAR-10, resnet110_cifar10_train.onnx.inc: N=2^16, "
-                        "36 464 weight plaintexts) run as REPLICAS: whole images per GPU, %d concurrent image streams per GPU x batches of " + str(n_batch) + " images; "
+                        "36 464 weight plaintexts) run as REPLICAS: whole images per GPU, %d concurrent image streams per GPU x batches of %d images; "
                         "synthetic image and weights (with N(0,0.05) weights a 110-layer network leaves the range of the bootstrap on "
-                        "both runtimes, so the logits are not meaningful: only the work is measured)" % n_streams)
+                        "both runtimes, so the logits are not meaningful: only the work is measured)" % (n_streams, n_batch))
     elif args.roofline_only:
         def step():
             return None

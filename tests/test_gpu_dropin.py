@@ -234,6 +234,22 @@ def test_resnet110_workload_runs_on_one_gpu():
     assert len(vals) == 10 and all(math.isfinite(v) for v in vals)
 
 
+def test_bench_resnet110_workload_line():
+    """`bench.py --workload resnet110` (the secondary measurement of the configs[4] network as replicas): one image on one stream
+    ends in a JSON line that names the workload."""
+    import json
+    import sys
+
+    lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet110.so")
+    if not os.path.exists(lib):
+        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "resnet110", "--no-cpu-baseline", "--streams", "1",
+                        "--batch", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["unit"] == "images/s" and d["value"] > 0 and "ResNet-110" in d["metric"] and "REPLICAS" in d["config"]["workload"]
+
+
 @pytest.mark.parametrize("name", ["add", "add_const", "mult_const", "conv2d_keep_shape"])
 def test_ckks_level_provider_programs(name):
     """SURVEY 8f-2, the provider-level (ciphertext-granular) API: the reference's programs generated for the CKKS-level provider
