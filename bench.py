@@ -485,7 +485,7 @@ def main():
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     ap.add_argument("--no-shard-leg", action="store_true",
                     help="with --gpus N > 1: skip the secondary limb-sharded ResNet-20 image the ranks run after the headline")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=12,
                     help="images per launch on every stream (Acehip_rt_set_batch): the images of a batch share launches, keys, "
                          "twiddles, bootstrap tables and encoded weight plaintexts; a step = one batch per stream")
     args = ap.parse_args()

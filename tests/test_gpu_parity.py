@@ -25,6 +25,12 @@ SETS = [  # N, L, q0, sf, dnum, levels
     (8192, 4, 60, 50, 2, [4, 3]),
     (16384, 4, 60, 50, 2, [4]),
     (64, 40, 60, 50, 2, [40, 25]),   # alpha = 20, K = 17: more source limbs than one register chunk of the base conversion
+    # the matrix-core base conversion (keyswitch.hip base_conv_mfma_kernel: N a multiple of 1024, primes above 2^32, digits and K of
+    # at most 16 limbs): two k-steps (alpha = 12, K = 13), output tiles of 16 with ragged ends, short last digits, one limb
+    (1024, 24, 60, 50, 2, [24, 17, 9, 1]),
+    (2048, 30, 60, 55, 3, [30, 23, 16, 10]),   # alpha = 10
+    (1024, 9, 60, 50, 3, [9, 8, 4]),          # one k-step (alpha = 3)
+    (1024, 5, 33, 30, 0, [5, 2]),            # primes below 2^32: not eligible, the multiply-add kernels at the same ring size
 ]
 
 
