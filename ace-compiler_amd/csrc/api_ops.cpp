@@ -476,11 +476,11 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
   plan.nd = hp.num_decomp(level);
   const bool fold = c->dc.logN == 16;
   // matrix-core base conversion (keyswitch.hip base_conv_mfma_kernel): whole workgroups of 1024 coefficients, digits / K of at
-  // most 16 limbs, primes between 2^32 and 2^63 (nine 7-bit digits; keyswitch.hip reduce80).  ACEHIP_CONV_MFMA=0 keeps the multiply-add kernels (measurement).
+  // most 16 limbs, primes between 2^32 and 2^61 (nine 7-bit digits; keyswitch.hip reduce80).  ACEHIP_CONV_MFMA=0 keeps the multiply-add kernels (measurement).
   static const bool mfma_on = [] { const char* e = getenv("ACEHIP_CONV_MFMA"); return !e || atoi(e) != 0; }();
   const u32 steps_up = (hp.alpha + 7) / 8, steps_down = (hp.K + 7) / 8;
   bool mfma = mfma_on && c->on_device && hp.N % 1024 == 0 && hp.alpha <= 16 && hp.K <= 16;
-  for (u32 i = 0; i < hp.L + hp.K && mfma; ++i) mfma = (hp.primes[i].q >> 63) == 0 && (hp.primes[i].q >> 32) != 0;  // (reduce80)
+  for (u32 i = 0; i < hp.L + hp.K && mfma; ++i) mfma = (hp.primes[i].q >> 61) == 0 && (hp.primes[i].q >> 32) != 0;  // (reduce80: 5q < 2^64, mh < 2^32)
   if (mfma) {
     plan.mfma_up = steps_up;
     plan.mfma_down = steps_down;
