@@ -123,6 +123,40 @@ def test_decomp_modup_moddown_rescale(pair):
             assert np.array_equal(rt.rescale(a, level), o.rescale(a, level)), level
 
 
+def test_base_conversion_extreme_values():
+    """ModUp / ModDown on inputs that drive every sum of the base conversion to its largest and smallest value: all residues
+    q_i - 1, all zero, and alternating -- the matrix-core form adds byte products of offset operands (keyswitch.hip
+    base_conv_mfma_kernel: accumulator offsets, 80-bit recombination), so its range argument is checked at the ends."""
+    N, L, q0, sf, dnum = 1024, 24, 60, 50, 2
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        for level in (24, 17, 5):
+            T = level + o.K
+            gis = [o.gidx(l, level) for l in range(T)]
+            top = np.stack([np.full(N, o.primes[g] - 1, dtype=np.uint64) for g in gis])
+            alt = top.copy()
+            alt[:, ::2] = 0
+            K, nd = o.K, o.num_decomp(level)
+            for name, x in (("max", top), ("zero", np.zeros_like(top)), ("alternating", alt)):
+                a = np.ascontiguousarray(x[:level])
+                # the batched forms are the ones that take the matrix-core kernel (all digits at once; both polynomials of a pair)
+                da, de = rt.to_device(a), rt.buf(nd * T * N)
+                rt.check(rt.lib.acehip_modup_digits(rt.h, de.ptr, da.ptr, level, None))
+                ext = de.download((nd, T, N))
+                for d in range(nd):
+                    assert np.array_equal(ext[d], o.decomp_modup(a, level, d)), (name, level, d)
+                d0, d1, r0, r1 = rt.to_device(x), rt.to_device(x[:, ::-1].copy()), rt.buf(level * N), rt.buf(level * N)
+                rt.check(rt.lib.acehip_mod_down2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+                assert np.array_equal(r0.download((level, N)), o.mod_down(x, level)), (name, level)
+                assert np.array_equal(r1.download((level, N)), o.mod_down(x[:, ::-1].copy(), level)), (name, level)
+                for b in (da, de, d0, d1, r0, r1):
+                    b.free()
+    finally:
+        rt.close()
+        o.close()
+
+
 def test_pair_forms_and_all_digit_modup(pair):
     """acehip_mod_down2 / acehip_rescale2 (c0 and c1 of a ciphertext in the same launches) and acehip_modup_digits
     (every digit at once) against the single-polynomial oracle results"""
