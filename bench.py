@@ -397,7 +397,7 @@ def shard_model_bench(args):
     ranks.close()
 
 
-def limb_sharded_leg(ranks, timeout_s=420):
+def limb_sharded_leg(ranks, timeout_s=240):
     """Secondary measurement of a multi-GPU run (N > 1), NOT the headline: after the replica measurement the same ranks run ONE
     ResNet-20 image with its RNS limbs spread over them (BASELINE configs[4]'s execution mode on the headline's network) --
     `bench.py --mode shard` as a child process per rank with its own rendezvous port and RCCL id file, so that a failure or a
