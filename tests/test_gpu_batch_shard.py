@@ -156,10 +156,15 @@ def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
     _need(exe)
     mock = _mock_rccl(tmp_path)
     env = {"ACEHIP_RT_DATA_SYNTH": "1"}
-    _, plain = _run(exe, ["1"], env, tmp_path, "plain", timeout=1200)
+    _, plain = _run(exe, ["2"], env, tmp_path, "plain", timeout=1200)
     ranks = _run_ranks(exe, ["1"], 2, dict(env, ACEHIP_RCCL_LIB=mock), tmp_path, "mp2")
     for r, (out, dumps) in enumerate(ranks):
         assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 output differs from the unsharded run" % r
+    # sharded AND batched: two images per launch on every rank (every exchange then moves both images' limbs)
+    ranks = _run_ranks(exe, ["2"], 2, dict(env, ACEHIP_RCCL_LIB=mock, MODEL_BATCH="2"), tmp_path, "mp2b2")
+    for r, (out, dumps) in enumerate(ranks):
+        for i in range(2):
+            assert dumps["0.%d" % i] == plain["%d.0" % i], "rank %d: image %d of a sharded batch differs from its unsharded single run" % (r, i)
 
 
 def test_bench_shard_mode_one_rank_joins_rccl():
