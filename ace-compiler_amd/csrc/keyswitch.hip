@@ -176,10 +176,7 @@ __device__ __forceinline__ u64 reduce80(u64 v0, u32 v1, u64 q, u64 ml, u32 m) {
   r = r >= q2 ? r - q2 : r;
   return r >= q ? r - q : r;
 }
-#ifndef ACEHIP_MFMA_WAVE_COEFFS
-#define ACEHIP_MFMA_WAVE_COEFFS 256  // coefficients a wave walks with its B fragments loaded once (measured: 256 / 512 / 1024)
-#endif
-constexpr u32 kMfmaWaveCoeffs = ACEHIP_MFMA_WAVE_COEFFS, kMfmaWgCoeffs = 4 * kMfmaWaveCoeffs;
+constexpr u32 kMfmaWaveCoeffs = 256, kMfmaWgCoeffs = 4 * kMfmaWaveCoeffs;
 
 template <int STEPS>
 __global__ __launch_bounds__(256) void base_conv_mfma_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
