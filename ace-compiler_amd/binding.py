@@ -75,6 +75,7 @@ SYMBOLS = [
     ("acehip_base_conv", C.c_int, [_vp, _vp, _vp, _u32, C.c_int, _vp, _u32, _vp]),
     ("acehip_key_switch", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_switch_bytes", _u64, [_vp, _u32]),
+    ("acehip_conv_mfma_tables", C.c_long, [_vp, _u32, C.c_int32, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_encode", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _u32, _vp]),
     ("acehip_encode_batch", C.c_int, [_vp, _vp, _vp, _u32, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _vp]),

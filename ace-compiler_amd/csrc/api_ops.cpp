@@ -572,6 +572,40 @@ const KsPlan* get_ks_plan(acehip_ctx* c, u32 level) {
 }
 extern "C" {
 
+// the tables of the matrix-core base conversion for one problem, as get_ks_plan uploads them (host arithmetic only)
+long acehip_conv_mfma_tables(const acehip_ctx* c, uint32_t level, int32_t digit, uint8_t* frag, size_t frag_cap, uint32_t* off, size_t off_cap,
+                             uint32_t* dims) {
+  if (!c || !dims) return fail(ACEHIP_EINVAL, "acehip_conv_mfma_tables: null argument");
+  const HostParams& hp = c->hp;
+  if (level == 0 || level > hp.L) return fail(ACEHIP_EINVAL, "acehip_conv_mfma_tables: bad level");
+  if (hp.alpha > 16 || hp.K > 16) return fail(ACEHIP_EINVAL, "acehip_conv_mfma_tables: digits of more than 16 limbs have no matrix-core form");
+  std::vector<uint8_t> f;
+  std::vector<u32> o;
+  u32 n_in, n_out, steps;
+  if (digit >= 0) {
+    if ((u32)digit >= hp.num_decomp(level)) return fail(ACEHIP_EINVAL, "acehip_conv_mfma_tables: bad digit");
+    HostParams::ModUp hm = hp.modup(level, (u32)digit);
+    n_in = hm.n2;
+    n_out = hm.nc;
+    steps = (hp.alpha + 7) / 8;
+    conv_mfma_tables(n_in, n_out, steps, [&](u32 i, u32 j) { return hm.hat_mod[(size_t)i * hm.nc + j]; },
+                     [&](u32 j) { return hp.primes[hm.compl_idx[j]].q; }, f, o);
+  } else {
+    n_in = hp.K;
+    n_out = level;
+    steps = (hp.K + 7) / 8;
+    conv_mfma_tables(n_in, n_out, steps, [&](u32 i, u32 j) { return hp.phat_modq[(size_t)j * hp.K + i]; },
+                     [&](u32 j) { return hp.primes[j].q; }, f, o);
+  }
+  dims[0] = n_in;
+  dims[1] = n_out;
+  dims[2] = steps;
+  dims[3] = (n_out + 15) / 16;
+  if (frag && frag_cap >= f.size()) std::memcpy(frag, f.data(), f.size());
+  if (off && off_cap >= o.size()) std::memcpy(off, o.data(), o.size() * sizeof(u32));
+  return (long)f.size();
+}
+
 int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key,
                       uint32_t level, acehip_stream s_) {
   if (int e = check_dev(c)) return e;

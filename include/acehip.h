@@ -387,6 +387,16 @@ uint64_t acehip_shard_traffic(const acehip_ctx* ctx, uint64_t* steps, int reset)
 int acehip_shard_schedule(const acehip_ctx* ctx, uint32_t world, int op, uint32_t level, uint32_t* out_step, uint32_t* out_pos,
                           uint32_t* out_root, size_t cap);
 
+/* The constant tables of the matrix-core base conversion (the sums of Reduce_rns_base polynomial.c:928-967 /
+ * Decompose_modup :1302-1320 as int8 matrix products), for checking them without a GPU (works on a host-only context).
+ * digit >= 0: the ModUp of that digit at `level`; digit < 0: the ModDown at `level`.  dims[4] = {sources n_in, outputs n_out,
+ * k-steps, tiles of 16 outputs}.  frag: [tile][k-step][digit b < 9][lane < 64][16 bytes] -- byte e of lane (r = lane & 15,
+ * g = lane >> 4) is digit b (7 bits) of  hat(i, j) * 2^(8a) mod t_j  for source i = 8*step + 2g + (e >> 3), byte a = e & 7 of its
+ * residue, output j = 16*tile + r (zero past n_in / n_out); off: [16*tiles][9] = 128 * (sum over the sources' bytes of that digit).
+ * Returns the bytes of frag (copies are made when the capacities, in elements, suffice), negative on error. */
+long acehip_conv_mfma_tables(const acehip_ctx* ctx, uint32_t level, int32_t digit, uint8_t* frag, size_t frag_cap, uint32_t* off,
+                             size_t off_cap, uint32_t* dims);
+
 /* algorithmic HBM bytes of one acehip_key_switch at `level` (8N(l + 2b(l+K) + 2l)) */
 uint64_t acehip_key_switch_bytes(const acehip_ctx* ctx, uint32_t level);
 

@@ -128,3 +128,78 @@ def test_reference_link_line_with_archives(tmp_path):
     needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True, check=True).stdout
     assert "libFHErt_ant.so" not in needed and "libacehip.so" not in needed   # the runtime is inside the executable
     assert "libamdhip64" in needed
+
+
+@pytest.mark.parametrize("params", [(1024, 24, 60, 50, 2), (2048, 9, 60, 50, 3), (65536, 34, 51, 50, 3)], ids=lambda p: "n%d_l%d_d%d" % (p[0], p[1], p[4]))
+def test_matrix_core_conversion_tables_reproduce_the_exact_sums(params):
+    """The base conversion on the matrix cores (keyswitch.hip base_conv_mfma_kernel) multiplies the BYTES of the source residues
+    (sign bit flipped) with 7-bit digits of hat(i, j) * 2^(8a) mod t_j and starts its accumulators at an offset.  Everything the
+    kernel needs comes from acehip_conv_mfma_tables; this test replays the kernel's arithmetic with Python integers on random
+    residues and checks, for ModUp digits and ModDown at several levels, that (1) the constants are the reference's --
+    hat(i, j) = prod of the other primes of the source basis mod t_j (crt.c:426-533) --, (2) every accumulator ends non-negative
+    and below 2^23, and (3) the recombined 80-bit value is congruent to sum_i y_i * hat(i, j) mod t_j, the sum Reduce_rns_base
+    (polynomial.c:928-967) reduces.  No GPU: host tables only."""
+    import ctypes as C
+    import random
+
+    N, L, q0, sf, dnum = params
+    rt = A.AceHip(N, L, q0, sf, dnum, host_only=True)
+    rng = random.Random(5)
+    try:
+        primes, K, alpha = list(rt.primes), rt.K, rt.alpha
+        for level in sorted({L, max(1, L // 2), 1}):
+            nd = rt.lib.acehip_num_decomp(rt.h, level)
+            assert nd == -(-level // alpha)
+            for digit in list(range(nd)) + [-1]:
+                dims = (C.c_uint32 * 4)()
+                need = rt.lib.acehip_conv_mfma_tables(rt.h, level, digit, None, 0, None, 0, dims)
+                assert need > 0, rt.err()
+                n_in, n_out, steps, tiles = list(dims)
+                frag = (C.c_uint8 * need)()
+                off = (C.c_uint32 * (tiles * 16 * 9))()
+                assert rt.lib.acehip_conv_mfma_tables(rt.h, level, digit, frag, need, off, len(off), dims) == need
+                assert need == tiles * steps * 9 * 64 * 16
+                # source / target primes of the problem
+                if digit >= 0:
+                    src = list(range(digit * alpha, min((digit + 1) * alpha, level)))
+                    tgt = [g for g in list(range(level)) + list(range(L, L + K)) if g not in src]
+                else:
+                    src = list(range(L, L + K))
+                    tgt = list(range(level))
+                assert (n_in, n_out) == (len(src), len(tgt)), (digit, level, n_in, n_out, src, tgt)
+
+                def dig(tile, step, b, lane, e):
+                    return frag[((((tile * steps + step) * 9 + b) * 64 + lane) * 16) + e]
+
+                y = [rng.randrange(primes[g]) for g in src]
+                y[0] = primes[src[0]] - 1  # an extreme residue
+                for j, gt in enumerate(tgt):
+                    t = primes[gt]
+                    tile, r = divmod(j, 16)
+                    total = 0
+                    acc = [off[j * 9 + b] for b in range(9)]
+                    for i, gs in enumerate(src):
+                        step, g, half = i // 8, (i % 8) // 2, i % 2
+                        lane = g * 16 + r
+                        # (1) the constant the digits of byte 0 spell is the reference's hat(i, j)
+                        hat = sum(dig(tile, step, b, lane, half * 8) << (7 * b) for b in range(9))
+                        want = 1
+                        for k in src:
+                            if k != gs:
+                                want = want * primes[k] % t
+                        assert hat == want, (level, digit, i, j)
+                        for a8 in range(8):
+                            u = (y[i] >> (8 * a8)) & 0xFF
+                            for b in range(9):
+                                d7 = dig(tile, step, b, lane, half * 8 + a8)
+                                assert d7 < 128
+                                acc[b] += (u - 128) * d7
+                        total += y[i] * hat
+                    assert all(0 <= v < (1 << 23) for v in acc), acc          # (2)
+                    v = sum(c << (7 * b) for b, c in enumerate(acc))
+                    assert v < (1 << 80) and v % t == total % t, (level, digit, j)  # (3)
+                # columns past n_out carry zero constants and zero offsets
+                for j in range(n_out, tiles * 16):
+                    assert all(off[j * 9 + b] == 0 for b in range(9))
+    finally:
+        rt.close()
