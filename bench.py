@@ -456,9 +456,11 @@ def limb_sharded_leg(ranks, timeout_s=240):
     if isinstance(res, dict) and "error" in res:
         out["error"] = res["error"]
     elif isinstance(res, dict):
-        out.update({"images_per_s": res["value"], "ms_per_image": res["ms_per_step"], "scaling": "strong", "shard": res.get("shard"),
-                    "last_logits": res.get("config", {}).get("last_logits"),
+        out.update({"images_per_s": res.get("value"), "ms_per_image": res.get("ms_per_step"), "scaling": "strong", "shard": res.get("shard"),
+                    "last_logits": (res.get("config") or {}).get("last_logits"),
                     "output_ciphertexts_identical_on_all_ranks": bool(all_ok and digest != 0.0 and hi == lo)})
+    else:
+        out["error"] = "no result line from rank 0"
     return out
 
 
@@ -709,7 +711,8 @@ def main():
     shard_leg = None
     force_leg = os.environ.get("ACEHIP_BENCH_FORCE_SHARD_LEG") == "1"  # test hook: exercise the leg's plumbing with one rank
     if (world > 1 or force_leg) and use_model and not r110 and not args.no_shard_leg:
-        shard_leg = limb_sharded_leg(ranks)  # (after the timed region; the model context above has released its memory)
+        shard_leg = limb_sharded_leg(ranks)  # (after the timed region; the model context above has released its memory; never raises
+        #                                       before its three reductions are through: every failure path is an "error" entry)
 
     # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
     n_polys = 2 * N_CT
