@@ -17,21 +17,35 @@ static RT_DATA_INFO* rt_data_info() { return Get_rt_data_info ? Get_rt_data_info
 
 namespace rt {
 
+// Randomness layout.  Every KEY draws from a generator of its own, derived from the context's key seed and the key's
+// identity (secret 1, public 2, relinearisation 3, automorphism key k: 2^34 + k) -- a key is the same whichever thread makes
+// it and in whatever order keys are asked for, so a fixed ACEHIP_SEED names one key set (tests/c/gen_parity_ref.c derives the
+// same set on the CPU and injects it into the reference).  ENCRYPTION draws from the calling thread's stream (Context::rng),
+// which Acehip_rt_seed_encryptor re-seeds.
+static u64 splitmix(u64 z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+std::mt19937_64 key_rng(u64 tag) {
+  RT_ASSERT(g_primary != nullptr, "no prepared context");
+  return std::mt19937_64(splitmix(g_primary->key_seed ^ splitmix(tag)));
+}
+
 // Sample_triangle random_sample.c:78-97: -1 w.p. 1/4, +1 w.p. 1/4, 0 w.p. 1/2
-void sample_triangle(std::vector<int64_t>& v) {
-  Context& c = ctx();
+void sample_triangle(std::vector<int64_t>& v, std::mt19937_64& rng) {
   for (auto& x : v) {
-    const u64 r = c.rng() & 3;
+    const u64 r = rng() & 3;
     x = r == 0 ? -1 : (r == 1 ? 1 : 0);
   }
 }
 
 // Sample_ternary random_sample.c:99-150: exactly `hamming_weight` non-zeros, signs roughly balanced
-void sample_ternary(std::vector<int64_t>& v, size_t hw) {
-  Context& c = ctx();
+void sample_ternary(std::vector<int64_t>& v, size_t hw, std::mt19937_64& rng) {
   const size_t n = v.size();
   if (hw == 0) {
-    for (auto& x : v) x = (int64_t)(c.rng() % 3) - 1;
+    for (auto& x : v) x = (int64_t)(rng() % 3) - 1;
     return;
   }
   if (hw > n) hw = n;
@@ -41,9 +55,9 @@ void sample_ternary(std::vector<int64_t>& v, size_t hw) {
     std::fill(v.begin(), v.end(), 0);
     size_t weight = 0;
     while (weight < hw) {
-      const size_t idx = c.rng() % n;
+      const size_t idx = rng() % n;
       if (v[idx] == 0) {
-        if (c.rng() & 1) {
+        if (rng() & 1) {
           v[idx] = 1;
           ++ones;
         } else {
@@ -63,8 +77,9 @@ static u64 p_mod(u64 q) {  // P mod q
 }
 
 // Generate_switching_key ckks_key_generator.c:127-200:  b_j = -a_j*old + e_j + P*new [digit j limbs]
-SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) {
+SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt, u64 tag) {
   Context& c = ctx();
+  std::mt19937_64 rng = key_rng(tag);
   const u32 T = c.L + c.K;
   const size_t N = c.N, poly_words = (size_t)T * N;
   auto* sk = new SwitchKeyStore();
@@ -78,11 +93,11 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt) 
   for (u32 j = 0; j < c.dnum; ++j) {
     u64* b = sk->data + ((size_t)j * 2 + 0) * poly_words;
     u64* a = sk->data + ((size_t)j * 2 + 1) * poly_words;
-    HIPCHK(acehip_sample_uniform(c.hip, a, c.L, 0, T, c.rng(), nullptr));            // a_j (NTT domain)
+    HIPCHK(acehip_sample_uniform(c.hip, a, c.L, 0, T, rng(), nullptr));              // a_j (NTT domain)
     q_ew(ACEHIP_HW_MUL, b, a, old_key_ntt, c.L, 0, T);            // a_j * old
     for (u32 i = 0; i < T; ++i) scal[i] = (i < c.L && i / c.alpha == j) ? p_mod(c.primes[i]) : 0;
     q_scalars(ACEHIP_HW_MULC, pm, new_key_ntt, scal.data(), c.L, 0, T);  // P*new on digit j
-    sample_triangle(tri);
+    sample_triangle(tri, rng);
     poly_from_small(&e, tri);
     poly_ntt(&e, false);
     q_ew(ACEHIP_HW_ADD, pm, pm, (u64*)e._data, c.L, 0, T);        // e + P*new
@@ -132,7 +147,7 @@ SwitchKeyStore* ensure_auto_key(u32 auto_idx) {
   const uint32_t* perm = acehip_auto_order(c.hip, (u32)inv);
   RT_ASSERT(perm, "automorphism table: %s", acehip_last_error());
   q_rotate(old_key, c.sk_ntt, perm, c.L, 0, T);
-  SwitchKeyStore* k = make_switch_key(c.sk_ntt, old_key);
+  SwitchKeyStore* k = make_switch_key(c.sk_ntt, old_key, KEY_TAG_AUTO + auto_idx);
   dfree(old_key);
   sync();  // complete in memory before another thread's stream may read it
   prim.auto_keys[auto_idx] = k;
@@ -166,6 +181,7 @@ static void shard_connect(u32 rank, u32 world, const unsigned char* id) {
   if (getenv("ACEHIP_SEED") == nullptr) {  // the same randomness on every rank
     u64 seed = 0x9E3779B97F4A7C15ull;
     for (int i = 0; i < 128; ++i) seed = (seed ^ id[i]) * 0x100000001B3ull;
+    c.key_seed = seed;
     c.rng.seed(seed);
     c.seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
   }
@@ -217,7 +233,8 @@ void generate_keys() {
   const size_t N = c.N;
   // secret key (Generate_secret_key :69-83)
   c.sk_coef.assign(N, 0);
-  sample_ternary(c.sk_coef, c.hamming);
+  std::mt19937_64 sk_rng = key_rng(KEY_TAG_SECRET), pk_rng = key_rng(KEY_TAG_PUBLIC);
+  sample_ternary(c.sk_coef, c.hamming, sk_rng);
   POLYNOMIAL s{};
   poly_alloc(&s, c.N, c.L, c.K);
   poly_from_small(&s, c.sk_coef);
@@ -226,11 +243,11 @@ void generate_keys() {
   // public key (Generate_public_key :85-125): pk1 = a, pk0 = -a*s + e
   c.pk0 = dalloc((size_t)c.L * N, false);
   c.pk1 = dalloc((size_t)c.L * N, false);
-  HIPCHK(acehip_sample_uniform(c.hip, c.pk1, c.L, 0, c.L, c.rng(), nullptr));
+  HIPCHK(acehip_sample_uniform(c.hip, c.pk1, c.L, 0, c.L, pk_rng(), nullptr));
   POLYNOMIAL e{};
   poly_alloc(&e, c.N, c.L, 0);
   std::vector<int64_t> tri(N);
-  sample_triangle(tri);
+  sample_triangle(tri, pk_rng);
   poly_from_small(&e, tri);
   poly_ntt(&e, false);
   q_ew(ACEHIP_HW_MUL, c.pk0, c.pk1, c.sk_ntt, c.L, 0, c.L);
@@ -239,7 +256,7 @@ void generate_keys() {
   // relinearisation key (Generate_relin_key :204-216): new = s^2 (q-limbs; p-limbs stay 0), old = s
   u64* s2 = dalloc((size_t)T * N, true, c.L);
   q_ew(ACEHIP_HW_MUL, s2, c.sk_ntt, c.sk_ntt, c.L, 0, c.L);
-  SwitchKeyStore* rk = make_switch_key(s2, c.sk_ntt);
+  SwitchKeyStore* rk = make_switch_key(s2, c.sk_ntt, KEY_TAG_RELIN);
   dfree(s2);
   c.relin = *rk;
   c.relin.key._parts = c.relin.parts.data();
@@ -292,6 +309,7 @@ void Prepare_context() {
   // ACEHIP_SEED makes runs reproducible.  seed_rng only ever hands out seeds for attaching threads, under shared_mu.
   if (const char* e = getenv("ACEHIP_SEED")) {
     const u64 seed = strtoull(e, nullptr, 10);
+    c->key_seed = seed;
     c->rng.seed(seed);
     c->seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
   } else {
@@ -299,6 +317,7 @@ void Prepare_context() {
     std::seed_seq s1{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()}, s2{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()};
     c->rng.seed(s1);
     c->seed_rng.seed(s2);
+    c->key_seed = ((u64)rd() << 32) ^ rd() ^ ((u64)rd() << 17);
   }
   // canonical-embedding tables (Precompute_fft ntt.c:587-610), m = 2N
   const size_t m = 2ull * c->N;
@@ -429,6 +448,7 @@ void Acehip_rt_thread_release(void) { thread_release(); }
 // pointers): hands over everything the shim still holds back and waits for the device.
 void Acehip_rt_sync(void) { sync(); }
 void Acehip_rt_next_input(void) { pt_image_boundary(); }
+void Acehip_rt_seed_encryptor(uint64_t seed) { ctx().rng.seed(seed); }
 
 // Extension: image batches.  B images run through every launch of this thread (Run_main_graph is called ONCE per batch): the
 // GPU form of the reference's image-parallel loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116), where the threads share
@@ -439,6 +459,7 @@ void Acehip_rt_set_batch(uint32_t b) {
   Context& c = ctx();
   RT_ASSERT(b >= 1 && b <= 64, "Acehip_rt_set_batch: 1..64 images");
   RT_ASSERT(!c.shard_sim || b == 1, "simulated limb-sharded execution runs one image");
+  set_batch_aware();
   if (b == c.batch) return;
   sync();
   RT_ASSERT(arena_peak_bytes() == 0, "Acehip_rt_set_batch: call it before the thread's first input (its pool is in use already)");
@@ -446,7 +467,10 @@ void Acehip_rt_set_batch(uint32_t b) {
   set_launch_mode(0, b);
 }
 uint32_t Acehip_rt_batch(void) { return batch_size(); }
-void Acehip_rt_select_image(uint32_t k) { select_image(k); }
+void Acehip_rt_select_image(uint32_t k) {
+  set_batch_aware();
+  select_image(k);
+}
 // Extension: limb-sharded execution (BASELINE configs[4]).  world / rank of this process and what the exchanges moved so far.
 uint32_t Acehip_rt_shard_world(void) { return g_ctx ? g_ctx->shard_world : 1; }
 uint32_t Acehip_rt_shard_rank(void) { return g_ctx ? g_ctx->shard_rank : 0; }

@@ -351,9 +351,9 @@ void encrypt(CIPHERTEXT* res, PLAINTEXT* plain) {
   poly_alloc(&v, c.N, l, 0);
   poly_alloc(&e1, c.N, l, 0);
   poly_alloc(&e2, c.N, l, 0);
-  sample_triangle(tri); poly_from_small(&v, tri); poly_ntt(&v, false);
-  sample_triangle(tri); poly_from_small(&e1, tri); poly_ntt(&e1, false);
-  sample_triangle(tri); poly_from_small(&e2, tri); poly_ntt(&e2, false);
+  sample_triangle(tri, c.rng); poly_from_small(&v, tri); poly_ntt(&v, false);
+  sample_triangle(tri, c.rng); poly_from_small(&e1, tri); poly_ntt(&e1, false);
+  sample_triangle(tri, c.rng); poly_from_small(&e2, tri); poly_ntt(&e2, false);
   u64* c0 = q_limbs(&res->_c0_poly);
   u64* c1 = q_limbs(&res->_c1_poly);
   q_ew(ACEHIP_HW_MUL, c0, c.pk0, q_limbs(&v), l, 0, l);

@@ -112,7 +112,8 @@ struct Context {
   std::map<u32, SwitchKeyStore*> auto_keys;   // automorphism index -> key
   std::map<int32_t, u32> rot2auto;            // rotation -> automorphism index
   std::vector<int64_t> sk_coef;               // ternary secret, host copy (signed)
-  std::mt19937_64 rng;                        // this thread's sampler (secret key, errors, seeds of the device sampler)
+  std::mt19937_64 rng;                        // this thread's encryption randomness (Acehip_rt_seed_encryptor re-seeds it)
+  u64 key_seed = 0;                           // primary context: every key's generator derives from it (rt_context.cpp key_rng)
   std::mt19937_64 seed_rng;                   // primary context only: seeds of attaching threads, used under shared_mu
   // FFT tables for the canonical embedding of decode (ntt.c:587-610): m = 2N
   std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
@@ -183,6 +184,8 @@ u32 current_rep0();
 u32 current_nrep();
 bool in_image_scope();
 u32 selected_image();
+bool batch_aware();      // false: ACEHIP_BATCH in the environment of a program that never selects an image (Prepare_input fills all)
+void set_batch_aware();
 void select_image(u32 k);
 void set_launch_mode(u32 rep0, u32 nrep);
 struct UniformScope {  // work whose results every image shares (keys, bootstrap tables ...): one replica, blocks outside the arena
@@ -244,13 +247,15 @@ void copy_limbs(u64* dst, const u64* src, size_t words, u32 nq = NQ_ANY, u32 fir
 double wall_s();
 
 // ---- sampling (random_sample.c) ----
-void sample_triangle(std::vector<int64_t>& v);                         // :78-97
-void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight);   // :99-150
+void sample_triangle(std::vector<int64_t>& v, std::mt19937_64& rng);                         // :78-97
+void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight, std::mt19937_64& rng);   // :99-150
+constexpr u64 KEY_TAG_SECRET = 1, KEY_TAG_PUBLIC = 2, KEY_TAG_RELIN = 3, KEY_TAG_AUTO = 1ull << 34;
+std::mt19937_64 key_rng(u64 tag);  // the generator of one key: a function of the context's key seed and the key's identity
 
 // ---- keys (ckks_key_generator.c) ----
 void generate_keys();
 void shard_connect_if_asked();   // rt_context.cpp: ACEHIP_SHARD=1 joins the RCCL communicator of the launcher's ranks
-SwitchKeyStore* make_switch_key(const u64* new_key_ntt /*[L+K][N]*/, const u64* old_key_ntt);
+SwitchKeyStore* make_switch_key(const u64* new_key_ntt /*[L+K][N]*/, const u64* old_key_ntt, u64 tag /* KEY_TAG_* */);
 u32 ensure_rot_key(int32_t rotation);   // Insert_rot_map :290; returns automorphism index
 SwitchKeyStore* ensure_auto_key(u32 auto_idx);
 void free_switch_key(SwitchKeyStore* k);

@@ -153,11 +153,7 @@ void Tm_taken(const char* msg) {
 }
 
 // ---- rtlib.c:41-87 ----
-void Prepare_input(TENSOR* input, const char* name) {
-  io_init();
-  // image batch (Acehip_rt_set_batch): this call fills the selected image's copy of the input ciphertext; the recorded
-  // Pt_from_msg sequence restarts with the first image of a batch
-  const rt::u32 k = rt::selected_image();
+static void prepare_one_image(TENSOR* input, const char* name, rt::u32 k) {
   if (k == 0) rt::pt_image_boundary();
   rt::ImageScope one_image(k);
   const size_t len = TENSOR_SIZE(input);
@@ -174,6 +170,19 @@ void Prepare_input(TENSOR* input, const char* name) {
   encrypt(ct, &pt);
   poly_free(&pt._poly);
   io_at(g_inputs, name, 0) = ct;
+}
+
+void Prepare_input(TENSOR* input, const char* name) {
+  io_init();
+  // image batch (Acehip_rt_set_batch): this call fills the selected image's copy of the input ciphertext; the recorded
+  // Pt_from_msg sequence restarts with the first image of a batch.  A program that knows nothing of batches (ACEHIP_BATCH=B in
+  // the environment of an unchanged main: it never selects an image) gets B independent encryptions of its tensor -- image k
+  // takes the k-th (v, e1, e2) of the thread's stream -- so that no image of the batch ever computes on unset memory
+  if (rt::batch_size() > 1 && !rt::batch_aware()) {
+    for (rt::u32 k = 0; k < rt::batch_size(); ++k) prepare_one_image(input, name, k);
+    return;
+  }
+  prepare_one_image(input, name, rt::selected_image());
 }
 
 double* Handle_output(const char* name) {
@@ -193,7 +202,9 @@ double* Handle_output(const char* name) {
     for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
     poly_free(&pt._poly);
   }
-  if (k + 1 >= rt::batch_size()) {
+  // the ciphertext goes with the last image of the batch (or with the only one a batch-unaware program ever reads); an output
+  // whose remaining images are never read is freed by the next Set_output_data into its slot
+  if (k + 1 >= rt::batch_size() || !rt::batch_aware()) {
     Free_cipher(ct);
     io_at(g_outputs, name, 0) = nullptr;
   }
@@ -215,6 +226,7 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
   CIPHER out = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
   Copy_ciph(out, data);
   Free_ciph_poly(data, 1);
+  if (CIPHER stale = (CIPHER)io_at(g_outputs, name, idx)) Free_cipher(stale);  // (a batch whose last images were never read)
   io_at(g_outputs, name, idx) = out;
   // ACEHIP_DUMP_OUTPUT=<prefix>: every output ciphertext is also written to <prefix>.<call>.<image> (ACEHCT01, rt_serial.cpp):
   // how the tests compare an image batch, or a limb-sharded run, bit for bit with the plain run of an unchanged program

@@ -220,6 +220,9 @@ u32 current_rep0() { return g_mode_rep0; }
 u32 current_nrep() { return g_mode_nrep; }
 u32 batch_size() { return g_ctx ? g_ctx->batch : 1; }
 u32 selected_image() { return g_image; }
+static bool g_batch_aware = false;  // the program addresses images itself (Acehip_rt_set_batch / Acehip_rt_select_image were called)
+bool batch_aware() { return g_batch_aware; }
+void set_batch_aware() { g_batch_aware = true; }
 void select_image(u32 k) {
   RT_ASSERT(k < batch_size(), "image %u outside the batch of %u", k, batch_size());
   g_image = k;

@@ -21,6 +21,11 @@ void       Acehip_rt_thread_release(void);
  * Acehip_rt_prefetched_count() = plaintexts this thread received from the prefetcher so far (statistics, tests). */
 void       Acehip_rt_next_input(void);
 size_t     Acehip_rt_prefetched_count(void);
+/* Extension: the calling thread's ENCRYPTION randomness (the v, e1, e2 of Prepare_input / Encrypt) restarts from `seed`.  Keys never
+ * draw from that stream: each key has a generator of its own derived from ACEHIP_SEED and the key's identity (csrc/rt/rt_context.cpp),
+ * so ACEHIP_SEED + this call make the ciphertext of an input -- and with it every output of Main_graph -- reproducible whichever
+ * thread, stream or image batch carries it (tests/test_gpu_gen_parity.py, bench.py "verified"). */
+void       Acehip_rt_seed_encryptor(uint64_t seed);
 /* Extension: on-disk containers (the reference has none).  All return 0 or a negative code
  * (-1 cannot open, -2 truncated / wrong magic, -3 written for other CKKS parameters).
  *   "ACEHCT01" ciphertext / plaintext: u32 n_polys, N, level, num_p, is_ntt, slots, sf_degree, 0; f64 scaling_factor;

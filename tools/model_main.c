@@ -4,6 +4,9 @@
  * rtlib/ant/dataset/resnet_cifar.main.inc).  The generated source is included UNCHANGED from where it
  * lies (-DMODEL_INC='"<path>.inc"'); see `make -C oracle models`.
  *   usage: model <n_images> [c h w]      env: ACEHIP_RT_DATA_SYNTH=1 for synthetic weights
+ *   MODEL_ENC_SEED=<s>: image i is encrypted with the randomness of seed s + i (Acehip_rt_seed_encryptor), whatever batch or
+ *   stream carries it; with ACEHIP_SEED that makes every output ciphertext a function of (seeds, image index) alone.  The same
+ *   source is built against the REFERENCE rtlib with tests/c/gen_parity_ref.c, which serves the same call on the CPU.
  */
 #include <math.h>
 #include <stdio.h>
@@ -12,6 +15,10 @@
 #include <time.h>
 
 #include "common/rtlib.h"
+
+void Acehip_rt_seed_encryptor(uint64_t seed); /* include/rt_ant/rt_api.h (tests/c/gen_parity_ref.c in the reference build) */
+void Acehip_rt_set_batch(uint32_t n_images);
+void Acehip_rt_select_image(uint32_t k);
 
 static double now_s(void) {
   struct timespec t;
@@ -31,6 +38,7 @@ int main(int argc, char* argv[]) {
   printf("[MODEL] Prepare_context: %.3f s\n", t1 - t0);
   if (batch < 1) batch = 1;
   if (batch > 1) Acehip_rt_set_batch((uint32_t)batch);
+  const char*        enc_seed = getenv("MODEL_ENC_SEED");
   unsigned long long z = 1;
   for (int img0 = 0; img0 < n_images; img0 += batch) {
     const int nb = n_images - img0 < batch ? n_images - img0 : batch;
@@ -44,6 +52,7 @@ int main(int argc, char* argv[]) {
       }
       if (k < nb) z = zk;
       if (batch > 1) Acehip_rt_select_image((uint32_t)k);
+      if (enc_seed) Acehip_rt_seed_encryptor(strtoull(enc_seed, NULL, 10) + (unsigned long long)(img0 + (k < nb ? k : nb - 1)));
       Prepare_input(in, "input");
       Free_tensor(in);
     }
@@ -56,6 +65,8 @@ int main(int argc, char* argv[]) {
       if (k < nb) {
         printf("[MODEL] image %d: encrypt %.3f s, Main_graph+decrypt %.3f s, logits:", img0 + k, (b - a) / batch, (now_s() - b) / batch);
         for (int i = 0; i < 10; ++i) printf(" %.4f", out[i]);
+        printf("\n[MODEL] image %d logits9:", img0 + k);
+        for (int i = 0; i < 10; ++i) printf(" %.9f", out[i]);
         printf("\n");
       }
       free(out);
