@@ -144,6 +144,7 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
 void acehip_ctx_destroy(acehip_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  shard_release(ctx);  // RCCL communicator, exchange stream, events (api_shard.cpp)
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->hw_scratch && !ctx->scratch_external) (void)hipFree(ctx->hw_scratch);
   delete ctx;

@@ -158,3 +158,4 @@ struct XItem {
   u32 root;
 };
 int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s);
+void shard_release(acehip_ctx* c);  // RCCL communicator + exchange stream / events of a context (acehip_ctx_destroy)

@@ -445,7 +445,11 @@ int acehip_shard_encode_limbs(acehip_shard* sh, uint64_t* d_q_own, const int64_t
 // on the launch stream.  RCCL is loaded with dlopen when first needed: unsharded programs never map it.
 // ------------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <memory>
+#include <thread>
 
 struct Id128 {  // ncclUniqueId (rccl.h): passed by value to ncclCommInitRank
   char b[128];
@@ -522,9 +526,10 @@ int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
       }
     }
     const int e2 = api->GroupEnd();
-    if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
+    // (also after a failed group: whatever was enqueued on the exchange stream is ordered before the launches that follow)
     HIP_TRY(hipEventRecord(rc->after, rc->xs));
     HIP_TRY(hipStreamWaitEvent(s, rc->after, 0));
+    if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
     return ACEHIP_OK;
   }
   // simulated ranks: owner's replica -> every other hosted replica (absolute addresses: a DevCtx without rebasing)
@@ -558,6 +563,20 @@ int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
   }
   flush();
   return post_launch();
+}
+
+// called by acehip_ctx_destroy: the communicator, its stream and events go with the context
+void shard_release(acehip_ctx* c) {
+  if (!c || !c->rccl) return;
+  RcclComm* rc = (RcclComm*)c->rccl;
+  RcclApi* api = rccl_api();
+  if (rc->xs) (void)hipStreamSynchronize(rc->xs);
+  if (rc->comm && api && api->CommDestroy) (void)api->CommDestroy(rc->comm);
+  if (rc->before) (void)hipEventDestroy(rc->before);
+  if (rc->after) (void)hipEventDestroy(rc->after);
+  if (rc->xs) (void)hipStreamDestroy(rc->xs);
+  delete rc;
+  c->rccl = nullptr;
 }
 
 extern "C" {
@@ -601,13 +620,47 @@ int acehip_ctx_shard_rccl(acehip_ctx* c, uint32_t rank, uint32_t world, const vo
   rc->world = world;
   Id128 id;
   std::memcpy(id.b, unique_id, 128);
-  if (int e = api->CommInitRank(&rc->comm, (int)world, id, (int)rank)) {
-    delete rc;
-    return fail(ACEHIP_EHIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  // ncclCommInitRank returns when EVERY rank has joined and cannot be cancelled: a rank that read a stale id, or whose peers died,
+  // would wait for ever.  It runs on a helper thread and the caller gives up after ACEHIP_RCCL_INIT_TIMEOUT_S (default 180 s) with
+  // an error (the shim aborts the process on it); the helper is left behind in that case.
+  struct Join {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int err = 0;
+    void* comm = nullptr;
+  };
+  auto join = std::make_shared<Join>();
+  const int dev = c->device;
+  std::thread([join, api, id, world, rank, dev] {
+    (void)hipSetDevice(dev);
+    void* comm = nullptr;
+    const int e = api->CommInitRank(&comm, (int)world, id, (int)rank);
+    std::lock_guard<std::mutex> lk(join->mu);
+    join->err = e;
+    join->comm = comm;
+    join->done = true;
+    join->cv.notify_all();
+  }).detach();
+  {
+    const char* t = getenv("ACEHIP_RCCL_INIT_TIMEOUT_S");
+    const int limit_s = t && atoi(t) > 0 ? atoi(t) : 180;
+    std::unique_lock<std::mutex> lk(join->mu);
+    if (!join->cv.wait_for(lk, std::chrono::seconds(limit_s), [&] { return join->done; })) {
+      delete rc;
+      return fail(ACEHIP_EHIP, "ncclCommInitRank: rank " + std::to_string(rank) + " of " + std::to_string(world) + " did not join within " +
+                                   std::to_string(limit_s) + " s (stale communicator id, or a peer that never started?)");
+    }
+    if (join->err) {
+      delete rc;
+      return fail(ACEHIP_EHIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(join->err) : "error"));
+    }
+    rc->comm = join->comm;
   }
   if (hipStreamCreateWithFlags(&rc->xs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rc->before, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&rc->after, hipEventDisableTiming) != hipSuccess) {
-    delete rc;
+    c->rccl = rc;
+    shard_release(c);  // (communicator, and whichever of the stream / events exist)
     return fail(ACEHIP_EHIP, "acehip_ctx_shard_rccl: stream / event creation failed");
   }
   c->rccl = rc;

@@ -7,8 +7,11 @@
 
 #include "rt_internal.hpp"
 
+#include <cctype>
+#include <cerrno>
+#include <fcntl.h>
 #include <sys/stat.h>
-#include <ctime>
+#include <unistd.h>
 
 // Programs generated for the CKKS-level provider interface (rt_seal examples) do not define this callback: it is an
 // optional (weak) reference here, a missing definition means "no weight data file".
@@ -168,12 +171,19 @@ u32 ensure_rot_key(int32_t rotation) {
 
 // ACEHIP_SHARD=1: the processes of a launcher (torchrun, mpirun: RANK / WORLD_SIZE / LOCAL_RANK in the environment) are the ranks
 // of ONE limb-sharded computation: each owns the limbs gi % WORLD_SIZE == RANK on its own GPU.  Rank 0 creates the RCCL id and
-// publishes it in a file every rank of the node can read (ACEHIP_SHARD_ID_FILE, default /tmp/acehip_rccl_<MASTER_PORT>.id); a
-// caller that has its own channel passes the id with Acehip_rt_shard_connect instead.  All ranks must use the same ACEHIP_SEED
-// (keys and encryption randomness are derived per rank from the same stream); without one it is taken from the id.
+// publishes it in a file only this job's ranks look for; a caller that has its own channel passes the id with
+// Acehip_rt_shard_connect instead.  All ranks must use the same ACEHIP_SEED (every key derives from it); without one it is taken
+// from the id.
+//
+// The rendezvous file.  Name (unless ACEHIP_SHARD_ID_FILE names one): <dir>/acehip_rccl_<uid>_<job>.id with <dir> = $XDG_RUNTIME_DIR,
+// $TMPDIR or /tmp and <job> = the launcher's run id (TORCHELASTIC_RUN_ID) when there is one, MASTER_PORT and the launcher's pid
+// (the ranks of one launch are children of one process) -- two jobs on one node, or a retry on the same port, look for different
+// files.  Content: magic, a token derived from the same job identity, the 128-byte id; a reader accepts only a regular file of its
+// own user with the right token that is younger than five minutes.  Rank 0 creates it with O_CREAT | O_EXCL | O_NOFOLLOW, mode
+// 0600, under a temporary name and renames it into place; it is removed once every rank has joined.  The join itself is bounded
+// (acehip_ctx_shard_rccl, ACEHIP_RCCL_INIT_TIMEOUT_S): a rank whose peers never arrive exits with an error instead of hanging.
 static void shard_connect(u32 rank, u32 world, const unsigned char* id) {
   Context& c = ctx();
-  RT_ASSERT(c.batch == 1 || true, "batch");
   const int rc = acehip_ctx_shard_rccl(c.hip, rank, world, id, 128);
   RT_ASSERT(rc >= 0, "acehip_ctx_shard_rccl: %s", acehip_last_error());
   c.shard_world = world;
@@ -186,6 +196,20 @@ static void shard_connect(u32 rank, u32 world, const unsigned char* id) {
     c.seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
   }
 }
+static std::string shard_job_identity() {
+  std::string job;
+  const char* run = getenv("TORCHELASTIC_RUN_ID");
+  if (run && *run && strcmp(run, "none") != 0) job += std::string(run) + "_";
+  job += std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + std::to_string((long)getppid());
+  for (char& ch : job)
+    if (!isalnum((unsigned char)ch) && ch != '_' && ch != '-') ch = '_';
+  return job;
+}
+static u64 shard_job_token(const std::string& job) {
+  u64 h = 0xCBF29CE484222325ull ^ (u64)geteuid();
+  for (unsigned char ch : job) h = (h ^ ch) * 0x100000001B3ull;
+  return h;
+}
 void shard_connect_if_asked() {
   const char* on = getenv("ACEHIP_SHARD");
   if (on == nullptr || atoi(on) == 0) return;
@@ -194,37 +218,64 @@ void shard_connect_if_asked() {
   RT_ASSERT(r != nullptr && w != nullptr, "ACEHIP_SHARD=1 needs RANK and WORLD_SIZE (torchrun / mpirun)");
   const u32 rank = (u32)atoi(r), world = (u32)atoi(w);
   RT_ASSERT(world >= 1 && rank < world, "bad RANK / WORLD_SIZE");
+  const std::string job = shard_job_identity();
   std::string path;
-  if (const char* f = getenv("ACEHIP_SHARD_ID_FILE")) path = f;
-  else path = std::string("/tmp/acehip_rccl_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+  u64 token;
+  if (const char* f = getenv("ACEHIP_SHARD_ID_FILE")) {  // the caller names the file (and with it the job): the token follows the name
+    path = f;
+    token = shard_job_token(path);
+  } else {
+    const char* dir = getenv("XDG_RUNTIME_DIR");
+    if (!dir || !*dir) dir = getenv("TMPDIR");
+    if (!dir || !*dir) dir = "/tmp";
+    path = std::string(dir) + "/acehip_rccl_" + std::to_string((long)geteuid()) + "_" + job + ".id";
+    token = shard_job_token(job);
+  }
+  struct Record {
+    char magic[8];
+    u64 token;
+    unsigned char id[128];
+  } rec;
   unsigned char id[128];
   if (rank == 0) {
-    remove(path.c_str());  // (left behind by a run that died between publishing and joining)
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    unlink(path.c_str());  // (left behind by a run that died between publishing and joining)
+    unlink(tmp.c_str());
     const int n = acehip_rccl_unique_id(id, sizeof id);
     RT_ASSERT(n == 128, "acehip_rccl_unique_id: %s", acehip_last_error());
-    const std::string tmp = path + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    RT_ASSERT(f != nullptr && fwrite(id, 1, 128, f) == 128, "cannot write %s", tmp.c_str());
-    fclose(f);
+    memcpy(rec.magic, "ACEHRCCL", 8);
+    rec.token = token;
+    memcpy(rec.id, id, 128);
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    RT_ASSERT(fd >= 0, "cannot create %s: %s", tmp.c_str(), strerror(errno));
+    const bool ok = write(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && fsync(fd) == 0;
+    close(fd);
+    RT_ASSERT(ok, "cannot write %s", tmp.c_str());
     RT_ASSERT(rename(tmp.c_str(), path.c_str()) == 0, "cannot publish %s", path.c_str());
   } else {
-    size_t got = 0;
-    for (int tries = 0; tries < 6000 && got != 128; ++tries) {  // up to a minute
-      struct stat st;
-      FILE* f = fopen(path.c_str(), "rb");
-      if (f) {  // an id older than a few minutes belongs to an earlier run that never removed it: keep waiting for this run's
-        if (fstat(fileno(f), &st) == 0 && time(nullptr) - st.st_mtime < 300) got = fread(id, 1, 128, f);
-        fclose(f);
+    const char* t = getenv("ACEHIP_RCCL_INIT_TIMEOUT_S");
+    const int limit_s = t && atoi(t) > 0 ? atoi(t) : 180;
+    bool got = false;
+    for (int tries = 0; tries < limit_s * 100 && !got; ++tries) {
+      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+      if (fd >= 0) {  // (an older file, another user's, or another job's token: not this run's -- keep waiting for rank 0)
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && time(nullptr) - st.st_mtime < 300 &&
+            read(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && memcmp(rec.magic, "ACEHRCCL", 8) == 0 && rec.token == token) {
+          memcpy(id, rec.id, 128);
+          got = true;
+        }
+        close(fd);
       }
-      if (got != 128) {
+      if (!got) {
         struct timespec ts = {0, 10 * 1000 * 1000};
         nanosleep(&ts, nullptr);
       }
     }
-    RT_ASSERT(got == 128, "rank %u: no RCCL id in %s", rank, path.c_str());
+    RT_ASSERT(got, "rank %u: no RCCL id for this job in %s within %d s", rank, path.c_str(), limit_s);
   }
   shard_connect(rank, world, id);
-  if (rank == 0) remove(path.c_str());  // (every rank has joined: ncclCommInitRank returns only then)
+  if (rank == 0) unlink(path.c_str());  // (every rank has joined: ncclCommInitRank returns only then)
 }
 
 void generate_keys() {
@@ -369,7 +420,7 @@ void Prepare_context() {
       bool ok = Pt_mgr_init(di->_file_name);
       RT_ASSERT(ok, "Pt_mgr_init(%s) failed", di->_file_name);
     }
-    sync();
+    rt::sync();
   }
   set_launch_mode(0, c->shard_sim ? 1 : c->batch);
 }
@@ -383,7 +434,7 @@ void Finalize_context() {
   std::lock_guard<std::recursive_mutex> fin_lock(shared_mu());
   const uint64_t fin_t0 = rtm_enabled() ? rtm_now() : 0;
   Context& c = *g_ctx;
-  sync();
+  rt::sync();
   HIPCHK(acehip_encode_status(c.hip));  // the reference asserts on encode overflow; report it at the latest here
   if (!c.keys_save_path.empty()) RT_ASSERT(save_keys(c.keys_save_path.c_str()) == 0, "cannot write key file %s", c.keys_save_path.c_str());
   if (rt_data_info() != nullptr) Pt_mgr_fini();
@@ -446,7 +497,7 @@ void Acehip_rt_thread_release(void) { thread_release(); }
 
 // Extension for callers that touch Coeffs() memory themselves (acehip_* / HIP calls on the raw device
 // pointers): hands over everything the shim still holds back and waits for the device.
-void Acehip_rt_sync(void) { sync(); }
+void Acehip_rt_sync(void) { rt::sync(); }
 void Acehip_rt_next_input(void) { pt_image_boundary(); }
 void Acehip_rt_seed_encryptor(uint64_t seed) { ctx().rng.seed(seed); }
 
@@ -461,7 +512,7 @@ void Acehip_rt_set_batch(uint32_t b) {
   RT_ASSERT(!c.shard_sim || b == 1, "simulated limb-sharded execution runs one image");
   set_batch_aware();
   if (b == c.batch) return;
-  sync();
+  rt::sync();
   RT_ASSERT(arena_peak_bytes() == 0, "Acehip_rt_set_batch: call it before the thread's first input (its pool is in use already)");
   c.batch = b;
   set_launch_mode(0, b);
@@ -504,7 +555,7 @@ void Run_main_graph() {
   const double t0 = wall_s();
   bool ok = Main_graph();
   const double t1 = wall_s();
-  sync();
+  rt::sync();
   ctx().t_main += wall_s() - t0;
   ctx().t_issue += t1 - t0;
   RT_ASSERT(ok, "Main_graph() failed");

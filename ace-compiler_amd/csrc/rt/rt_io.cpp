@@ -221,6 +221,12 @@ CIPHERTEXT Get_input_data(const char* name, size_t idx) {
   return ret;
 }
 
+// Acehip_rt_dump_next_output(prefix): the calling thread's NEXT Set_output_data also writes its ciphertext, one file per image of
+// the batch, to <prefix>.<image> (ACEHCT01).  One shot and per thread, unlike the process-wide ACEHIP_DUMP_OUTPUT: how bench.py checks
+// an image of its timed region against the reference's digest without dumping every step of every stream.
+static thread_local std::string g_dump_next;
+void Acehip_rt_dump_next_output(const char* prefix) { g_dump_next = prefix ? prefix : ""; }
+
 void Set_output_data(const char* name, size_t idx, CIPHER data) {
   io_init();
   CIPHER out = (CIPHER)calloc(1, sizeof(CIPHERTEXT));
@@ -240,6 +246,16 @@ void Set_output_data(const char* name, size_t idx, CIPHER data) {
     }
     rt::select_image(sel);
     ++n_call;
+  }
+  if (!g_dump_next.empty()) {
+    const rt::u32 sel = rt::selected_image();
+    for (rt::u32 k = 0; k < rt::batch_size(); ++k) {
+      rt::select_image(k);
+      const std::string path = g_dump_next + "." + std::to_string(k);
+      RT_ASSERT(Acehip_rt_save_ciph(path.c_str(), out) == 0, "cannot write %s", path.c_str());
+    }
+    rt::select_image(sel);
+    g_dump_next.clear();
   }
 }
 

@@ -36,9 +36,17 @@ namespace {
 struct File {
   FILE* f = nullptr;
   const char* path;
-  File(const char* p, const char* mode, bool secret = false) : path(p) {
-    if (secret) {  // key material: never readable by group / others, whatever the umask says
-      const int fd = open(p, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  std::string tmp;       // key files are written under a temporary name and renamed into place by commit()
+  bool discard = false;  // limb-sharded runs: every rank takes part in the gathers, rank 0 alone writes
+  File(const char* p, const char* mode, bool secret = false, bool discard_ = false) : path(p), discard(discard_) {
+    if (discard) {
+      f = fopen("/dev/null", "wb");
+    } else if (secret) {
+      // key material: a new file of mode 0600 (never through a symbolic link, never an existing file), complete before it gets its
+      // name -- an interrupted save leaves the old file (or none), not a truncated one
+      tmp = std::string(p) + ".tmp." + std::to_string((long)getpid());
+      unlink(tmp.c_str());
+      const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
       if (fd >= 0) {
         (void)fchmod(fd, 0600);
         f = fdopen(fd, mode);
@@ -52,8 +60,21 @@ struct File {
     struct stat st;
     return f && fstat(fileno(f), &st) == 0 ? (long)st.st_size : -1;
   }
+  bool commit() {  // flush, reach the disk, take the final name
+    if (!f) return false;
+    bool ok = fflush(f) == 0 && (discard || fsync(fileno(f)) == 0);
+    ok = fclose(f) == 0 && ok;
+    f = nullptr;
+    if (!tmp.empty()) {
+      if (ok) ok = rename(tmp.c_str(), path) == 0;
+      if (!ok) unlink(tmp.c_str());
+      tmp.clear();
+    }
+    return ok;
+  }
   ~File() {
     if (f) fclose(f);
+    if (!tmp.empty()) unlink(tmp.c_str());  // never committed: nothing half-written stays behind
   }
   bool put(const void* p, size_t bytes) { return fwrite(p, 1, bytes, f) == bytes; }
   bool get(void* p, size_t bytes) { return fread(p, 1, bytes, f) == bytes; }
@@ -176,7 +197,7 @@ static int save_keys_impl(const char* path, bool with_secret) {
   RT_ASSERT(g_primary != nullptr, "save_keys: no prepared context");
   Context& c = *g_primary;
   if (with_secret && c.sk_ntt == nullptr) return -1;  // an evaluation-only context has no secret to write
-  File f(path, "wb", true);
+  File f(path, "wb", true, /*discard=*/c.shard_world > 1 && !c.shard_sim && c.shard_rank != 0);
   if (!f.f) return -1;
   sync();
   UniformScope keys_are_shared;
@@ -200,7 +221,7 @@ static int save_keys_impl(const char* path, bool with_secret) {
     const u32 e[2] = {kv.first, 0};
     ok = ok && f.put(e, 8) && put_key(kv.second->data);
   }
-  return ok ? 0 : -1;
+  return ok && f.commit() ? 0 : -1;
 }
 int save_keys(const char* path) { return save_keys_impl(path, true); }
 int save_eval_keys(const char* path) { return save_keys_impl(path, false); }

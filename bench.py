@@ -269,14 +269,45 @@ def finish_cpu_baseline(res, stats_per_image):
 
 
 
+GEN_PARITY = os.path.join(ROOT, "tests", "golden", "gen_parity.json")
+
+
+def reference_fixture(key="resnet20"):
+    """The committed digest of the REFERENCE rtlib's output ciphertext for one image of the generated ResNet (tests/golden/gen_parity.json,
+    made in the dev container by tests/golden/gen_gen_parity.py: reference rtlib + the key set / encryption randomness of ACEHIP_SEED
+    injected by tests/c/gen_parity_ref.c).  None when the fixture has no entry for this model."""
+    try:
+        fix = json.load(open(GEN_PARITY))
+        m = fix["models"][key]
+        return {"seed": fix["seed"], "enc_seed": m["enc_seed"], "weights": m["weights"], "digest": m["outputs"]["0.0"], "logits9": m.get("logits9")}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def model_main_image0():
+    """image 0 of tools/model_main.c (xorshift64, U(-1,1)): the image the reference run of the fixture was fed"""
+    import numpy as np
+
+    m, z, v = (1 << 64) - 1, 1, []
+    for _ in range(3 * 32 * 32):
+        z ^= (z << 13) & m
+        z ^= z >> 7
+        z ^= (z << 17) & m
+        v.append((z >> 11) / 9007199254740992.0 * 2.0 - 1.0)
+    return np.ascontiguousarray(np.array(v, dtype=np.float64))
+
+
 def load_model_runtime(device, batch=1):
     """dlopen the generated ResNet-20 (+ the rt_ant drop-in it is linked against) and return (lib, step):
     step() pushes `batch` synthetic images through Prepare_input / Run_main_graph / Handle_output -- one Run_main_graph per
-    batch (Acehip_rt_set_batch, include/rt_ant/rt_api.h: the images share every launch, key, twiddle and weight plaintext)."""
+    batch (Acehip_rt_set_batch, include/rt_ant/rt_api.h: the images share every launch, key, twiddle and weight plaintext).
+    step(verify=(slot, enc_seed, prefix)): the image in position `slot` of the batch is the fixture's image, encrypted with the
+    fixture's randomness, and the batch's output ciphertexts are written to <prefix>.<image> (Acehip_rt_dump_next_output)."""
     import numpy as np
 
     os.environ["ACEHIP_DEVICE"] = str(device)
-    os.environ.setdefault("ACEHIP_RT_DATA_SYNTH", "1")
+    if "ACEHIP_RT_DATA_FILE" not in os.environ:
+        os.environ.setdefault("ACEHIP_RT_DATA_SYNTH", "1")
     # libmodel defines Main_graph + the Get_* callbacks and is linked against libFHErt_ant.so, so one
     # dlopen resolves both directions of the generated-code <-> runtime boundary
     fhe = C.CDLL(MODEL_LIB, mode=C.RTLD_GLOBAL)
@@ -288,18 +319,28 @@ def load_model_runtime(device, batch=1):
     fhe.Handle_output.argtypes = [C.c_char_p]
     fhe.Acehip_rt_set_batch.argtypes = [C.c_uint32]
     fhe.Acehip_rt_select_image.argtypes = [C.c_uint32]
+    fhe.Acehip_rt_seed_encryptor.argtypes = [C.c_uint64]
+    fhe.Acehip_rt_seed_encryptor.restype = None
+    fhe.Acehip_rt_dump_next_output.argtypes = [C.c_char_p]
+    fhe.Acehip_rt_dump_next_output.restype = None
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
     img_rng = np.random.default_rng(1)
+    fixed = model_main_image0()
 
-    def step():
+    def step(verify=None):
         for k in range(batch):
             img = np.ascontiguousarray(img_rng.uniform(-1.0, 1.0, size=3 * 32 * 32))
+            if verify is not None and k == verify[0]:
+                img = fixed
+                fhe.Acehip_rt_seed_encryptor(verify[1])
             t = fhe.Alloc_tensor(1, 3, 32, 32, img.ctypes.data)
             if batch > 1:
                 fhe.Acehip_rt_select_image(k)
             fhe.Prepare_input(t, b"input")
             fhe.Free_tensor(t)
+        if verify is not None:
+            fhe.Acehip_rt_dump_next_output(verify[2].encode())
         fhe.Run_main_graph()
         vals = None
         for k in range(batch):
@@ -486,7 +527,8 @@ def main():
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     ap.add_argument("--no-shard-leg", action="store_true",
-                    help="with --gpus N > 1: skip the secondary limb-sharded ResNet-20 image the ranks run after the headline")
+                    help="never run the secondary limb-sharded ResNet-20 image (it is opt-in anyway: ACEHIP_BENCH_SHARD_LEG=1 with "
+                         "--gpus N > 1 runs it after the headline line has been printed; result on stderr)")
     ap.add_argument("--batch", type=int, default=12,
                     help="images per launch on every stream (Acehip_rt_set_batch): the images of a batch share launches, keys, "
                          "twiddles, bootstrap tables and encoded weight plaintexts; a step = one batch per stream")
@@ -568,6 +610,7 @@ def main():
         rt.check(lib.acehip_key_switch(h, o0.ptr, o1.ptr, a.ptr, key.ptr, L, None))
 
     logits = None
+    fix, verify_prefix, verify_note, weights_note = None, None, None, "synthetic weights N(0,0.05)"
     n_streams = max(args.streams, 1) if use_model else 1
     n_batch = max(args.batch, 1) if use_model else 1
     if use_model:
@@ -576,6 +619,29 @@ def main():
         # Image streams: the reference runs one OpenMP thread per image on one context (resnet_cifar.main.inc:77-116);
         # same structure here: the context (keys) is prepared once, every image thread attaches to it with its own
         # scratch, pool, queue and HIP stream, so the small dependent kernels of several images overlap on the GPU.
+        # Verification inside the timed region (not a separate run): with the fixture's ACEHIP_SEED the context holds the key set
+        # the REFERENCE rtlib was given for its CPU run of this program (tests/golden/gen_parity.json), the weights are that run's
+        # file, and the first timed batch of every stream carries that run's image, encrypted with that run's randomness, in batch
+        # position (stream index): its output ciphertext must hash to the reference's digest -- byte-identical to the CPU rtlib.
+        if not r110:
+            fix = reference_fixture("resnet20")
+            if fix is None:
+                verify_note = "tests/golden/gen_parity.json has no resnet20 entry"
+            elif os.environ.get("ACEHIP_SEED", str(fix["seed"])) != str(fix["seed"]) or "ACEHIP_RT_DATA_FILE" in os.environ:
+                fix, verify_note = None, "ACEHIP_SEED / ACEHIP_RT_DATA_FILE set by the caller: not the fixture's keys or weights"
+            else:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import model_weights
+                import tempfile
+
+                wfile, wmeta = model_weights.ensure("resnet20", fix["weights"]["sigma"])
+                os.environ["ACEHIP_RT_DATA_FILE"] = wfile
+                os.environ["ACEHIP_SEED"] = str(fix["seed"])
+                weights_note = "synthetic weights N(0,%g) (tools/make_weight_file.py, md5 %s)" % (fix["weights"]["sigma"], wmeta["md5"][:8])
+                if wmeta["md5"] != fix["weights"]["md5"]:
+                    fix, verify_note = None, "this numpy writes a different weight file than the fixture's (md5 %s vs %s)" % (wmeta["md5"], fix["weights"]["md5"])
+                else:
+                    verify_prefix = os.path.join(tempfile.gettempdir(), "acehip_bench_verify_%d_r%d" % (os.getpid(), rank))
         fhe, _ = load_model_runtime(local_rank)
         fhe.Prepare_context()  # this thread owns the context: keys are generated once (on the device) and shared
         gate = threading.Barrier(n_streams + 1)
@@ -593,8 +659,10 @@ def main():
                     gate.wait()
                     op = cmd["op"]
                     if op == "step":
-                        for _ in range(cmd["n"]):               # images back to back: streams are not kept in lock step
-                            stream_logits[i] = one_image()
+                        for j in range(cmd["n"]):               # images back to back: streams are not kept in lock step
+                            # the FIRST batch of a verified region carries the fixture's image in position i of stream i's batch
+                            v = (i % n_batch, fix["enc_seed"], "%s_s%d" % (verify_prefix, i)) if (cmd.get("verify") and j == 0) else None
+                            stream_logits[i] = one_image(v)
                     elif op == "reset":
                         read_stats(reset=True)                 # statistics are per thread as well
                     elif op == "stats":
@@ -616,25 +684,25 @@ def main():
         for t in threads:
             t.start()
 
-        def run_all(op, n=1):
-            cmd["op"], cmd["n"] = op, n
+        def run_all(op, n=1, verify=False):
+            cmd["op"], cmd["n"], cmd["verify"] = op, n, verify
             try:
                 gate.wait()
                 gate.wait()
             except threading.BrokenBarrierError:
                 raise SystemExit("bench: an image stream failed: %s" % stream_err)
 
-        def step(n=1):  # n images on every stream of this GPU, concurrently
-            run_all("step", n)
+        def step(n=1, verify=False):  # n images on every stream of this GPU, concurrently
+            run_all("step", n, verify)
             return stream_logits[0]
 
         unit, metric = "images/s", "encrypted images/sec (ResNet-20 CIFAR-10, N=2^16)"
         workload = ("C4 (BASELINE configs[3]): ACE-compiled ResNet-20/CIFAR-10 encrypted inference, N=2^16, L=34, dnum=3, "
-                    "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and synthetic weights "
-                    "N(0,0.05); %d concurrent image stream(s) per GPU (host threads attached to one context and key set, one HIP stream "
+                    "19 bootstraps, 227 rotation keys, 6044 weight plaintexts; synthetic image U(-1,1) and %s; "
+                    "%d concurrent image stream(s) per GPU (host threads attached to one context and key set, one HIP stream "
                     "each) x batches of %d images per launch (the reference's own parallel axis is one OpenMP thread per image on "
                     "shared keys and weights: the images of a batch share launches, keys, twiddles and weight plaintexts); a step = "
-                    "one batch per stream" % (n_streams, n_batch))
+                    "one batch per stream" % (weights_note, n_streams, n_batch))
         if r110:
             metric = "encrypted images/sec (ResNet-110 CIFAR-10, N=2^16) -- secondary measurement, not the BASELINE headline"
             workload = ("the workload of BASELINE configs[4] (ACE-compiled ResNet-110/CIFAR-10, resnet110_cifar10_train.onnx.inc: N=2^16, "
@@ -669,7 +737,7 @@ def main():
         read_stats(reset=True)
     t0 = time.perf_counter()
     if use_model:
-        logits = step(args.steps)  # every stream runs its K images back to back; the region ends when all are done
+        logits = step(args.steps, verify=fix is not None)  # every stream runs its K batches back to back; the region ends when all are done
     else:
         for _ in range(args.steps):
             logits = step()
@@ -682,6 +750,28 @@ def main():
         stats = read_stats(reset=False)
     barrier()
     elapsed = ranks.max_over_ranks(elapsed_local)
+    verification = None
+    if use_model and not r110:
+        verification = {"verified": None, "note": verify_note}
+        if fix is not None:
+            import glob
+            import hashlib
+
+            got = []
+            for i in range(n_streams):
+                path = "%s_s%d.%d" % (verify_prefix, i, i % n_batch)
+                got.append(hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None)
+            for f in glob.glob(verify_prefix + "_s*"):
+                os.remove(f)
+            ok_here = 1.0 if all(g == fix["digest"] for g in got) else 0.0
+            ok_all = -ranks.max_over_ranks(-ok_here)
+            verification = {
+                "verified": bool(ok_all),
+                "what": "inside the timed region: the first batch of every image stream of every rank carries the fixture's image (batch "
+                        "position = stream index) under the fixture's key set and encryption randomness; sha256 of its output ciphertext "
+                        "(ACEHCT01) against the digest of the REFERENCE rtlib's CPU run of the same unchanged program "
+                        "(tests/golden/gen_parity.json, tests/c/gen_parity_ref.c)",
+                "reference_digest": fix["digest"], "digests_rank0": got, "streams_checked_per_rank": n_streams, "ranks": world}
     value = world * n_streams * n_batch * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
@@ -708,12 +798,6 @@ def main():
         for t in threads:
             t.join()
         fhe.Finalize_context()
-    shard_leg = None
-    force_leg = os.environ.get("ACEHIP_BENCH_FORCE_SHARD_LEG") == "1"  # test hook: exercise the leg's plumbing with one rank
-    if (world > 1 or force_leg) and use_model and not r110 and not args.no_shard_leg:
-        shard_leg = limb_sharded_leg(ranks)  # (after the timed region; the model context above has released its memory; never raises
-        #                                       before its three reductions are through: every failure path is an "error" entry)
-
     # ---------------- roofline of the dominant kernel family: batched forward NTT ----------------
     n_polys = 2 * N_CT
     batch = rt.buf(n_polys * poly_words)
@@ -821,10 +905,11 @@ def main():
                 "us_per_limb_transform": (round(ntt_kernel_s / n_lt * 1e6, 4) if (ntt_kernel_s and n_lt) else None),
                 "best_case_batch_us_per_limb_transform": round((fwd_ms + inv_ms) / 2 * 1e3 / limbs, 4),
                 "GBs_algorithmic": (round(n_lt * 16 * N / ntt_kernel_s / 1e9, 1) if (ntt_kernel_s and n_lt) else None)}
+        if verification is not None:
+            out["verified"] = verification["verified"]
+            out["verification"] = verification
         if cache_run is not None:
             out["with_plaintext_cache"] = cache_run
-        if shard_leg is not None:
-            out["limb_sharded"] = shard_leg
         if logits is not None:
             out["config"]["last_logits"] = [round(v, 5) for v in logits]
         if args.roofline_only:
@@ -841,6 +926,19 @@ def main():
                 out["cpu_baseline"]["gpu_over_cpu_measured"] = round(value / cpu_res["value"], 1)
                 out["cpu_baseline"]["gpu_over_one_socket"] = round(value / ref_v, 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    # Secondary and opt-in, AFTER the headline line is on fd 1 (a failure or a hang of it can no longer delay or lose the line):
+    # ACEHIP_BENCH_SHARD_LEG=1 with --gpus N > 1 runs one ResNet-20 image limb-sharded over the same ranks (child processes, own
+    # communicator, bounded by a timeout).  Its result goes to stderr ("[bench] limb_sharded {...}") and, where gpurun_out/ exists,
+    # to gpurun_out/limb_sharded_leg.json -- never into the headline line.
+    force_leg = os.environ.get("ACEHIP_BENCH_FORCE_SHARD_LEG") == "1"  # test hook: exercise the leg's plumbing with one rank
+    want_leg = (world > 1 and os.environ.get("ACEHIP_BENCH_SHARD_LEG") == "1" and not args.no_shard_leg) or force_leg
+    if want_leg and use_model and not r110:
+        shard_leg = limb_sharded_leg(ranks)  # (never raises before its three reductions are through: every failure path is an "error" entry)
+        if rank == 0 and shard_leg is not None:
+            sys.stderr.write("[bench] limb_sharded " + json.dumps(shard_leg) + "\n")
+            sys.stderr.flush()
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                json.dump(shard_leg, open(os.path.join(ROOT, "gpurun_out", "limb_sharded_leg.json"), "w"), indent=1)
     ranks.close()
     rt.close()
 

@@ -26,6 +26,10 @@ size_t     Acehip_rt_prefetched_count(void);
  * so ACEHIP_SEED + this call make the ciphertext of an input -- and with it every output of Main_graph -- reproducible whichever
  * thread, stream or image batch carries it (tests/test_gpu_gen_parity.py, bench.py "verified"). */
 void       Acehip_rt_seed_encryptor(uint64_t seed);
+/* Extension: the calling thread's next Set_output_data also writes its ciphertext to <prefix>.<image> (ACEHCT01; one file per image
+ * of the batch).  One shot, per thread.  (ACEHIP_DUMP_OUTPUT=<prefix> in the environment does the same for every call of every thread:
+ * <prefix>.<call>.<image>.) */
+void       Acehip_rt_dump_next_output(const char* prefix);
 /* Extension: on-disk containers (the reference has none).  All return 0 or a negative code
  * (-1 cannot open, -2 truncated / wrong magic, -3 written for other CKKS parameters).
  *   "ACEHCT01" ciphertext / plaintext: u32 n_polys, N, level, num_p, is_ntt, slots, sf_degree, 0; f64 scaling_factor;

@@ -6,7 +6,7 @@ PRODUCT derives from ACEHIP_SEED and writes every Set_output_data ciphertext in 
 The fixture holds sha256 digests of those files -- data only.  tests/test_gpu_gen_parity.py runs the same unchanged programs
 against libFHErt_ant.so with the same seed (lazy queue on; image batches; poison mode) and must reproduce every digest.
 
-  usage: gen_gen_parity.py [examples] [resnet20] [resnet110]     (default: examples; the models take 0.5 h / 2.2 h of one core and
+  usage: gen_gen_parity.py [examples] [ksw] [resnet20] [resnet110]     (default: examples; the models take 0.5 h / 2.2 h of one core and
                                                                  44 GB, and are merged into the existing file)
 """
 import glob
@@ -50,6 +50,21 @@ def run_example(name, batch, skip, tmp):
     return d
 
 
+KSW_SETS = {"n1024_l7": "1024 6 60 50 3", "n4096_resnet_primes": "4096 33 51 50 3", "n65536_resnet20": "65536 33 51 50 3"}
+
+
+def run_ksw(args, tmp):
+    """tests/c/ksw_variants.c against the reference: digests of the four BASE forms + which OPT forms have the base form's bytes"""
+    d = os.path.join(tmp, "ksw_" + args.replace(" ", "_"))
+    os.makedirs(d)
+    env = dict(os.environ, GEN_PARITY_SEED=str(SEED))
+    r = subprocess.run([os.path.join(EX, "refgen_ksw_variants"), d] + args.split(), capture_output=True, text=True, env=env, timeout=3600)
+    assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    verdicts = dict(re.findall(r"opt_vs_base (\w+) (EQUAL|DIFFERENT)", r.stdout))
+    assert len(verdicts) == 4
+    return {"args": args, "base": {os.path.basename(p)[:-3]: sha(p) for p in sorted(glob.glob(d + "/*.ct"))}, "opt_vs_base": verdicts}
+
+
 def run_model(key, tmp):
     """one image of the generated ResNet with the synthetic weight file of tools/make_weight_file.py (sigma from weights.json)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -84,6 +99,10 @@ def main():
                 # image k of a batch of B under an unchanged program = the k-th of B encryptions in a row from the thread's stream
                 data["examples"][name] = {"single": run_example(name, 1, 0, tmp), "batch3": {str(k): run_example(name, 3, k, tmp) for k in range(3)}}
                 print(name, data["examples"][name]["single"])
+        if "ksw" in what:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refgen"])
+            data["ksw_variants"] = {name: run_ksw(args, tmp) for name, args in KSW_SETS.items()}
+            print(data["ksw_variants"])
         for key in MODELS:
             if key in what:
                 data.setdefault("models", {})[key] = run_model(key, tmp)

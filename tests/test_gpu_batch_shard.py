@@ -100,16 +100,17 @@ def _mock_rccl(tmp):
     return so
 
 
-def _run_ranks(exe, args, world, env_extra, tmp, tag, timeout=1500):
+def _run_ranks(exe, args, world, env_extra, tmp, tag, timeout=1500, one_gpu_per_rank=False):
     """the program once per rank, concurrently, as a launcher would start it (ACEHIP_SHARD=1 + RANK / WORLD_SIZE / LOCAL_RANK);
-    every process uses GPU 0 and exchanges limbs through the library named by ACEHIP_RCCL_LIB"""
+    every process uses GPU 0 and exchanges limbs through the library named by ACEHIP_RCCL_LIB -- or, with one_gpu_per_rank, rank r
+    uses GPU r and the real librccl"""
     port = str(29600 + os.getpid() % 300)
     id_file = os.path.join(str(tmp), tag + ".rccl_id")
     procs = []
     for r in range(world):
         prefix = os.path.join(str(tmp), "%s_r%d" % (tag, r))
         env = dict(os.environ, ACEHIP_SEED="20261004", ACEHIP_DUMP_OUTPUT=prefix, ACEHIP_SHARD="1", RANK=str(r), WORLD_SIZE=str(world),
-                   LOCAL_RANK="0", MASTER_PORT=port, ACEHIP_SHARD_ID_FILE=id_file, ACEHIP_PROFILE="1", **env_extra)
+                   LOCAL_RANK=str(r) if one_gpu_per_rank else "0", MASTER_PORT=port, ACEHIP_SHARD_ID_FILE=id_file, ACEHIP_PROFILE="1", **env_extra)
         procs.append((prefix, subprocess.Popen([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
     outs = []
     for prefix, p in procs:
@@ -167,6 +168,34 @@ def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
             assert dumps["0.%d" % i] == plain["%d.0" % i], "rank %d: image %d of a sharded batch differs from its unsharded single run" % (r, i)
 
 
+def _gpu_count():
+    import torch
+
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: real RCCL refuses two ranks on one device (the one-GPU test box runs the "
+                                              "same programs over tests/c/mock_rccl.c above)")
+def test_two_real_rccl_ranks_are_bit_identical(tmp_path):
+    """The day a node is there: eg_rotate, eg_bootstrap and one ResNet-20 image with their limbs spread over TWO GPUs, one process each,
+    the exchanges of Decomp_modup / Mod_down / Rescale / ModRaise / decode as real ncclBroadcast calls over xGMI (root != self for half
+    of the limbs) -- every rank's output ciphertext equals the unsharded run's, and bytes were received."""
+    for name in ("rotate", "bootstrap"):
+        exe = os.path.join(EX_DIR, "eg_" + name)
+        _need(exe)
+        _, plain = _run(exe, [], {}, tmp_path, "plain_" + name)
+        for r, (out, dumps) in enumerate(_run_ranks(exe, [], 2, {}, tmp_path, "rccl2_" + name, one_gpu_per_rank=True)):
+            assert "SUCESS!" in out and dumps == plain, "rank %d: eg_%s differs from the unsharded run" % (r, name)
+            line = [ln for ln in out.splitlines() if "limb exchanges:" in ln]
+            assert line and int(line[0].split("limb exchanges:")[1].split()[0]) > 0, out[-2000:]
+    exe = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+    _need(exe)
+    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
+    _, plain = _run(exe, ["1"], env, tmp_path, "plain_r20", timeout=1200)
+    for r, (out, dumps) in enumerate(_run_ranks(exe, ["1"], 2, env, tmp_path, "rccl2_r20", one_gpu_per_rank=True)):
+        assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 over two GPUs differs from the unsharded run" % r
+
+
 def test_bench_shard_mode_one_rank_joins_rccl():
     """`bench.py --mode shard` (what torchrun starts once per GPU for BASELINE configs[4]) with a single rank: the rt_ant shim
     loads librccl, creates and joins its own communicator (ACEHIP_SHARD=1: id file, ncclCommInitRank), runs the generated
@@ -187,10 +216,11 @@ def test_bench_shard_mode_one_rank_joins_rccl():
     assert d["shard"]["rccl_ranks"] == 1 and d["shard"]["owned_limbs_per_rank"] == [45] and d["shard"]["bytes_received_per_image_all_ranks"] == 0
 
 
-def test_bench_multi_gpu_line_carries_a_limb_sharded_leg():
-    """`bench.py --gpus N` (N > 1, the driver's scaling run) adds a `limb_sharded` object: the ranks run one ResNet-20 image
-    limb-sharded as child processes after the headline.  One GPU here, so the leg is forced with a single rank
-    (ACEHIP_BENCH_FORCE_SHARD_LEG=1): child start, environment, JSON hand-over, output digest and clean-up are the same code."""
+def test_bench_limb_sharded_leg_runs_after_the_headline_line():
+    """`ACEHIP_BENCH_SHARD_LEG=1 bench.py --gpus N` (N > 1): AFTER the headline line is printed the ranks run one ResNet-20 image
+    limb-sharded as child processes and report on stderr (never in the headline line, which a hang of the leg can then no longer
+    delay).  One GPU here, so the leg is forced with a single rank (ACEHIP_BENCH_FORCE_SHARD_LEG=1): child start, environment, JSON
+    hand-over, output digest and clean-up are the same code."""
     import json
     import sys
 
@@ -203,7 +233,10 @@ def test_bench_multi_gpu_line_carries_a_limb_sharded_leg():
                         "--warmup", "0"], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    leg = d["limb_sharded"]
+    assert "limb_sharded" not in d and d["value"] > 0
+    line = [ln for ln in r.stderr.splitlines() if ln.startswith("[bench] limb_sharded ")]
+    assert line, r.stderr[-3000:]
+    leg = json.loads(line[-1][len("[bench] limb_sharded "):])
     assert "error" not in leg, leg
     assert leg["ranks_succeeded"] and leg["output_ciphertexts_identical_on_all_ranks"] and leg["images_per_s"] > 0
     assert leg["shard"]["rccl_ranks"] == 1 and len(leg["last_logits"]) == 10

@@ -93,3 +93,135 @@ def test_generated_example_with_a_mechanism_switched_off(name, env, tmp_path):
     out, got = _run(os.path.join(EX_DIR, "eg_" + name), [], env, tmp_path, "off")
     assert "SUCESS!" in out
     assert got == FIX["examples"][name]["single"]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The benchmarked program itself: the ACE-generated ResNet-20 (rtlib/ant/dataset/resnet20_cifar10_pre.onnx.inc, unchanged; BASELINE
+# configs[3]).  FIX["models"]["resnet20"] is the REFERENCE rtlib's CPU run of it (dev container, 0.5 h of one core): key set and
+# encryption randomness of ACEHIP_SEED injected, synthetic weight file N(0, sigma) of tools/model_weights.py (sigma chosen so that the
+# logits are of order 0.1-1: profiles/r04a_sigma_sweep.txt), image 0 of tools/model_main.c.
+# ------------------------------------------------------------------------------------------------------------------------------
+import re
+import sys
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+MODEL = FIX.get("models", {}).get("resnet20")
+MODEL_EXE = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
+
+
+def _model_env(extra=None):
+    import model_weights
+
+    if MODEL is None:
+        pytest.skip("tests/golden/gen_parity.json has no resnet20 entry (tests/golden/gen_gen_parity.py resnet20)")
+    wfile, meta = model_weights.ensure("resnet20", MODEL["weights"]["sigma"])
+    if meta["md5"] != MODEL["weights"]["md5"]:
+        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    env = {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(MODEL["enc_seed"])}
+    env.update(extra or {})
+    return env
+
+
+def _logits9(stdout):
+    return [m.split() for m in re.findall(r"logits9:((?: -?\d+\.\d+)+)", stdout)]
+
+
+def test_resnet20_output_ciphertext_is_byte_identical_to_the_reference_cpu_run(tmp_path):
+    """one image through the lazy shim -- 2.5 M queued limb-ops, 170 k deferred fills, 19 bootstraps, 6 044 weight plaintexts:
+    the output ciphertext hashes to the reference's digest, the decrypted logits print the same nine decimals, and the reference's
+    bookkeeping lines (scripts/ace_pre.log:28) are reproduced"""
+    out, got = _run(MODEL_EXE, ["1"], _model_env(), tmp_path, "r20", timeout=1200)
+    assert got == MODEL["outputs"], "ResNet-20 output ciphertext differs from the reference rtlib's CPU run"
+    assert _logits9(out) == [["%.9f" % v for v in MODEL["logits9"]]]
+    assert max(abs(v) for v in MODEL["logits9"]) > 0.05   # real digits: the old N(0,0.05) weights gave logits of 1e-3
+    assert "rot_key_cnt = 227," in out and "Total memory size for weight plain: cnt = 6044," in out
+
+
+def test_resnet20_batches_of_3_and_12_and_three_threads_match_the_reference(tmp_path):
+    """what bench.py times is 3 image streams x 12 images per launch.  12 images one by one, in batches of 3, as one batch of 12: every
+    image's output ciphertext is the same bytes in all three runs (image i is encrypted with the randomness of seed + i whatever
+    carries it), and image 0 -- the reference's image -- hashes to the reference's digest.  Three OpenMP threads on one context
+    (tools/model_main_omp.c, the reference's own main structure, resnet_cifar.main.inc:77-116), each running that image: three times
+    the reference's digest."""
+    env = _model_env()
+    _, d1 = _run(MODEL_EXE, ["12"], env, tmp_path, "b1", timeout=1500)
+    _, d3 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="3"), tmp_path, "b3", timeout=1500)
+    _, d12 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="12"), tmp_path, "b12", timeout=1500)
+    assert d1["0.0"] == MODEL["outputs"]["0.0"]
+    assert len(set(d1.values())) == 12
+    for i in range(12):
+        assert d3["%d.%d" % (i // 3, i % 3)] == d1["%d.0" % i], "image %d differs in batches of 3" % i
+        assert d12["0.%d" % i] == d1["%d.0" % i], "image %d differs in a batch of 12" % i
+    omp = os.path.join(EX_DIR, "modelomp_resnet20_cifar10_pre")
+    prefix = os.path.join(str(tmp_path), "omp")
+    r = subprocess.run([omp, "3"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, ACEHIP_SEED=str(FIX["seed"]), OMP_NUM_THREADS="3", MODEL_DUMP_PREFIX=prefix, **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(glob.glob(prefix + ".img*"))
+    assert len(files) == 3 and all(_sha(f) == MODEL["outputs"]["0.0"] for f in files)
+
+
+def test_resnet20_logits_with_independent_keys_agree_to_ckks_precision(tmp_path):
+    """the tolerance-level check, now with digits: OUR random keys and encryption randomness (no seed), same weights and image --
+    the logits agree with the reference's to 1e-3 of the largest one (the reference examples' own tolerance, eg_fhertlib_relin.c:16-17)"""
+    env = dict(os.environ, **_model_env())
+    env.pop("MODEL_ENC_SEED")
+    r = subprocess.run([MODEL_EXE, "1"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = [float(x) for x in _logits9(r.stdout)[0]]
+    scale = max(abs(v) for v in MODEL["logits9"])
+    assert max(abs(a - b) for a, b in zip(got, MODEL["logits9"])) <= 1e-3 * scale, (got, MODEL["logits9"])
+
+
+def test_a_single_changed_rotation_is_caught(tmp_path, capsys):
+    """negative control: the same program with ONE rotation amount changed (workloads/Makefile model_resnet20_perturbed) on the same
+    keys, weights and image -- the digest differs and the logits leave the tolerance of the previous test by orders of magnitude"""
+    exe = os.path.join(EX_DIR, "model_resnet20_perturbed")
+    out, got = _run(exe, ["1"], _model_env(), tmp_path, "pert", timeout=1200)
+    assert got["0.0"] != MODEL["outputs"]["0.0"]
+    bad = [float(x) for x in _logits9(out)[0]]
+    scale = max(abs(v) for v in MODEL["logits9"])
+    err = max(abs(a - b) for a, b in zip(bad, MODEL["logits9"]))
+    with capsys.disabled():
+        print("\n[negative control] one Rotate amount changed: max |logit - reference| = %.4f (tolerance of the parity test: %.6f)" % (err, 1e-3 * scale))
+    assert err > 20 * 1e-3 * scale
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The reference's key-switch optimisation unit tests (rtlib/ant/unittest/ut_ksw_opt.cxx:115-660) as a bit-level contract:
+# tests/c/ksw_variants.c, base forms through the rt_ant operator API.
+# ------------------------------------------------------------------------------------------------------------------------------
+KSW = FIX.get("ksw_variants", {})
+
+
+def _build_ksw(tmp):
+    import ace_compiler_amd  # noqa: F401
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = os.path.join(str(tmp), "ksw_variants")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-O1", os.path.join(ROOT, "tests", "c", "ksw_variants.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+                           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("name", sorted(KSW) or ["(no fixture)"])
+def test_key_switch_base_forms_match_the_reference(name, tmp_path):
+    """sum of rotations of one ciphertext, sum of rotations of three, multiply + relinearise + rescale, rotate-multiply-rescale-rotate:
+    our results have the bytes of the reference's BASE forms.  The fixture also records which of the reference's OPT forms are NOT
+    bit-equal to its own base forms (ModDown hoisted over a sum, ModDown merged with Rescale, both plus a hoisted ModUp): a runtime
+    must not "optimise" into those -- only the hoisted ModUp keeps the bits, and that one the runtime does (rt_poly.cpp ModupCache)."""
+    if not KSW:
+        pytest.skip("tests/golden/gen_parity.json has no ksw_variants entry (tests/golden/gen_gen_parity.py ksw)")
+    exe = _build_ksw(tmp_path)
+    d = tmp_path / "out"
+    d.mkdir()
+    for env_extra in ({}, {"ACEHIP_MODUP_REUSE": "0"}):
+        r = subprocess.run([exe, str(d)] + KSW[name]["args"].split(), capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, ACEHIP_SEED=str(FIX["seed"]), **env_extra))
+        assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        got = {os.path.basename(p)[:-3]: _sha(p) for p in sorted(glob.glob(str(d) + "/*.ct"))}
+        assert got == KSW[name]["base"]
+    assert KSW[name]["opt_vs_base"] == {"modup_hoist": "EQUAL", "moddown_hoist": "DIFFERENT", "moddown_rescale": "DIFFERENT",
+                                        "moddown_rescale_modup": "DIFFERENT"}

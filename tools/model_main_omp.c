@@ -1,13 +1,18 @@
 /* model_main_omp.c -- the structure of the reference's model main (rtlib/ant/dataset/resnet_cifar.main.inc:77-116)
  * without its CIFAR reader: Prepare_context once, then `#pragma omp parallel for` over images with Prepare_input /
  * Run_main_graph / Handle_output per thread, Finalize_context once.  Worker threads never call Prepare_context: they
- * attach to the prepared context on first use.  Build: gcc -fopenmp -DMODEL_INC='"....onnx.inc"' ... */
+ * attach to the prepared context on first use.  Build: gcc -fopenmp -DMODEL_INC='"....onnx.inc"' ...
+ * MODEL_ENC_SEED=<s>: every iteration encrypts with the randomness of seed s (the same image: the same ciphertext);
+ * MODEL_DUMP_PREFIX=<p>: iteration i writes its output ciphertext to <p>.img<i>.0 (Acehip_rt_dump_next_output). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
 
 #include "common/rtlib.h"
+
+void Acehip_rt_seed_encryptor(uint64_t seed); /* include/rt_ant/rt_api.h */
+void Acehip_rt_dump_next_output(const char* prefix);
 
 static double now_s() {
   struct timespec t;
@@ -29,8 +34,14 @@ int main(int argc, char* argv[]) {
       z ^= z << 13; z ^= z >> 7; z ^= z << 17;
       in->_vals[i] = (double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0;
     }
+    if (getenv("MODEL_ENC_SEED")) Acehip_rt_seed_encryptor(strtoull(getenv("MODEL_ENC_SEED"), NULL, 10));
     Prepare_input(in, "input");
     Free_tensor(in);
+    if (getenv("MODEL_DUMP_PREFIX")) {
+      char prefix[1024];
+      snprintf(prefix, sizeof prefix, "%s.img%d", getenv("MODEL_DUMP_PREFIX"), img);
+      Acehip_rt_dump_next_output(prefix);
+    }
     Run_main_graph();
     double* out = Handle_output("output");
 #pragma omp critical
