@@ -125,6 +125,19 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
       if (!ctx->dc.tw8_max_polys) ctx->dc.twp_fwd = ctx->dc.twp_inv = nullptr;
     }
   }
+  if (hp.logN == 16) {  // FP64 butterflies for the 48..50-bit scaling primes (ntt_fp.hpp); ACEHIP_NTT_FP=0: integer classes only
+    const char* e = getenv("ACEHIP_NTT_FP");
+    bool any = false;
+    for (u32 i = 0; i < T; ++i) any = any || hp.primes[i].q < 1266637395197952ull;  // kFpPrimeMax
+    if ((!e || atoi(e) != 0) && any) {
+      std::vector<double> twd((size_t)T * hp.N);
+      for (size_t i = 0; i < twd.size(); ++i) twd[i] = (double)hp.rou[i];  // (exact wherever the class is used: w < q < 2^53)
+      ctx->dc.twd_fwd = ctx->up(twd);
+      for (size_t i = 0; i < twd.size(); ++i) twd[i] = (double)hp.rou_inv[i];
+      ctx->dc.twd_inv = ctx->up(twd);
+      if (!ctx->dc.twd_fwd || !ctx->dc.twd_inv) ctx->dc.twd_fwd = ctx->dc.twd_inv = nullptr;
+    }
+  }
   {  // ACEHIP_NTT_NARROW = largest launch (limb rows) that takes the narrow small-launch passes (0: never)
     const char* e = getenv("ACEHIP_NTT_NARROW");
     ctx->dc.ntt_narrow_max_rows = e ? (u32)strtoul(e, nullptr, 0) : 16u;

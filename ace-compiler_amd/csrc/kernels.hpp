@@ -32,6 +32,10 @@ struct DevCtx {
   const u64* twp_fwd = nullptr;
   const u64* twp_inv = nullptr;
   u32 tw8_max_polys = 0;
+  // the twiddles as doubles [L+K][N] (ntt_fp.hpp: FP64 butterflies for the primes below 2^50.17 in the wide N = 2^16 passes);
+  // null: every limb takes the integer classes (ACEHIP_NTT_FP=0, other ring sizes)
+  const double* twd_fwd = nullptr;
+  const double* twd_inv = nullptr;
   // ---- replicas.  The caller's polynomial memory (the rt_ant shim's pool arena) may exist several times, rep_stride bytes
   // apart: one copy per image of a batch (the GPU form of the reference's image-parallel loop, resnet_cifar.main.inc:77-116:
   // B images run through the same launches and share every key, twiddle, bootstrap diagonal and weight plaintext), or one

@@ -26,6 +26,7 @@
 
 #include "device_arith.hpp"
 #include "kernels.hpp"
+#include "ntt_fp.hpp"
 
 namespace acehip {
 
@@ -376,6 +377,7 @@ __device__ __forceinline__ u32 cpad(u32 rho) { return rho + (rho >> 4); }
 struct StridedArgs {
   LimbBuf buf;
   const ulong2* __restrict__ TW;
+  const double* __restrict__ TWD;  // the limb's twiddles as doubles (FP class, ntt_fp.hpp)
   u64* lds;
   u32 cc, hg, col;
   u64 q;
@@ -390,15 +392,12 @@ struct StridedArgs {
 // (encode), SRC_CONV8/12 the fast base conversion of up to 8/12 coefficient-domain source limbs (ModUp / ModDown: the
 // converted limbs are never written in coefficient form; 16 sources would spill registers: those take the separate kernel)
 enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV8 = 8, SRC_CONV12 = 12 };
-template <bool SMALL, int SRC>
-__device__ __forceinline__ void strided_fwd_body(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
-                                                 u32 row, u32 z, u32 rep, u32 n_bytes, u32 split_bits) {
+// canonical input of the forward strided pass, rows 16k+hg of the workgroup's tile (SRC: see above)
+template <int SRC>
+__device__ __forceinline__ void strided_fwd_source(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
+                                                   u32 row, u32 z, u32 rep, u32 n_bytes, u32 split_bits, u64 (&x)[16]) {
   constexpr bool FROM_MSG = SRC == SRC_MSG;
   const u64 q = a.q;
-  const BfK bk = bf_consts<SMALL>(q);
-  u64 x[16];
-  Tw t0, t1[2], t2[4], t3[8];
-  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch (no hoisting / merging across paths)
   if (FROM_MSG) {  // the signed message, reduced mod this limb's prime (and scaled): Encode_impl ckks_encoder.c:262-285
     const u64 sc = f.msg_scale ? f.msg_scale[pos] : 0;
     const LimbBuf mbuf = limb_buf(reinterpret_cast<const u64*>(reb(c, f.msg, rep) + z * f.msg_stride), n_bytes);
@@ -452,6 +451,17 @@ __device__ __forceinline__ void strided_fwd_body(const DevCtx& c, const StridedA
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, (a.hg << 11) + a.col * 8, (u32)k << 15);  // row 16k+hg, row pitch 2 KiB
   }
+}
+
+template <bool SMALL, int SRC>
+__device__ __forceinline__ void strided_fwd_body(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
+                                                 u32 row, u32 z, u32 rep, u32 n_bytes, u32 split_bits) {
+  const u64 q = a.q;
+  const BfK bk = bf_consts<SMALL>(q);
+  u64 x[16];
+  Tw t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch (no hoisting / merging across paths)
+  strided_fwd_source<SRC>(c, a, P, f, pos, row, z, rep, n_bytes, split_bits, x);
   load_tw_uniform<SMALL>(a.TW, t0, t1, t2, t3);  // round A: stages 0..3 (uniform twiddles TW[1..15])
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
@@ -514,6 +524,87 @@ __device__ __forceinline__ void strided_inv_body(u64* __restrict__ X, const ulon
   asm volatile("" ::: "memory");
 }
 
+// ---- FP class (ntt_fp.hpp): the same passes with FP64 butterflies.  Layouts, LDS traffic and twiddle indices are those of the
+// integer bodies; x[] holds integer-valued doubles, the LDS tile and the intermediate between the passes their bit patterns.
+template <int SRC>
+__device__ __forceinline__ void strided_fwd_body_fp(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
+                                                    u32 row, u32 z, u32 rep, u32 n_bytes, u32 split_bits) {
+  const FpK k = fp_consts(a.q);
+  double x[16], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+  {
+    u64 xi[16];
+    strided_fwd_source<SRC>(c, a, P, f, pos, row, z, rep, n_bytes, split_bits, xi);  // canonical residues
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fp_from_u64(xi[i]);
+  }
+  fp_load_tw_uniform(a.TWD, t0, t1, t2, t3);  // round A: stages 0..3
+  fp_radix16_fwd(x, t0, t1, t2, t3, k);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a.lds[(16 * i + a.hg) * kRowPitch + a.cc] = fp_bits(x[i]);
+  fp_load_tw(a.TWD, 4, a.hg, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(a.lds[(16 * a.hg + i) * kRowPitch + a.cc]);
+  fp_radix16_fwd(x, t0, t1, t2, t3, k);  // round B: stages 4..7
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bst(a.buf, (a.hg << 15) + a.col * 8, (u32)i << 11, fp_bits(x[i]));  // |v| <= 0.51q, as doubles
+  asm volatile("" ::: "memory");
+}
+
+// inverse: input = the contiguous FP pass' doubles (|v| <= 0.51q); canonical (or centred) u64 output
+__device__ __forceinline__ void strided_inv_body_fp(u64* __restrict__ X, const double* __restrict__ TWD, u64* lds, const DevPrime& P,
+                                                    const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
+  constexpr u32 log_s = 8;
+  const u64 q = P.q;
+  const FpK k = fp_consts(q);
+  double x[16], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(ntld(&X[((size_t)(16 * hg + i) << log_s) + col]));
+  fp_load_tw(TWD, 4, hg, t0, t1, t2, t3);
+  fp_radix16_inv_321(x, t1, t2, t3, k);
+  fp_radix16_inv_0(x, t0, k);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds[(16 * hg + i) * kRowPitch + cc] = fp_bits(x[i]);
+  fp_load_tw_uniform(TWD, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(lds[(16 * i + hg) * kRowPitch + cc]);
+  fp_radix16_inv_321(x, t1, t2, t3, k);  // |v| <= 2.53q
+  // stage 0 with N^-1 (or the caller's scale) folded into its two multiplications, as in strided_inv_body
+  u64 un = P.n_inv, uw = P.inv_w1_ninv;
+  if (f.inv_scale) {
+    const u64* sc = f.inv_scale + 4 * (size_t)pos;
+    un = sc[0];
+    uw = sc[2];
+  }
+  const double tn = fp_from_u64(un), tw = fp_from_u64(uw);
+  const double half = fp_from_u64(q >> 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double s = x[i] + x[i + 8], d = x[i] - x[i + 8];  // |.| <= 5.06q
+    double a = fp_canon_f(fp_mulmod(s, tn, k), k), b = fp_canon_f(fp_mulmod(d, tw, k), k);
+    if (f.center_out) {  // the centred lift, as the two's complement the integer path stores
+      a = a > half ? a - k.q : a;
+      b = b > half ? b - k.q : b;
+      x[i] = a;
+      x[i + 8] = b;
+    } else {
+      x[i] = a;
+      x[i + 8] = b;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    u64 v;
+    if (f.center_out) v = (u64)(int64_t)x[i];  // |x| < 2^50: exact
+    else              v = fp_to_u64(x[i]);
+    ntst(&X[((size_t)(16 * i + hg) << log_s) + col], v);
+  }
+  asm volatile("" ::: "memory");
+}
+
 // (uniform64: a load issued after stores of the same kernel is a vector load even when its address is uniform)
 // One resolved workgroup of a pass: tile of limb row y of polynomial z, the limb's position / prime
 struct NttWg {
@@ -551,13 +642,17 @@ __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ 
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
   const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
   const u32 col = w.tile * 16 + cc;  // N = 2^16 only (launch_ntt_fused): constant row stride, addresses = one base + immediates
+  const double* __restrict__ TWD = c.twd_fwd ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
+  const bool fp = TWD != nullptr && q < kFpPrimeMax;  // FP class: both passes of the transform decide alike (wave-uniform)
   if (!INVERSE) {
-    const StridedArgs a{limb_buf(X, c.N * 8), TW, lds, cc, hg, col, q};
-    if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
-    else                     strided_fwd_body<false, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
+    const StridedArgs a{limb_buf(X, c.N * 8), TW, TWD, lds, cc, hg, col, q};
+    if (fp)                       strided_fwd_body_fp<SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
+    else if (q <= kSmallPrimeMax) strided_fwd_body<true, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
+    else                          strided_fwd_body<false, SRC>(c, a, P, f, w.pos, w.y, w.z, w.rep, c.N * 8, c.split_bits);
   } else {
-    if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, w.pos, cc, hg, col);
-    else                     strided_inv_body<false>(X, TW, lds, P, f, w.pos, cc, hg, col);
+    if (fp)                       strided_inv_body_fp(X, TWD, lds, P, f, w.pos, cc, hg, col);
+    else if (q <= kSmallPrimeMax) strided_inv_body<true>(X, TW, lds, P, f, w.pos, cc, hg, col);
+    else                          strided_inv_body<false>(X, TW, lds, P, f, w.pos, cc, hg, col);
   }
 }
 
@@ -670,10 +765,66 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
   asm volatile("" ::: "memory");
 }
 
+// ---- FP class, contiguous pass.  forward: input = the strided FP pass' doubles; x[] returns the canonical u64 residues of the 16
+// contiguous rho = 16*lo4+k, like contig_fwd_body
+__device__ __forceinline__ void contig_fwd_body_fp(const u64* __restrict__ X, const double* __restrict__ TWD, u64* lds, u32 s8, u32 o, u32 b,
+                                                   u32 lo4, u64 q, u64 (&xo)[16]) {
+  const FpK k = fp_consts(q);
+  double x[16], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(ntld(&X[b * 256 + 16 * i + lo4]));
+  fp_load_tw(TWD, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
+  fp_radix16_fwd(x, t0, t1, t2, t3, k);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds[b * kBlkPitch + 17 * i + lo4] = fp_bits(x[i]);
+  fp_load_tw(TWD, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(lds[b * kBlkPitch + 17 * lo4 + i]);
+  fp_radix16_fwd(x, t0, t1, t2, t3, k);  // round B; |v| <= 0.51q
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xo[i] = fp_to_u64(x[i] < 0 ? x[i] + k.q : x[i]);
+}
+
+// inverse: canonical u64 input from S (coalesced through LDS, as contig_inv_body), output doubles |v| <= 0.51q for the strided FP pass
+__device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u64* __restrict__ S, const double* __restrict__ TWD, u64* lds,
+                                                   u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
+  const FpK k = fp_consts(q);
+  const u32 tid = threadIdx.x;
+  double x[16], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
+    const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
+    const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+    lds[bb * kBlkPitch + cpad(rho)] = vv.x;
+    lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
+  }
+  fp_load_tw(TWD, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_from_u64(lds[b * kBlkPitch + 17 * lo4 + i]);
+  fp_radix16_inv_321(x, t1, t2, t3, k);
+  fp_radix16_inv_0(x, t0, k);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds[b * kBlkPitch + 17 * lo4 + i] = fp_bits(x[i]);
+  fp_load_tw(TWD, s8, o, t0, t1, t2, t3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(lds[b * kBlkPitch + 17 * i + lo4]);
+  fp_radix16_inv_321(x, t1, t2, t3, k);
+  fp_radix16_inv_0(x, t0, k);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ntst(&X[b * 256 + 16 * i + lo4], fp_bits(x[i]));
+  asm volatile("" ::: "memory");
+}
+
 // CONTIG pass of one workgroup.
 // FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
 // f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
-template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8>
+template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8, bool FP_OK>
 __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
                                             u64* lds, const NttWg& w) {
   const DevPrime& P = c.primes[w.gi];
@@ -686,10 +837,15 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
   const u32 o = w.tile * 16 + b;
 
+  // FP class (ntt_fp.hpp): only where the OTHER pass of the transform is the wide strided pass (launch_ntt_fused sets FP_OK), never
+  // with CANON_OUT (the hybrid sizes, whose other stages are the generic integer kernel)
+  const double* __restrict__ TWD = (FP_OK && c.twd_fwd) ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
+  const bool fp = TWD != nullptr && q < kFpPrimeMax;
   if (!INVERSE) {
     u64 x[16];
-    if (q <= kSmallPrimeMax) contig_fwd_body<true, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
-    else                     contig_fwd_body<false, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    if (fp)                       contig_fwd_body_fp(X, TWD, lds, s8, o, b, lo4, q, x);
+    else if (q <= kSmallPrimeMax) contig_fwd_body<true, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    else                          contig_fwd_body<false, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
@@ -724,12 +880,13 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
   } else {
     const u64* __restrict__ S =
         FUSE ? reb(c, w.z ? f.src1 : f.src0, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
-    if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
-    else                     contig_inv_body<false, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
+    if (fp)                       contig_inv_body_fp(X, S, TWD, lds, s8, o, b, lo4, q);
+    else if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
+    else                          contig_inv_body<false, CANON_OUT, TW8>(X, S, TW, TP, lds, s8, o, b, lo4, q);
   }
 }
 
-template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8 = false>
+template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8 = false, bool FP_OK = false>
 __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                           u32 n_limbs, u32 n_polys) {
@@ -738,7 +895,7 @@ __global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __re
   NttWg w{blk.tile, blk.y, blk.z, 0, 0, 0};
   ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
-  contig_pass<INVERSE, CANON_OUT, FUSE, TW8>(c, poly, poly_stride, pos_off, f, lds, w);
+  contig_pass<INVERSE, CANON_OUT, FUSE, TW8, FP_OK>(c, poly, poly_stride, pos_off, f, lds, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1100,22 +1257,23 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
     else if (f.conv && f.conv_max_in <= 8)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV8>), ACEHIP_NTT_ARGS);
     else if (f.conv)               hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV12>), ACEHIP_NTT_ARGS);
     else                           hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MEM>), ACEHIP_NTT_ARGS);
+    // (FP_OK: the strided pass above was this transform's first pass, so limbs of the FP class arrive as doubles)
     if (tw8) {
-      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, true>), ACEHIP_NTT_ARGS);
-      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, true>), ACEHIP_NTT_ARGS);
-      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, true>), ACEHIP_NTT_ARGS);
+      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, true, true>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, true, true>), ACEHIP_NTT_ARGS);
+      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, true, true>), ACEHIP_NTT_ARGS);
     } else {
-      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1>), ACEHIP_NTT_ARGS);
-      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2>), ACEHIP_NTT_ARGS);
-      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0>), ACEHIP_NTT_ARGS);
+      if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, false, true>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, false, true>), ACEHIP_NTT_ARGS);
+      else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, false, true>), ACEHIP_NTT_ARGS);
     }
   } else {
     if (tw8) {
-      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, true>), ACEHIP_NTT_ARGS);
-      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, true>), ACEHIP_NTT_ARGS);
+      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, true, true>), ACEHIP_NTT_ARGS);
+      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, true, true>), ACEHIP_NTT_ARGS);
     } else {
-      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1>), ACEHIP_NTT_ARGS);
-      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0>), ACEHIP_NTT_ARGS);
+      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, false, true>), ACEHIP_NTT_ARGS);
+      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, false, true>), ACEHIP_NTT_ARGS);
     }
     hipLaunchKernelGGL((ntt8_strided_kernel<true, SRC_MEM>), ACEHIP_NTT_ARGS);
   }

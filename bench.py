@@ -827,6 +827,48 @@ def main():
     limbs = n_polys * T
     bytes_per_dir = 16 * N * limbs  # algorithmic: read + write every limb once
 
+    # the same two kernels on the HEADLINE workload's own primes (the generated ResNet-20: L=34, K=11, q0 51 bits, 33 scaling primes
+    # of 50 bits, 60-bit P primes): 1024-limb batches again, (a) the limb mix of a key-switch in the middle of the network -- 32
+    # PQ-extended polynomials at level 21: 20 scaling primes (FP64 butterflies, csrc/ntt_fp.hpp), limb 0 and 11 P-limbs (integer
+    # classes) -- and (b) scaling primes only (32 polynomials x limbs 1..32)
+    wl = None
+    if True:
+        rt2 = A.AceHip(65536, 34, 51, 50, 3, device=local_rank)
+        T2 = 34 + rt2.K
+        rng2 = np.random.default_rng(99 + rank)
+        host2 = np.empty((T2, N), dtype=np.uint64)
+        for l in range(T2):
+            host2[l] = rng2.integers(0, rt2.primes[l], size=N, dtype=np.uint64)
+
+        def time_batch(level, pos0, n_limbs, n_p=32):
+            words = n_limbs * N
+            buf = rt2.buf(n_p * words)
+            rows = [pos0 + i if pos0 + i < level else 34 + (pos0 + i - level) for i in range(n_limbs)]  # prime of every position
+            src = np.ascontiguousarray(host2[rows])
+            for p_ in range(n_p):
+                rt2.check(rt2.lib.acehip_memcpy_h2d(buf.at(p_ * words), src.ctypes.data, words * 8, None))
+            base = buf.ptr - pos0 * N * 8
+            f_ = lambda: rt2.check(rt2.lib.acehip_ntt_batch(rt2.h, base, words, n_p, level, pos0, n_limbs, 0, None))  # noqa: E731
+            i_ = lambda: rt2.check(rt2.lib.acehip_ntt_batch(rt2.h, base, words, n_p, level, pos0, n_limbs, 1, None))  # noqa: E731
+            for _ in range(2):
+                f_()
+                i_()
+            tf = ti = 0.0
+            for _ in range(reps):
+                tf += rt2.time_ms(f_, 1)
+                ti += rt2.time_ms(i_, 1)
+            got = np.empty_like(src)
+            rt2.check(rt2.lib.acehip_memcpy_d2h(got.ctypes.data, buf.at((n_p - 1) * words), words * 8, None))
+            if not os.environ.get("ACEHIP_BENCH_NO_VERIFY"):
+                assert np.array_equal(got, src), "NTT round trip over the timed batch is not the identity"
+            buf.free()
+            return tf / reps, ti / reps, n_p * n_limbs
+
+        mix_f, mix_i, mix_limbs = time_batch(21, 0, 32)
+        fp_f, fp_i, fp_limbs = time_batch(34, 1, 32)
+        wl = {"mix": (mix_f, mix_i, mix_limbs), "fp": (fp_f, fp_i, fp_limbs), "fp_on": os.environ.get("ACEHIP_NTT_FP", "1") != "0"}
+        rt2.close()
+
     if not args.roofline_only:
         for _ in range(3):
             ks()
@@ -834,6 +876,11 @@ def main():
     ks_bytes = lib.acehip_key_switch_bytes(h, L)
 
     if rank == 0:
+        # the roofline object reports the batch with the workload's own limb mix; the C3-parameter batch (56-bit primes, integer
+        # SMALL class: the figure of rounds 1-3) and the scaling-prime batch stay beside it
+        c3_fwd_ms, c3_inv_ms, c3_limbs = fwd_ms, inv_ms, limbs
+        fwd_ms, inv_ms, limbs = wl["mix"]
+        bytes_per_dir = 16 * N * limbs
         achieved = bytes_per_dir / (fwd_ms * 1e-3) / 1e9
         traffic = image_traffic = ntt_kernel_s = None
         traffic_src = {"file": "profiles/traffic.json", "status": "absent"}
@@ -872,7 +919,17 @@ def main():
                          "launch_ms": round(fwd_ms, 4), "inverse_launch_ms": round(inv_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_dir,
                          "ntt_fwd_inv_GBs": round(2 * bytes_per_dir / ((fwd_ms + inv_ms) * 1e-3) / 1e9, 2),
-                         "batch": "%d limbs (%d PQ-extended ciphertext pairs, L=25 K=7), 512 MiB" % (limbs, N_CT)},
+                         "batch": "%d limbs, 512 MiB: 32 PQ-extended polynomials at level 21 of the headline workload's parameter set (generated "
+                                  "ResNet-20: L=34, K=11) -- per polynomial 20 scaling primes of 50 bits (FP64 butterflies%s), limb 0 (51 bits) and "
+                                  "11 P-limbs of 60 bits (integer butterflies)" % (limbs, "" if wl["fp_on"] else " SWITCHED OFF: ACEHIP_NTT_FP=0"),
+                         "other_batches": {
+                             "scaling_primes_only": {"what": "32 polynomials x limbs 1..32 of the same set (50-bit primes only)", "limbs": wl["fp"][2],
+                                                     "launch_ms": round(wl["fp"][0], 4), "inverse_launch_ms": round(wl["fp"][1], 4),
+                                                     "frac": round(16 * N * wl["fp"][2] / (wl["fp"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                             "c3_parameter_set": {"what": "%d limbs (%d PQ-extended ciphertext pairs of BASELINE configs[2]: L=25 K=7, 56-bit scaling primes: "
+                                                          "integer butterflies; the roofline batch of rounds 1-3)" % (c3_limbs, N_CT), "limbs": c3_limbs,
+                                                  "launch_ms": round(c3_fwd_ms, 4), "inverse_launch_ms": round(c3_inv_ms, 4),
+                                                  "frac": round(16 * N * c3_limbs / (c3_fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}},
             "key_switch": {"workload": "C3 (BASELINE configs[2]): full key-switch N=2^16 L=25 dnum=4 K=7",
                            "ms": round(ks_ms, 4), "per_s": round(1e3 / ks_ms, 2), "algorithmic_bytes": int(ks_bytes),
                            "achieved_GBs": round(ks_bytes / (ks_ms * 1e-3) / 1e9, 2),

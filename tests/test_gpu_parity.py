@@ -389,19 +389,86 @@ def test_conv_fusion_matches():
     assert " passed" in r.stdout and "deselected" in r.stdout, r.stdout[-500:]
 
 
-@pytest.mark.parametrize("rows,tw8", [("0", "65535"), ("100000", "65535"), ("0", "0")], ids=["wide_only", "narrow_always", "wide_16byte_twiddles"])
-def test_ntt_tile_width_variants_match(rows, tw8):
+@pytest.mark.parametrize("cfg", [(65536, 20, 51, 50, 3, (20, 13)), (65536, 12, 51, 48, 2, (12, 9))], ids=["delta50", "delta48"])
+def test_fp_class_ntt_n65536(cfg):
+    """The 48..50-bit scaling primes take FP64 butterflies in the wide N = 2^16 passes (csrc/ntt_fp.hpp): the same bits as the oracle
+    (= the reference's canonical NTT, ntt.c:190-353) on random inputs, at the extreme values of every range argument of that arithmetic
+    (all q-1, zero, alternating 0 / q-1, a single 1, a single q-1), through the plain transforms (limb 0, 51 bits, and the 60-bit
+    P-limbs of the same launch stay on the integer classes) and through the fused neighbours: Mod_down / Rescale tails in the last
+    pass, out-of-place first inverse pass, all-digit ModUp, key-switch."""
+    N, L, q0, sf, dnum, levels = cfg
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        K = o.K
+        level = levels[0]
+        gis = [o.gidx(l, level) for l in range(level + K)]
+        qs = np.array([o.primes[g] for g in gis], dtype=np.uint64)[:, None]
+        x = o.uniform(level + K, level, 31)
+        cases = {"uniform": x, "all_qm1": np.broadcast_to(qs - np.uint64(1), x.shape).copy(), "zero": np.zeros_like(x)}
+        alt = np.zeros_like(x)
+        alt[:, ::2] = (qs - np.uint64(1))
+        cases["alternating"] = alt
+        one = np.zeros_like(x)
+        one[:, 1] = 1
+        cases["single_one"] = one
+        last = np.zeros_like(x)
+        last[:, N - 1] = (qs - np.uint64(1))[:, 0]
+        cases["single_qm1_last"] = last
+        for name, v in cases.items():
+            f = rt.ntt(v, level)
+            assert np.array_equal(f, o.ntt_fwd(v, gis)), name
+            assert np.array_equal(rt.ntt(v, level, inverse=True), o.ntt_inv(v, gis)), name
+            assert np.array_equal(rt.ntt(f, level, inverse=True), v), name
+        for level in levels:
+            x0, x1 = o.uniform(level + K, level, 271 + level), o.uniform(level + K, level, 272 + level)
+            e0, e1 = o.mod_down(x0, level), o.mod_down(x1, level)
+            assert np.array_equal(rt.mod_down(x0, level), e0)
+            d0, d1, r0, r1 = rt.to_device(x0), rt.to_device(x1), rt.buf(level * N), rt.buf(level * N)
+            rt.check(rt.lib.acehip_mod_down2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+            assert np.array_equal(r0.download((level, N)), e0) and np.array_equal(r1.download((level, N)), e1)
+            for d in (d0, d1, r0, r1):
+                d.free()
+            a0, a1 = o.uniform(level, level, 273 + level), o.uniform(level, level, 274 + level)
+            f0, f1 = o.rescale(a0, level), o.rescale(a1, level)
+            assert np.array_equal(rt.rescale(a0, level), f0)
+            d0, d1, r0, r1 = rt.to_device(a0), rt.to_device(a1), rt.buf((level - 1) * N), rt.buf((level - 1) * N)
+            rt.check(rt.lib.acehip_rescale2(rt.h, r0.ptr, r1.ptr, d0.ptr, d1.ptr, level, None))
+            assert np.array_equal(r0.download((level - 1, N)), f0) and np.array_equal(r1.download((level - 1, N)), f1)
+            for d in (d0, d1, r0, r1):
+                d.free()
+            nd = o.num_decomp(level)
+            da, de = rt.to_device(a0), rt.buf(nd * (level + K) * N)
+            rt.check(rt.lib.acehip_modup_digits(rt.h, de.ptr, da.ptr, level, None))
+            ext = de.download((nd, level + K, N))
+            for d in range(nd):
+                assert np.array_equal(ext[d], o.decomp_modup(a0, level, d)), (level, d)
+            da.free()
+            de.free()
+            key = o.make_key(2100)
+            c0, c1 = rt.key_switch(a0, key, level)
+            g0, g1 = o.key_switch(a0, key, level)
+            assert np.array_equal(c0, g0) and np.array_equal(c1, g1), level
+    finally:
+        rt.close()
+        o.close()
+
+
+@pytest.mark.parametrize("rows,tw8,fp", [("0", "65535", "1"), ("100000", "65535", "1"), ("0", "0", "1"), ("0", "65535", "0"), ("16", "65535", "0")],
+                         ids=["wide_only", "narrow_always", "wide_16byte_twiddles", "wide_only_integer_classes", "default_widths_integer_classes"])
+def test_ntt_tile_width_variants_match(rows, tw8, fp):
     """N = 2^16 transforms run as narrow passes (1024-coefficient tiles, ntt_fast.hip ntt4_*) up to ACEHIP_NTT_NARROW limb rows
     and as wide passes (4096-coefficient tiles) above: both must reproduce the reference-generated golden vectors and the
-    fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced -- and once with
-    the contiguous passes on the 16-byte twiddle tables (ACEHIP_NTT_TW8_POLYS=0) instead of the companion-only stream."""
+    fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced -- once with
+    the contiguous passes on the 16-byte twiddle tables (ACEHIP_NTT_TW8_POLYS=0) instead of the companion-only stream, and with the
+    FP64 butterflies of the small primes switched off (ACEHIP_NTT_FP=0: every limb on the integer classes)."""
     import subprocess
     import sys
 
-    env = dict(os.environ, ACEHIP_NTT_NARROW=rows, ACEHIP_NTT_TW8_POLYS=tw8)
+    env = dict(os.environ, ACEHIP_NTT_NARROW=rows, ACEHIP_NTT_TW8_POLYS=tw8, ACEHIP_NTT_FP=fp)
     tests = [os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_encode.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + tests + ["-k",
-                        "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536 or "
+                        "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536 or test_fp_class_ntt_n65536 or "
                         "(test_encode_matches_reference and n65536) or test_encode_batch_abi or (test_weight_prefetch and n65536)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
