@@ -539,6 +539,9 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the resident NTT batch of the roofline object (profiling aid: under rocprofv3 every ntt8_* "
                          "launch of the process then has the timed batch's size)")
+    ap.add_argument("--roofline-batch", choices=["all", "mix", "scaling", "c3"], default="all",
+                    help="with --roofline-only under a profiler: time only this one of the three 1024-limb NTT batches, so that every "
+                         "ntt8_* launch of the process is the roofline object's own batch (mix), the scaling-prime batch or the C3 batch")
     ap.add_argument("--streams", type=int, default=3,
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
@@ -826,20 +829,22 @@ def main():
     def inv():
         rt.check(lib.acehip_ntt_batch(h, batch.ptr, poly_words, n_polys, L, 0, T, 1, None))
 
-    for _ in range(2):
-        fwd()
-        inv()
     reps = 10
-    fwd_ms = inv_ms = 0.0
-    for _ in range(reps):
-        fwd_ms += rt.time_ms(fwd, 1)
-        inv_ms += rt.time_ms(inv, 1)
-    fwd_ms /= reps
-    inv_ms /= reps
-    back = np.empty((T, N), dtype=np.uint64)
-    rt.check(lib.acehip_memcpy_d2h(back.ctypes.data, batch.at((n_polys - 1) * poly_words), poly_words * 8, None))
-    if not os.environ.get("ACEHIP_BENCH_NO_VERIFY"):  # timing experiments with deliberately wrong kernels only
-        assert np.array_equal(back, host), "NTT round trip over the timed batch is not the identity"
+    fwd_ms = inv_ms = float("nan")
+    if args.roofline_batch in ("all", "c3"):
+        for _ in range(2):
+            fwd()
+            inv()
+        fwd_ms = inv_ms = 0.0
+        for _ in range(reps):
+            fwd_ms += rt.time_ms(fwd, 1)
+            inv_ms += rt.time_ms(inv, 1)
+        fwd_ms /= reps
+        inv_ms /= reps
+        back = np.empty((T, N), dtype=np.uint64)
+        rt.check(lib.acehip_memcpy_d2h(back.ctypes.data, batch.at((n_polys - 1) * poly_words), poly_words * 8, None))
+        if not os.environ.get("ACEHIP_BENCH_NO_VERIFY"):  # timing experiments with deliberately wrong kernels only
+            assert np.array_equal(back, host), "NTT round trip over the timed batch is not the identity"
     limbs = n_polys * T
     bytes_per_dir = 16 * N * limbs  # algorithmic: read + write every limb once
 
@@ -880,8 +885,9 @@ def main():
             buf.free()
             return tf / reps, ti / reps, n_p * n_limbs
 
-        mix_f, mix_i, mix_limbs = time_batch(21, 0, 32)
-        fp_f, fp_i, fp_limbs = time_batch(34, 1, 32)
+        nan3 = (float("nan"), float("nan"), 1024)
+        mix_f, mix_i, mix_limbs = time_batch(21, 0, 32) if args.roofline_batch in ("all", "mix") else nan3
+        fp_f, fp_i, fp_limbs = time_batch(34, 1, 32) if args.roofline_batch in ("all", "scaling") else nan3
         wl = {"mix": (mix_f, mix_i, mix_limbs), "fp": (fp_f, fp_i, fp_limbs), "fp_on": os.environ.get("ACEHIP_NTT_FP", "1") != "0"}
         rt2.close()
 

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRIES = {"resnet20": "resnet20_pt_entries.txt", "resnet110": "resnet110_pt_entries.txt"}
-SIGMA = {"resnet20": 0.2, "resnet110": 0.05}
+SIGMA = {"resnet20": 0.2, "resnet110": 0.01}
 SEED = 2
 
 

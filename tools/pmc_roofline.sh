@@ -1,18 +1,19 @@
 #!/bin/bash
 # Collects the roofline kernel's counters on the GPU box: three separate rocprofv3 --pmc passes (the TCC block cannot
-# hold FETCH_SIZE and WRITE_SIZE together; MI355X_MICROARCH.md "rocprofv3 PMC slots") over `bench.py --roofline-only`,
-# plus a --kernel-trace --stats pass.  usage (under gpurun): tools/pmc_roofline.sh <tag>   -> gpurun_out/<tag>/summary.json
+# hold FETCH_SIZE and WRITE_SIZE together; MI355X_MICROARCH.md "rocprofv3 PMC slots") over `bench.py --roofline-only --roofline-batch mix`,
+# plus a --kernel-trace --stats pass.  Only the roofline object's own batch is run (--roofline-batch mix:
+# the level-21 limb mix of the generated ResNet-20's parameter set), so every ntt8_* launch of the process has its size.  usage (under gpurun): tools/pmc_roofline.sh <tag>   -> gpurun_out/<tag>/summary.json
 set -u
 TAG=${1:-pmc}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --roofline-only > "$OUT/bench_trace.json" 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" --roofline-only > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" --roofline-only > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OUT/sq" -- python3 "$ROOT/bench.py" --roofline-only > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/tcc" -- python3 "$ROOT/bench.py" --roofline-only > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --roofline-only --roofline-batch mix > "$OUT/bench_trace.json" 2> /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/bench.py" --roofline-only --roofline-batch mix > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$ROOT/bench.py" --roofline-only --roofline-batch mix > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OUT/sq" -- python3 "$ROOT/bench.py" --roofline-only --roofline-batch mix > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/tcc" -- python3 "$ROOT/bench.py" --roofline-only --roofline-batch mix > /dev/null 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict

@@ -1,9 +1,13 @@
 #!/bin/bash
-# GPU box: logits of the generated ResNet-20 on synthetic weight files of growing sigma (tools/model_weights.py) -- picks SIGMA
+# GPU box: logits of a generated ResNet on synthetic weight files of growing sigma (tools/model_weights.py) -- picks SIGMA
+#   tools/sigma_sweep.sh <resnet20|resnet110> sigma...
 set -e
 mkdir -p gpurun_out
+KEY=$1; shift
+case $KEY in resnet20) EXE=model_resnet20_cifar10_pre;; resnet110) EXE=model_resnet110_cifar10_train;; esac
 for s in "$@"; do
-  f=$(python3 tools/model_weights.py resnet20 $s | python3 -c "import sys,ast; print(ast.literal_eval(sys.stdin.read())[0])")
-  echo "sigma $s"
-  ACEHIP_SEED=20261004 MODEL_ENC_SEED=1000 MODEL_DATA_FILE=$f ACEHIP_RT_DATA_FILE=$f workloads/_gen/examples/model_resnet20_cifar10_pre 1 2>&1 | grep -E "logits9|abort|error|Assert" || true
+  f=$(python3 tools/model_weights.py $KEY $s | python3 -c "import sys,ast; print(ast.literal_eval(sys.stdin.read())[0])")
+  echo "$KEY sigma $s"
+  ACEHIP_SEED=20261004 MODEL_ENC_SEED=1000 MODEL_DATA_FILE=$f ACEHIP_RT_DATA_FILE=$f workloads/_gen/examples/$EXE 1 2>&1 | grep -E "logits9|abort|error|Assert" || true
+  rm -f $f
 done

@@ -52,7 +52,7 @@ def main():
         "csrc_fingerprint": csrc_fingerprint.fingerprint(), "git_commit": commit, "images_per_batch": batch,
         "ntt_forward_bytes_per_launch": int(ntt_bytes),
         "ntt_source": "tools/pmc_roofline.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --roofline-only; FETCH_SIZE x2 "
-                      "(gfx950 correction); strided + contiguous forward pass of the 1024-limb batch",
+                      "(gfx950 correction); strided + contiguous forward pass of the 1024-limb batch of the roofline object (--roofline-batch mix)",
         "resnet20_bytes_per_image": int((tot(s2) - tot(s1)) / batch),
         "resnet20_launches_per_image": round(sum(f["launches"] for f in fam.values()), 1),
         "resnet20_kernel_seconds_per_image": {k: round(v, 5) for k, v in sorted(ksec.items(), key=lambda kv: -kv[1])},
