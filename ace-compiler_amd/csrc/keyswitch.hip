@@ -179,7 +179,13 @@ __device__ __forceinline__ u64 reduce80(u64 v0, u32 v1, u64 q, u64 ml, u32 m) {
 constexpr u32 kMfmaWaveCoeffs = 256, kMfmaWgCoeffs = 4 * kMfmaWaveCoeffs;
 
 template <int STEPS>
-__global__ __launch_bounds__(256) void base_conv_mfma_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
+#ifndef ACEHIP_CONV_MIN_WG
+#define ACEHIP_CONV_MIN_WG 1  // workgroups per CU the register allocation must leave room for (experiments: tools/kernel_ab.sh)
+#endif
+#ifndef ACEHIP_BSGS_MIN_WG
+#define ACEHIP_BSGS_MIN_WG 3  // measured (profiles/r04l_kernel_ab.txt): BSGS kernel time 0.931 -> 0.744 s per 24 images at 3 waves per SIMD (4: 0.844; conversion at 4: worse, spills)
+#endif
+__global__ __launch_bounds__(256, ACEHIP_CONV_MIN_WG) void base_conv_mfma_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                              const u64* __restrict__ in, size_t in_stride,
                                                              const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
   constexpr int NB = (int)kConvMfmaDigits;
@@ -360,10 +366,74 @@ __global__ __launch_bounds__(256) void key_mac_fused_kernel(DevCtx c, u64* acc0,
   *reinterpret_cast<ulong2*>(acc1 + pb + i) = r1;
 }
 
+// The same products for a launch that covers several replicas (image batches): the key is the same for every image, so one
+// workgroup keeps its 512 coefficients of the key limbs of all digits in registers and walks the replicas -- the key stream is read
+// once per launch instead of once per replica (measured through L2 it arrived 6 times at 12 images per launch: 378 of the 1 190 MB
+// a call moved, profiles/r04h_traffic.json).  ND = digits held (nd <= ND).
+template <int ND>
+__global__ __launch_bounds__(256) void key_mac_fused_reps_kernel(DevCtx c, u64* acc0, u64* acc1, const u64* key, const u64* ext,
+                                                                 size_t ext_stride, const u64* in, u32 level, u32 nd, u32 alpha,
+                                                                 const u64* add0, LimbConsts w) {
+  const u32 X = (c.N / 2 + 255) / 256;
+  const u32 pos = __builtin_amdgcn_readfirstlane(blockIdx.x / X), x = blockIdx.x % X;
+  const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const DevPrime P = c.primes[gi];
+  const size_t T = c.L + c.K;
+  const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
+  const u32 i = (x * 256 + threadIdx.x) * 2;
+  if (i >= c.N) return;
+  const u32 own = (in != nullptr && pos < level) ? pos / alpha : 0xffffffffu;
+  ulong2 k0[ND], k1[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const u32 dd = (u32)d < nd ? (u32)d : 0;  // (digits past nd: reload digit 0, never used)
+    const u64* k0p = key + ((size_t)dd * 2) * T * c.N + kb;  // (keys lie outside the arena: the same for every replica)
+    k0[d] = *reinterpret_cast<const ulong2*>(k0p + i);
+    k1[d] = *reinterpret_cast<const ulong2*>(k0p + T * c.N + i);
+  }
+  const u64 wl = (add0 != nullptr && pos < level) ? w.w[pos] : 0;
+  for (u32 r = 0; r < c.nrep; ++r) {
+    const u32 rep = c.rep0 + r;
+    const u64* ext_r = reb(c, ext, rep);
+    const u64* in_r = reb(c, in, rep);
+    ulong2 r0{0, 0}, r1{0, 0};
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      if ((u32)d < nd) {
+        const u64* e_src = ((u32)d == own) ? in_r + pb : ext_r + (size_t)d * ext_stride + pb;
+        const ulong2 e = *reinterpret_cast<const ulong2*>(e_src + i);
+        r0.x = add_mod(r0.x, mul_mod(k0[d].x, e.x, P), P.q);
+        r0.y = add_mod(r0.y, mul_mod(k0[d].y, e.y, P), P.q);
+        r1.x = add_mod(r1.x, mul_mod(k1[d].x, e.x, P), P.q);
+        r1.y = add_mod(r1.y, mul_mod(k1[d].y, e.y, P), P.q);
+      }
+    }
+    if (add0 != nullptr && pos < level) {
+      const ulong2 a = *reinterpret_cast<const ulong2*>(reb(c, add0, rep) + pb + i);
+      r0.x = add_mod(r0.x, mul_mod(a.x, wl, P), P.q);
+      r0.y = add_mod(r0.y, mul_mod(a.y, wl, P), P.q);
+    }
+    *reinterpret_cast<ulong2*>(reb(c, acc0, rep) + pb + i) = r0;
+    *reinterpret_cast<ulong2*>(reb(c, acc1, rep) + pb + i) = r1;
+  }
+}
+
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0, const LimbConsts* w) {
   ACEHIP_ABLATE(ABL_KEYMAC);
-  dim3 grid(((c.N / 2 + 255) / 256) * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
+  const u32 X = (c.N / 2 + 255) / 256;
+  // several replicas and a key outside the arena (the usual case: keys are shared by all images): the replica-walking form
+  static const bool reps_on = [] { const char* e = getenv("ACEHIP_KEYMAC_REPS"); return !e || atoi(e) != 0; }();
+  const bool key_shared = !((u64)key - c.rep_lo < c.rep_span);
+  if (reps_on && c.nrep > 1 && key_shared && nd <= 4) {
+    dim3 grid(X * (level + c.K)), block(256);
+    const LimbConsts lw = w ? *w : LimbConsts{};
+    if (nd <= 2) hipLaunchKernelGGL(key_mac_fused_reps_kernel<2>, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0, lw);
+    else         hipLaunchKernelGGL(key_mac_fused_reps_kernel<4>, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0, lw);
+    return;
+  }
+  dim3 grid(X * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0,
                      w ? *w : LimbConsts{});
 }
@@ -379,7 +449,7 @@ void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key,
 // below 2^122 each), so the result is the canonical residue of the exact sum whatever the order.
 // ------------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(256) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u32 level) {
+__global__ __launch_bounds__(256, ACEHIP_BSGS_MIN_WG) void bsgs_inner_kernel(DevCtx c, BsgsArgs a, u32 level) {
   const RepBlk rb = rep_block(c, (c.N / 2 + 255) / 256, level + c.K);  // replicas of a tile side by side: the diagonals are shared
   const u32 pos = rb.y;
   const u32 gi = limb_prime(pos, level, c.L);
