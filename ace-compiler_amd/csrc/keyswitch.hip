@@ -178,13 +178,13 @@ __device__ __forceinline__ u64 reduce80(u64 v0, u32 v1, u64 q, u64 ml, u32 m) {
 }
 constexpr u32 kMfmaWaveCoeffs = 256, kMfmaWgCoeffs = 4 * kMfmaWaveCoeffs;
 
-template <int STEPS>
 #ifndef ACEHIP_CONV_MIN_WG
 #define ACEHIP_CONV_MIN_WG 1  // workgroups per CU the register allocation must leave room for (experiments: tools/kernel_ab.sh)
 #endif
 #ifndef ACEHIP_BSGS_MIN_WG
 #define ACEHIP_BSGS_MIN_WG 3  // measured (profiles/r04l_kernel_ab.txt): BSGS kernel time 0.931 -> 0.744 s per 24 images at 3 waves per SIMD (4: 0.844; conversion at 4: worse, spills)
 #endif
+template <int STEPS>
 __global__ __launch_bounds__(256, ACEHIP_CONV_MIN_WG) void base_conv_mfma_kernel(DevCtx c, u64* __restrict__ out, size_t out_stride,
                                                              const u64* __restrict__ in, size_t in_stride,
                                                              const ConvDesc* __restrict__ descs, u32 desc_step, PtrTab8 outz) {
