@@ -158,4 +158,6 @@ struct XItem {
   u32 root;
 };
 int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s);
+int shard_exchange_begin(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s);  // enqueue, ordered after s so far; s does not wait
+int shard_exchange_end(acehip_ctx* c, hipStream_t s);                                   // s waits for every exchange begun since
 void shard_release(acehip_ctx* c);  // RCCL communicator + exchange stream / events of a context (acehip_ctx_destroy)

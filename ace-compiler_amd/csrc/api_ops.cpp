@@ -186,24 +186,46 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
   u64* pc = c->ws;            // [2][K][N] p-limbs in the coefficient domain
   u64* tmp = pc + 2 * PK;     // [2][level][N]
   const DcList dcs = launch_dcs(c);
-  for (const DevCtx& dc : dcs) {
-    if (dc.logN == 16) {
-      NttFuse fi;
-      fi.src0 = in0 + QL;
-      fi.src1 = in1 ? in1 + QL : nullptr;
-      fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
-      launch_ntt_fused(dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
-    } else {
-      copy_limbs_dc(dc, pc, in0 + QL, hp.K, hp.L, s);
-      if (in1) copy_limbs_dc(dc, pc + PK, in1 + QL, hp.K, hp.L, s);
-      launch_ntt(dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
-    }
-  }
-  if (sharded(c)) {  // the conversion P -> Q needs every P-limb: each comes from its owner (SURVEY 8e collective 2)
+  auto p_limbs_of = [&](u32 z) {
     std::vector<XItem> x;
-    for (u32 z = 0; z < np; ++z)
-      for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{pc + z * PK + (size_t)j * N, (hp.L + j) % c->sh_world});
-    if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+    for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{pc + z * PK + (size_t)j * N, (hp.L + j) % c->sh_world});
+    return x;
+  };
+  if (sharded(c) && c->rccl != nullptr && np == 2 && hp.logN == 16) {
+    // ranks on separate GPUs: the P-limbs of c0 travel while the inverse transform of c1's runs (SURVEY 8e collective 2, overlapped)
+    for (u32 z = 0; z < 2; ++z) {
+      for (const DevCtx& dc : dcs) {
+        NttFuse fi;
+        fi.src0 = (z ? in1 : in0) + QL;
+        fi.inv_scale = plan->inv_down;
+        launch_ntt_fused(dc, pc + z * PK, 0, 0, hp.K, true, s, 0, 1, PK, 0, fi);
+      }
+      const std::vector<XItem> x = p_limbs_of(z);
+      if (int e = shard_exchange_begin(c, x.data(), x.size(), s)) return e;
+    }
+    if (int e = shard_exchange_end(c, s)) return e;
+  } else {
+    for (const DevCtx& dc : dcs) {
+      if (dc.logN == 16) {
+        NttFuse fi;
+        fi.src0 = in0 + QL;
+        fi.src1 = in1 ? in1 + QL : nullptr;
+        fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
+        launch_ntt_fused(dc, pc, 0, 0, hp.K, true, s, 0, np, PK, 0, fi);  // level 0: position j -> prime p_j
+      } else {
+        copy_limbs_dc(dc, pc, in0 + QL, hp.K, hp.L, s);
+        if (in1) copy_limbs_dc(dc, pc + PK, in1 + QL, hp.K, hp.L, s);
+        launch_ntt(dc, pc, 0, 0, hp.K, true, s, 0, np, PK);
+      }
+    }
+    if (sharded(c)) {  // the conversion P -> Q needs every P-limb: each comes from its owner (SURVEY 8e collective 2)
+      std::vector<XItem> x;
+      for (u32 z = 0; z < np; ++z) {
+        const std::vector<XItem> xz = p_limbs_of(z);
+        x.insert(x.end(), xz.begin(), xz.end());
+      }
+      if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
+    }
   }
   // (descriptor nd + 1: the ModDown problem with its K sources at limb positions 0.. of `pc`)
   const bool conv_in_ntt = conv_fusable(c, hp.K);

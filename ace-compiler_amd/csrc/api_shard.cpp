@@ -501,37 +501,61 @@ struct RcclComm {
   // issued so far, and the launches that follow after the exchange, by events (no host synchronisation).
   hipStream_t xs = nullptr;
   hipEvent_t before = nullptr, after = nullptr;
+  bool pending = false;  // an exchange was begun and not yet joined (shard_exchange_begin / _end)
 };
 constexpr int kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
 }  // namespace
 
-int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
+// An exchange in two halves, so that a pipeline can put independent launches between them: begin() orders the broadcasts after
+// everything issued on s so far and enqueues them on the exchange stream, end() makes s wait for every exchange begun since the
+// last end().  Between the two, launches on s run beside the broadcasts (the ModDown of a ciphertext: the inverse transform of c1's
+// P-limbs while c0's travel).  Simulated ranks copy on s itself: begin() is the whole exchange, end() nothing.
+int shard_exchange_begin(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
   if (c->sh_world <= 1 || n == 0) return ACEHIP_OK;
+  if (c->rccl == nullptr) return shard_exchange(c, items, n, s);
   const size_t N = c->hp.N;
   const u64 lo = c->dc.rep_lo, span = c->dc.rep_span, stride = c->dc.rep_stride;
   c->xchg_calls++;
-  if (c->rccl != nullptr) {  // one process per rank: broadcast from the owner, in place, for every selected replica
-    RcclComm* rc = (RcclComm*)c->rccl;
-    RcclApi* api = rccl_api();
-    HIP_TRY(hipEventRecord(rc->before, s));
-    HIP_TRY(hipStreamWaitEvent(rc->xs, rc->before, 0));
-    int e = api->GroupStart();
-    for (size_t k = 0; k < n && e == 0; ++k) {
-      const u64 a = (u64)items[k].ptr;
-      const bool in_arena = a - lo < span && stride != 0;
-      for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1) && e == 0; ++r) {
-        void* p = (void*)(in_arena ? a + (u64)r * stride : a);
-        e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, rc->xs);
-        if (items[k].root != rc->rank) c->xchg_bytes += N * 8;
-      }
+  RcclComm* rc = (RcclComm*)c->rccl;
+  RcclApi* api = rccl_api();
+  HIP_TRY(hipEventRecord(rc->before, s));
+  HIP_TRY(hipStreamWaitEvent(rc->xs, rc->before, 0));
+  int e = api->GroupStart();
+  for (size_t k = 0; k < n && e == 0; ++k) {
+    const u64 a = (u64)items[k].ptr;
+    const bool in_arena = a - lo < span && stride != 0;
+    for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1) && e == 0; ++r) {
+      void* p = (void*)(in_arena ? a + (u64)r * stride : a);
+      e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, rc->xs);
+      if (items[k].root != rc->rank) c->xchg_bytes += N * 8;
     }
-    const int e2 = api->GroupEnd();
-    // (also after a failed group: whatever was enqueued on the exchange stream is ordered before the launches that follow)
-    HIP_TRY(hipEventRecord(rc->after, rc->xs));
-    HIP_TRY(hipStreamWaitEvent(s, rc->after, 0));
-    if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
-    return ACEHIP_OK;
   }
+  const int e2 = api->GroupEnd();
+  // (also after a failed group: whatever was enqueued on the exchange stream is ordered before the launches that follow end())
+  HIP_TRY(hipEventRecord(rc->after, rc->xs));
+  rc->pending = true;
+  if (e || e2) return fail(ACEHIP_EHIP, std::string("RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e ? e : e2) : "error"));
+  return ACEHIP_OK;
+}
+int shard_exchange_end(acehip_ctx* c, hipStream_t s) {
+  if (c->sh_world <= 1 || c->rccl == nullptr) return ACEHIP_OK;
+  RcclComm* rc = (RcclComm*)c->rccl;
+  if (!rc->pending) return ACEHIP_OK;
+  rc->pending = false;
+  HIP_TRY(hipStreamWaitEvent(s, rc->after, 0));  // (the exchange stream is in order: the last recorded event covers every begin())
+  return ACEHIP_OK;
+}
+
+int shard_exchange(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s) {
+  if (c->sh_world <= 1 || n == 0) return ACEHIP_OK;
+  if (c->rccl != nullptr) {  // one process per rank: broadcast from the owner, in place, for every selected replica
+    const int e = shard_exchange_begin(c, items, n, s);
+    const int e2 = shard_exchange_end(c, s);
+    return e ? e : e2;
+  }
+  const size_t N = c->hp.N;
+  const u64 lo = c->dc.rep_lo, span = c->dc.rep_span, stride = c->dc.rep_stride;
+  c->xchg_calls++;
   // simulated ranks: owner's replica -> every other hosted replica (absolute addresses: a DevCtx without rebasing)
   DevCtx dc = c->dc;
   dc.rep_span = 0;

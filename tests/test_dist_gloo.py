@@ -331,3 +331,35 @@ def test_limb_sharded_leg_of_the_bench_survives_failing_children_two_ranks_gloo(
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 leg ok" in r.stdout and "rank 1 leg ok" in r.stdout
+
+
+def test_exchange_volume_of_a_key_switch_matches_the_survey():
+    """at the generated ResNets' parameter set (N = 2^16, L = 34, K = 11) a key-switch at the top level moves the whole
+    input once for ModUp (L x 512 KiB = 17 MiB) and the K P-limbs of both accumulators for ModDown (2K x 512 KiB = 11 MiB); a rank of an
+    8-GPU group receives the 7/8 of them it does not own.  Counted from the product library's own exchange schedule (host-only context,
+    no GPU): the positions listed are exactly those limbs, each from its owner gi % world."""
+    import ctypes as C
+
+    import ace_compiler_amd as A
+
+    N, L, q0, sf, dnum, world = 65536, 34, 51, 50, 3, 8
+    rt = A.AceHip(N, L, q0, sf, dnum, host_only=True)
+    try:
+        K, level, limb = rt.K, L, N * 8
+
+        def schedule(op):
+            cap = 256
+            st, pos, root = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+            n = rt.lib.acehip_shard_schedule(rt.h, world, op, level, st, pos, root, cap)
+            assert 0 < n <= cap
+            return [(pos[i], root[i]) for i in range(n)]
+
+        up, down = schedule(0), schedule(1)
+        assert K == 11 and [p for p, _ in up] == list(range(level)) and [r for _, r in up] == [i % world for i in range(level)]
+        assert [p for p, _ in down] == list(range(level, level + K)) and [r for _, r in down] == [(L + j) % world for j in range(K)]
+        assert len(up) * limb == 17 * 2 ** 20 and 2 * len(down) * limb == 11 * 2 ** 20
+        for rank in range(world):  # what one rank receives per key-switch: the limbs it does not own (c0 and c1 of the ModDown pair)
+            recv = sum(limb for _, r in up if r != rank) + 2 * sum(limb for _, r in down if r != rank)
+            assert 23.5 * 2 ** 20 <= recv <= 25 * 2 ** 20, (rank, recv)
+    finally:
+        rt.close()
