@@ -542,7 +542,7 @@ def main():
     ap.add_argument("--roofline-batch", choices=["all", "mix", "scaling", "c3"], default="all",
                     help="with --roofline-only under a profiler: time only this one of the three 1024-limb NTT batches, so that every "
                          "ntt8_* launch of the process is the roofline object's own batch (mix), the scaling-prime batch or the C3 batch")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="concurrent image streams per GPU for the ResNet headline: host threads of this process, each with "
                          "its own rt_ant context (keys, pool, queue) and HIP stream; 1 = a single stream")
     ap.add_argument("--no-shard-leg", action="store_true",

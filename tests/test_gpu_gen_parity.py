@@ -227,3 +227,33 @@ def test_key_switch_base_forms_match_the_reference(name, tmp_path):
         assert got == KSW[name]["base"]
     assert KSW[name]["opt_vs_base"] == {"modup_hoist": "EQUAL", "moddown_hoist": "DIFFERENT", "moddown_rescale": "DIFFERENT",
                                         "moddown_rescale_modup": "DIFFERENT"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]'s workload: the ACE-generated ResNet-110 (rtlib/ant/dataset/resnet110_cifar10_train.onnx.inc, unchanged), one image,
+# against the reference rtlib's CPU run with the same injected key set (2.2 h of one core in the dev container).  With synthetic
+# weights this 110-layer network leaves the range of the bootstrap on both runtimes, so the logits mean nothing -- the bytes do: every
+# intermediate is exact integer arithmetic on both sides.
+# ------------------------------------------------------------------------------------------------------------------------------
+MODEL110 = FIX.get("models", {}).get("resnet110")
+
+
+def _model110_env():
+    import model_weights
+
+    if MODEL110 is None:
+        pytest.skip("tests/golden/gen_parity.json has no resnet110 entry (tests/golden/gen_gen_parity.py resnet110)")
+    wfile, meta = model_weights.ensure("resnet110", MODEL110["weights"]["sigma"])
+    if meta["md5"] != MODEL110["weights"]["md5"]:
+        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    return {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(MODEL110["enc_seed"])}
+
+
+@pytest.mark.parametrize("mode", [{}, {"ACEHIP_SHARD_SIM": "2"}, {"ACEHIP_SHARD_SIM": "8"}], ids=["unsharded", "2_simulated_ranks", "8_simulated_ranks"])
+def test_resnet110_output_ciphertext_is_byte_identical_to_the_reference_cpu_run(mode, tmp_path):
+    """unsharded, and with its RNS limbs spread over 2 and 8 simulated ranks (the execution mode of configs[4]): the output ciphertext
+    hashes to the digest of the reference's CPU run"""
+    exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
+    out, got = _run(exe, ["1"], dict(_model110_env(), **mode), tmp_path, "r110", timeout=1500)
+    assert got == MODEL110["outputs"], "ResNet-110 output ciphertext differs from the reference rtlib's CPU run"
+    assert _logits9(out) == [["%.9f" % v for v in MODEL110["logits9"]]]
