@@ -78,6 +78,7 @@ SYMBOLS = [
     ("acehip_conv_mfma_tables", C.c_long, [_vp, _u32, C.c_int32, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     ("acehip_values_to_rns", C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_encode", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _u32, _vp]),
+    ("acehip_encode_with_scale", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _vp]),
     ("acehip_encode_batch", C.c_int, [_vp, _vp, _vp, _u32, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _vp]),
     ("acehip_encode_status", C.c_int, [_vp]),
     ("acehip_sample_uniform", C.c_int, [_vp, _vp, _u32, _u32, _u32, _u64, _vp]),

@@ -98,7 +98,7 @@ RT_ARCHIVE = os.path.join(LIBDIR, "libFHErt_ant.a")
 RT_OBJS_ARCHIVE = os.path.join(LIBDIR, "libFHErt_ant_objs.a")
 RT_COMMON_ARCHIVE = os.path.join(LIBDIR, "libFHErt_common.a")
 RT_SOURCES = ["rt_poly.cpp", "rt_context.cpp", "rt_encode.cpp", "rt_io.cpp", "rt_eval.cpp", "rt_bootstrap.cpp", "rt_serial.cpp",
-              "rt_timing.cpp"]
+              "rt_timing.cpp", "rt_valid.cpp"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 

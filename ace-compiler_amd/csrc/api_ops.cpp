@@ -848,8 +848,21 @@ int acehip_encode_batch(acehip_ctx* c, uint64_t* const* h_q, const void* const* 
   return post_launch();
 }
 
+static int encode_impl(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                       double sf, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream s, double round_add);
 int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
                   double sf, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream s) {
+  return encode_impl(c, d_q, d_p, d_vals, kind, len, slots, sf, sf_degree, level, n_p, s, 0.5);
+}
+// Encode_impl_with_scale (ckks_encoder.c:301-378): the message is llround(x * scale) -- no half added before the rounding, no power of
+// the scaling factor multiplied in afterwards
+int acehip_encode_with_scale(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                             double scale, uint32_t level, uint32_t n_p, acehip_stream s) {
+  if (!(scale > 0)) return fail(ACEHIP_EINVAL, "acehip_encode_with_scale: invalid scale for encode");
+  return encode_impl(c, d_q, d_p, d_vals, kind, len, slots, scale, 1, level, n_p, s, 0.0);
+}
+static int encode_impl(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                       double sf, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream s, double round_add) {
   if (int e = check_dev(c)) return e;
   const u32 N = c->hp.N;
   if (slots == 0) slots = N / 2;
@@ -860,7 +873,7 @@ int acehip_encode(acehip_ctx* c, uint64_t* d_q, uint64_t* d_p, const void* d_val
   hipStream_t st = (hipStream_t)s;
   dbg_touch(d_q, (size_t)level * N);
   dbg_touch(d_p, (size_t)n_p * N);
-  launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st);
+  launch_embed_inv(c->emb_msg, c->emb_work, d_vals, kind, len, slots, N, c->emb_rou, c->emb_rot, sf, c->emb_err, st, round_add);
   const u64 sfi = (u64)sf;
   for (const DevCtx& dc : launch_dcs(c)) {
     if (dc.logN == 16) {  // the first NTT pass reduces (and scales) the message itself: no residue pass over memory

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict_
                                                             size_t work_stride, EmbBatch batch, int kind, size_t len, u32 logn,
                                                             u32 log2m, const cd* __restrict__ rou,
                                                             const u32* __restrict__ rot_group, double sf, u32 coef_gap,
-                                                            int* __restrict__ err_flag) {
+                                                            int* __restrict__ err_flag, double round_add) {
   __shared__ cd blk[1u << EMB_LOW];
   const void* __restrict__ vals = batch.vals[blockIdx.y];
   msg += blockIdx.y * msg_stride;
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict_
     const u32 p = (u32)base + t;
     const u32 i = logn ? (__brev(p) >> (32 - logn)) : 0;
     const cd v = blk[t];
-    const double re = (v.x * inv_n) * sf + 0.5, im = (v.y * inv_n) * sf + 0.5;
+    // round_add: 0.5 for Encode_impl (ckks_encoder.c:247-250: x*Delta + 0.5, then llround), 0 for Encode_impl_with_scale (:357-360)
+    const double re = (v.x * inv_n) * sf + round_add, im = (v.y * inv_n) * sf + round_add;
     if (!(re <= 9.2e18 && re >= -9.2e18 && im <= 9.2e18 && im >= -9.2e18)) atomicOr(err_flag, 1);
     msg[(size_t)i * coef_gap] = llround(re);
     msg[(size_t)(i + slots) * coef_gap] = llround(im);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(128) void embed_inv_low_kernel(int64_t* __restrict_
 // msg[b][N] (device) <- rounded, scaled inverse embedding of batch.vals[b] (len values each, zero padded to `slots`), b < n_batch;
 // work must hold n_batch * slots complex values
 void launch_embed_inv_batch(int64_t* msg, cd* work, const EmbBatch& batch, u32 n_batch, int kind, size_t len, u32 slots, u32 N,
-                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
+                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s, double round_add) {
   ACEHIP_ABLATE(ABL_EMBED);
   u32 logn = 0, log2m = 1;
   while ((1u << logn) < slots) ++logn;
@@ -135,17 +136,17 @@ void launch_embed_inv_batch(int64_t* msg, cd* work, const EmbBatch& batch, u32 n
     hipLaunchKernelGGL(embed_inv_high_kernel, dim3((1u << EMB_LOW) / EMB_COLS, n_batch), dim3(256), (size_t)R * EMB_COLS * sizeof(cd),
                        s, work, batch, (size_t)slots, kind, len, logn, log2m, rou, rot_group);
     hipLaunchKernelGGL(embed_inv_low_kernel<false>, dim3(slots >> EMB_LOW, n_batch), dim3(128), 0, s, msg, (size_t)N, work,
-                       (size_t)slots, batch, kind, len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag);
+                       (size_t)slots, batch, kind, len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag, round_add);
   } else {
     hipLaunchKernelGGL(embed_inv_low_kernel<true>, dim3(1, n_batch), dim3(128), 0, s, msg, (size_t)N, work, (size_t)slots, batch, kind,
-                       len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag);
+                       len, logn, log2m, rou, rot_group, sf, coef_gap, err_flag, round_add);
   }
 }
 void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
-                      const u32* rot_group, double sf, int* err_flag, hipStream_t s) {
+                      const u32* rot_group, double sf, int* err_flag, hipStream_t s, double round_add) {
   EmbBatch b{};
   b.vals[0] = vals;
-  launch_embed_inv_batch(msg, work, b, 1, kind, len, slots, N, rou, rot_group, sf, err_flag, s);
+  launch_embed_inv_batch(msg, work, b, 1, kind, len, slots, N, rou, rot_group, sf, err_flag, s, round_add);
 }
 
 }  // namespace acehip

@@ -326,9 +326,9 @@ struct EmbBatch {  // messages of one batched embedding (device pointers), a ker
   const void* vals[EMB_BATCH_MAX];
 };
 void launch_embed_inv_batch(int64_t* msg, cd* work, const EmbBatch& batch, u32 n_batch, int kind, size_t len, u32 slots, u32 N,
-                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s);
+                            const cd* rou, const u32* rot_group, double sf, int* err_flag, hipStream_t s, double round_add = 0.5);
 void launch_embed_inv(int64_t* msg, cd* work, const void* vals, int kind, size_t len, u32 slots, u32 N, const cd* rou,
-                      const u32* rot_group, double sf, int* err_flag, hipStream_t s);
+                      const u32* rot_group, double sf, int* err_flag, hipStream_t s, double round_add = 0.5);
 void launch_mul_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // r[pos] = a[pos] + w[pos - pos0] mod prime(pos)   (adding a constant plaintext, Add_const ckks_evaluator.c:116)
 void launch_add_scalars(const DevCtx& c, u64* r, const u64* a, const LimbConsts& w, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);

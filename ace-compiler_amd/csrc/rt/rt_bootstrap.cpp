@@ -952,6 +952,20 @@ void bootstrap_setup_if_needed() {  // Bootstrap_precom context.c:162-185
   }
 }
 
+void bootstrap_precom_slots(u32 num_slots) {
+  Context& c = ctx();
+  const u32 bts_depth = approx_mod_depth(c.hamming) + 3 + 3;
+  if (c.L - 1 <= bts_depth) return;  // (the reference: nothing to set up when the depth does not allow a bootstrap)
+  UniformScope shared_by_all_images;
+  Precom* pre;
+  {
+    RtmScope rtm(RTM_BS_SETUP);
+    pre = bootstrap_setup(num_slots);
+  }
+  RtmScope rtm(RTM_BS_KEYGEN);
+  bootstrap_keygen(pre);
+}
+
 void bootstrap_release() {
   for (auto& kv : g_precom) {
     for (auto* tabs : {&kv.second->u0hatt_fft, &kv.second->u0_fft})

@@ -120,7 +120,21 @@ void stage_release() {
 }
 
 // Encode_impl ckks_encoder.c:199-297 on device-resident values (kind: 0 float, 1 double, 2 complex double)
+static void encode_device_impl(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt,
+                               double scale);
 void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt) {
+  encode_device_impl(res, d_vals, kind, len, level, slots, sf_degree, p_cnt, 0.0);
+}
+// Encode_impl_with_scale ckks_encoder.c:301-378: an explicit scale; the plaintext's scale degree is the smallest whose power of the
+// scaling factor reaches it (:330-334)
+void encode_device_with_scale(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, double scale, u32 p_cnt) {
+  RT_ASSERT(scale > 0, "invalid scale for encode");
+  u32 sf_degree = (u32)floor(scale / ctx().sf);
+  if (scale > ctx().sf * sf_degree) sf_degree++;
+  encode_device_impl(res, d_vals, kind, len, level, slots, sf_degree, p_cnt, scale);
+}
+static void encode_device_impl(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt,
+                               double scale) {
   RtmScope rtm(RTM_ENCODE_ARRAY);
   Context& c = ctx();
   RT_ASSERT(res, "null plaintext");
@@ -131,7 +145,7 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
   RT_ASSERT(level <= c.L, "level should not be larger than mul_depth + 1");
   RT_ASSERT(len <= slots, "slot size is too small");
   RT_ASSERT(slots <= N / 2, " slot size > N/2 ");
-  RT_ASSERT(sf_degree >= 1, "invalid scaling factor for encode");
+  RT_ASSERT(sf_degree >= 1 || scale > 0, "invalid scaling factor for encode");
   POLYNOMIAL* poly = &res->_poly;
   // Generated conv loops encode one weight plaintext per tap into the SAME PLAINTEXT shell, between the per-limb
   // multiply-accumulates of consecutive taps (resnet20_cifar10_pre.onnx.inc:1486-1503).  Flushing the per-limb queue
@@ -151,14 +165,18 @@ void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32
               "unmatched size");  // init_plaintext's check
     poly_free(poly);  // into the pool's limbo until the queue has been issued
   }
-  init_plaintext(res, slots, level, p_cnt, pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
+  init_plaintext(res, slots, level, p_cnt, scale > 0 ? scale : pow(c.sf, (double)sf_degree), sf_degree, false);  // encode writes every limb
   const Touch touch[3] = {{nullptr, 0}, {q_limbs(poly), (size_t)level * N}, {p_cnt ? p_limbs(poly) : nullptr, (size_t)p_cnt * N}};
   if (ahead) hw_pending_flush();
   else hw_flush_touching(__FILE__, __LINE__, touch, 3);  // (d_vals: staging ring / weights)
   {
     SelectGuard one_replica(shared_pt ? 0 : current_rep0(), shared_pt ? 1 : current_nrep());
-    HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
-                                 level, p_cnt, nullptr));
+    if (scale > 0)
+      HIPCHK_NOFLUSH(acehip_encode_with_scale(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, scale, level,
+                                              p_cnt, nullptr));
+    else
+      HIPCHK_NOFLUSH(acehip_encode(c.hip, q_limbs(poly), p_cnt ? p_limbs(poly) : nullptr, d_vals, kind, len, slots, c.sf, sf_degree,
+                                   level, p_cnt, nullptr));
   }
   if (!ahead) check_declared(__FILE__, __LINE__, touch, 3);
   poly->_is_ntt = true;
@@ -414,17 +432,6 @@ CIPHER Encrypt(CIPHER res, PLAIN plain) {
 }
 
 // cipher_eval.c:129-150: decrypt + decode, real parts
-double* Get_msg(CIPHER ciph) {
-  PLAINTEXT pt;
-  memset(&pt, 0, sizeof(pt));
-  decrypt(&pt, ciph);
-  std::vector<cplx> out;
-  decode(out, &pt);
-  double* data = (double*)malloc(sizeof(double) * out.size());
-  for (size_t i = 0; i < out.size(); ++i) data[i] = out[i].real();
-  poly_free(&pt._poly);
-  return data;
-}
 double* Get_msg_from_plain(PLAIN plain) {
   PLAINTEXT pt = *plain;  // decode converts to the coefficient domain in place: work on a copy
   pt._poly._data = nullptr;
@@ -437,20 +444,6 @@ double* Get_msg_from_plain(PLAIN plain) {
   poly_free(&pt._poly);
   return data;
 }
-void Print_cipher_msg(FILE* fp, const char* name, CIPHER ciph, uint32_t len) {
-  double* m = Get_msg(ciph);
-  fprintf(fp, "[%s] level=%zu slots=%u sf_degree=%u: [", name, Level(ciph), ciph->_slots, ciph->_sf_degree);
-  for (uint32_t i = 0; i < len && i < ciph->_slots; ++i) fprintf(fp, " %.6f", m[i]);
-  fprintf(fp, " ]\n");
-  free(m);
-}
-void Dump_cipher_msg(const char* name, CIPHER ciph, uint32_t len) { Print_cipher_msg(stdout, name, ciph, len); }
-void Validate(CIPHER ciph, double* msg, uint32_t len, int32_t epsilon) {
-  double* m = Get_msg(ciph);
-  const double eps = pow(10.0, (double)epsilon);
-  for (uint32_t i = 0; i < len; ++i)
-    RT_ASSERT(fabs(m[i] - msg[i]) < eps, "Validate failed at %u: %f != %f", i, m[i], msg[i]);
-  free(m);
-}
+// (Get_msg, Print_cipher_msg, Dump_cipher_msg, Validate and the rest of cipher_valid.h / cipher_eval.h: rt_valid.cpp)
 
 }  // extern "C"

@@ -270,6 +270,8 @@ void stage_release();
 void encode_device(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt);
 void encode_vector(PLAINTEXT* res, const cplx* values, size_t len, u32 level, u32 slots, u32 sf_degree, u32 p_cnt);
 void encode_value(PLAINTEXT* res, double value, u32 level, u32 sf_degree);
+void encode_device_with_scale(PLAINTEXT* res, const void* d_vals, int kind, size_t len, u32 level, u32 slots, double scale, u32 p_cnt);
+void encode_value_with_scale(PLAINTEXT* res, double value, u32 level, double scale);   // rt_valid.cpp
 void decode(std::vector<cplx>& out, PLAINTEXT* plain);
 void encrypt(CIPHERTEXT* res, PLAINTEXT* plain);                       // ckks_encryptor.c:20-95
 void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph);                        // ckks_decryptor.c:19-65
@@ -296,6 +298,7 @@ struct RtmScope {  // times the enclosing block when RTLIB_TIMING_OUTPUT is set;
 };
 
 void bootstrap_setup_if_needed();
+void bootstrap_precom_slots(u32 num_slots);  // Bootstrap_precom(num_slots) context.c:162-185: tables and keys of one slot count
 void bootstrap_release();
 namespace ev { void clear_monomial_cache(); }
 

@@ -237,6 +237,11 @@ int acehip_values_to_rns(acehip_ctx* ctx, uint64_t* d_poly, const int64_t* d_val
  * reference's assert) is recorded in a sticky flag: acehip_encode_status() synchronises and reports it. */
 int acehip_encode(acehip_ctx* ctx, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
                   double scaling_factor, uint32_t sf_degree, uint32_t level, uint32_t n_p, acehip_stream stream);
+/* the same with an explicit scale instead of a power of the scaling factor (Encode_at_level_with_scale ckks_encoder.c:401 ->
+ * Encode_impl_with_scale :301-378): every coefficient is llround(x * scale) -- no half is added before the rounding and nothing is
+ * multiplied in afterwards */
+int acehip_encode_with_scale(acehip_ctx* ctx, uint64_t* d_q, uint64_t* d_p, const void* d_vals, int kind, size_t len, uint32_t slots,
+                             double scale, uint32_t level, uint32_t n_p, acehip_stream stream);
 /* The same for n_batch <= 8 messages of equal kind / length / slots / scale / level in one set of launches (embedding
  * kernels over the batch, one NTT with n_batch polynomials sharing every limb's twiddles): h_q[b] / h_vals[b] are HOST arrays
  * of device pointers (output q-limbs, message values).  Results are bit-identical to n_batch acehip_encode calls.  This is what

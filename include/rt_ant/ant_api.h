@@ -27,6 +27,14 @@
 #define FALSE 0
 #endif
 
+/* DCMPLX as in the reference's include/util/fhe_types.h:33-40 (the same memory layout in both languages) */
+#ifdef __cplusplus
+#include <complex>
+typedef std::complex<double> DCMPLX;
+#else
+#include <complex.h>
+typedef double complex DCMPLX;
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -104,6 +112,8 @@ uint32_t Degree();
 double   Get_default_sc();
 size_t   Get_q_parts();
 size_t   Get_p_cnt();
+size_t   Get_part_size();                 /* limbs per key-switch digit (context.h:94) */
+void     Bootstrap_precom(uint32_t num_slots); /* bootstrap tables and keys for one slot count (context.h:118, context.c:162-185) */
 MODULUS* Q_modulus();
 MODULUS* P_modulus();
 
@@ -133,6 +143,11 @@ int64_t* Auto_order(int32_t rot_idx); /* device table; only ever passed back to 
 SW_KEY   Swk(bool is_rot, int32_t rot_idx);
 POLY     Pk0_at(SW_KEY swk, uint32_t idx);
 POLY     Pk1_at(SW_KEY swk, uint32_t idx);
+static inline size_t Get_level_from_pk(PUB_KEY pk) { return pk->_pk0._num_primes; }          /* key_gen.h:83-85 */
+static inline void   Set_level_for_pk(PUB_KEY pk, size_t level) {                            /* key_gen.h:93-96 */
+  pk->_pk0._num_primes = level;
+  pk->_pk1._num_primes = level;
+}
 
 /* ---- ciphertext API (reference include/ckks/cipher_eval.h:25-171, src/ckks/cipher_eval.c) ---- */
 void     Free_cipher(CIPHER ciph);
@@ -149,9 +164,16 @@ size_t   Level(CIPHER ciph);
 uint32_t Sc_degree(CIPHER ciph);
 uint32_t Get_slots(CIPHER ciph);
 void     Set_slots(CIPHER ciph, uint32_t slots);
-double*  Get_msg(CIPHER ciph);
+double*  Get_msg(CIPHER ciph);              /* (a ciphertext over the extended basis is brought down first, cipher_eval.c:129-148) */
+DCMPLX*  Get_msg_with_imag(CIPHER ciph);
 void     Print_cipher_msg(FILE* fp, const char* name, CIPHER ciph, uint32_t len);
+void     Print_cipher_msg_with_imag(FILE* fp, const char* name, CIPHER ciph, uint32_t len);
+void     Print_cipher_range(FILE* fp, const char* name, CIPHER ciph);
+void     Print_cipher_info(FILE* fp, const char* name, CIPHER ciph);
+void     Print_cipher_poly(FILE* fp, const char* name, CIPHER ciph);
+void     Print_poly_lite(FILE* fp, POLY input);   /* poly_eval.h:150 */
 void     Dump_cipher_msg(const char* name, CIPHER ciph, uint32_t len);
+CIPHER   Real_relu(CIPHER ciph);            /* decrypt, clear ReLU, encrypt again (cipher_eval.c:264-290): a debugging aid */
 void     Free_ciph_poly(CIPHER ciph, uint32_t cnt);
 void     Zero_ciph(CIPHER ciph);
 CIPHER   Add_ciph(CIPHER res, CIPHER ciph1, CIPHER ciph2);
@@ -162,15 +184,44 @@ CIPHER3  Mul_ciph3(CIPHER3 res, CIPHER ciph1, CIPHER ciph2);
 CIPHER   Mul_plain(CIPHER res, CIPHER ciph, PLAIN plain);
 CIPHER   Relin(CIPHER res, CIPHER3 ciph);
 CIPHER   Rescale_ciph(CIPHER res, CIPHER ciph);
+CIPHER   Upscale_ciph(CIPHER res, CIPHER ciph, uint32_t mod_size);    /* times the constant 1 encoded at scale 2^mod_size (ckks_evaluator.c:347-360) */
+CIPHER   Downscale_ciph(CIPHER res, CIPHER ciph, uint32_t waterline); /* upscale to waterline + scaling bits, then rescale (:361-379) */
 void     Modswitch_ciph(CIPHER ciph);
 CIPHER   Rotate_ciph(CIPHER res, CIPHER ciph, int32_t rotation);
 CIPHER   Bootstrap(CIPHER res, CIPHER ciph, uint32_t level_after_bts);
 CIPHER   Encrypt(CIPHER res, PLAIN plain);
+/* validation helpers the code generator emits when validation is on (reference include/ckks/cipher_valid.h:25-100, src/ckks/cipher_valid.c):
+ * Validate reports on stderr / stdout and goes on; <op>_msg: the operation on decrypted messages; <op>_rtv: the clear tensor operation on the
+ * decrypted input; <op>_ref: the clear tensor operation on clear data.  All results are malloc'ed arrays the caller frees. */
 void     Validate(CIPHER ciph, double* msg, uint32_t len, int32_t epsilon);
+double*  Add_plain_msg(CIPHER op0, PLAIN op1);
+double*  Add_msg(CIPHER op0, CIPHER op1, uint64_t len);
+double*  Add_ref(double* op0, double* op1, uint64_t len);
+double*  Mul_plain_msg(CIPHER op0, PLAIN op1);
+double*  Mul_msg(CIPHER op0, CIPHER op1);
+double*  Rotate_msg(CIPHER op0, int32_t rotation);
+double*  Relu_msg(CIPHER op0, uint64_t len);
+double*  Relu_rtv(CIPHER op0, uint64_t len);
+double*  Relu_ref(double* op0, uint64_t len);
+double*  Bootstrap_msg(CIPHER op0);
+double*  Conv_rtv(CIPHER op0, int n, int c, int h, int w, float* weight, int kn, int kc, int kh, int kw, float* bias, int bw, int sh, int sw, int pn,
+                  int pc, int ph, int pw);
+double*  Conv_ref(double* op0, int n, int c, int h, int w, float* weight, int kn, int kc, int kh, int kw, float* bias, int bw, int sh, int sw, int pn,
+                  int pc, int ph, int pw);
+double*  Gemm_rtv(CIPHER op0, int h, int w, float* weight, int wh, int ww, float* bias, int bw);
+double*  Gemm_ref(double* op0, int h, int w, float* weight, int wh, int ww, float* bias, int bw);
+double*  Average_pool_rtv(CIPHER op0, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int pn, int pc, int ph, int pw);
+double*  Average_pool_ref(double* op0, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int pn, int pc, int ph, int pw);
+double*  Max_pool_rtv(CIPHER op0, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int pn, int pc, int ph, int pw);
+double*  Max_pool_ref(double* op0, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int pn, int pc, int ph, int pw);
+double*  Global_average_pool_rtv(CIPHER op0, int n, int c, int h, int w);
+double*  Global_average_pool_ref(double* op0, int n, int c, int h, int w);
 
 /* ---- plaintext API (reference include/ckks/plain_eval.h:25-58, src/ckks/plain_eval.c) ---- */
 void    Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_degree, uint32_t level);
 void    Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t sc_degree, uint32_t level);
+void    Encode_plain_from_float_with_scale(PLAIN plain, float* input, size_t len, double scale, uint32_t level); /* plain_eval.h:28-33 */
+DCMPLX* Get_dcmplx_msg_from_plain(PLAIN plain);
 void    Free_plain(PLAIN plain);
 double* Get_msg_from_plain(PLAIN plain);
 

@@ -6,7 +6,7 @@ PRODUCT derives from ACEHIP_SEED and writes every Set_output_data ciphertext in 
 The fixture holds sha256 digests of those files -- data only.  tests/test_gpu_gen_parity.py runs the same unchanged programs
 against libFHErt_ant.so with the same seed (lazy queue on; image batches; poison mode) and must reproduce every digest.
 
-  usage: gen_gen_parity.py [examples] [ksw] [resnet20] [resnet110]     (default: examples; the models take 0.5 h / 2.2 h of one core and
+  usage: gen_gen_parity.py [examples] [ksw] [extras] [resnet20] [resnet110]     (default: examples; the models take 0.5 h / 2.2 h of one core and
                                                                  44 GB, and are merged into the existing file)
 """
 import glob
@@ -65,6 +65,22 @@ def run_ksw(args, tmp):
     return {"args": args, "base": {os.path.basename(p)[:-3]: sha(p) for p in sorted(glob.glob(d + "/*.ct"))}, "opt_vs_base": verdicts}
 
 
+EXTRAS_SETS = {"n1024_l7": "1024 6 60 50 3", "n65536_resnet20": "65536 33 51 50 3"}
+
+
+def run_extras(args, tmp):
+    """tests/c/api_extras.c against the reference: digests of the ciphertexts / plaintexts it writes + the text of its diagnostics"""
+    d = os.path.join(tmp, "extras_" + args.replace(" ", "_"))
+    os.makedirs(d)
+    env = dict(os.environ, GEN_PARITY_SEED=str(SEED))
+    r = subprocess.run([os.path.join(EX, "refgen_api_extras"), d] + args.split(), capture_output=True, text=True, env=env, timeout=3600)
+    assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    return {"args": args, "files": {os.path.basename(p)[:-3]: sha(p) for p in sorted(glob.glob(d + "/*.ct"))},
+            "text": open(os.path.join(d, "text.txt")).read().splitlines(),
+            "validate_stdout": [ln for ln in r.stdout.splitlines() if "internal validation" in ln],
+            "validate_stderr": [ln for ln in r.stderr.splitlines() if ln.startswith(("ERROR: validation", "idx:", "res:", "std:"))]}
+
+
 def run_model(key, tmp):
     """one image of the generated ResNet with the synthetic weight file of tools/make_weight_file.py (sigma from weights.json)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -103,6 +119,10 @@ def main():
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refgen"])
             data["ksw_variants"] = {name: run_ksw(args, tmp) for name, args in KSW_SETS.items()}
             print(data["ksw_variants"])
+        if "extras" in what:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refgen"])
+            data["api_extras"] = {name: run_extras(args, tmp) for name, args in EXTRAS_SETS.items()}
+            print(data["api_extras"])
         for key in MODELS:
             if key in what:
                 data.setdefault("models", {})[key] = run_model(key, tmp)

@@ -257,3 +257,35 @@ def test_resnet110_output_ciphertext_is_byte_identical_to_the_reference_cpu_run(
     out, got = _run(exe, ["1"], dict(_model110_env(), **mode), tmp_path, "r110", timeout=1500)
     assert got == MODEL110["outputs"], "ResNet-110 output ciphertext differs from the reference rtlib's CPU run"
     assert _logits9(out) == [["%.9f" % v for v in MODEL110["logits9"]]]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The part of the reference's rt_ant surface that no checked-in generated program calls (tests/c/api_extras.c): Upscale_ciph /
+# Downscale_ciph, the with-scale encoders, the message-level validation helpers, the diagnostics -- same bytes, same text.
+# ------------------------------------------------------------------------------------------------------------------------------
+EXTRAS = FIX.get("api_extras", {})
+
+
+@pytest.mark.parametrize("name", sorted(EXTRAS) or ["(no fixture)"])
+def test_api_extras_match_the_reference(name, tmp_path):
+    if not EXTRAS:
+        pytest.skip("tests/golden/gen_parity.json has no api_extras entry (tests/golden/gen_gen_parity.py extras)")
+    import ace_compiler_amd  # noqa: F401
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = os.path.join(str(tmp_path), "api_extras")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-O1", os.path.join(ROOT, "tests", "c", "api_extras.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+                           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe])
+    d = tmp_path / "out"
+    d.mkdir()
+    want = EXTRAS[name]
+    r = subprocess.run([exe, str(d)] + want["args"].split(), capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ACEHIP_SEED=str(FIX["seed"])))
+    assert r.returncode == 0 and "SUCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {os.path.basename(p)[:-3]: _sha(p) for p in sorted(glob.glob(str(d) + "/*.ct"))}
+    assert got == want["files"]
+    assert open(os.path.join(str(d), "text.txt")).read().splitlines() == want["text"]
+    assert [ln for ln in r.stdout.splitlines() if "internal validation" in ln] == want["validate_stdout"]
+    assert [ln for ln in r.stderr.splitlines() if ln.startswith(("ERROR: validation", "idx:", "res:", "std:"))] == want["validate_stderr"]
