@@ -11,6 +11,8 @@
 
 #include "rt_ev.hpp"
 
+#include "common/rt_config.h"  // Get_rtlib_config (rt_valid.cpp)
+
 namespace rt {
 
 namespace {
@@ -1058,8 +1060,7 @@ void bootstrap(Ct& res, Ct& ciph, u32 raise_level) {
     ev::rotate(rot, res, (int32_t)slots);
     ev::add(res, res, rot);
   }
-  const char* ci = getenv("RT_BTS_CLEAR_IMAG");
-  if (ci != nullptr && atoi(ci) != 0 && deg >= 1) {
+  if (Get_rtlib_config(CONF_BTS_CLEAR_IMAG /* RT_BTS_CLEAR_IMAG or Set_rtlib_config */) != 0 && deg >= 1) {
     Ct conj;
     ev::conjugate(conj, res);
     ev::add(res, res, conj);

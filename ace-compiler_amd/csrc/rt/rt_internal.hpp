@@ -278,13 +278,7 @@ void decrypt(PLAINTEXT* res, CIPHERTEXT* ciph);                        // ckks_d
 void init_plaintext(PLAINTEXT* p, u32 slots, size_t nq, size_t np, double sf, u32 sf_degree, bool zero = true);
 
 // ---- RTLIB_TIMING_OUTPUT table (rt_timing.cpp; ids in the order of rtlib/include/common/rtlib_timing.h:28-78) ----
-enum RtmId {
-  RTM_FINALIZE_CONTEXT, RTM_PREPARE_CONTEXT, RTM_IO_SUBMIT, RTM_IO_COMPLETE, RTM_ENCODE_ARRAY, RTM_ENCODE_VALUE, RTM_NTT, RTM_INTT,
-  RTM_MAIN_GRAPH, RTM_HW_ADD, RTM_HW_MUL, RTM_HW_ROT, RTM_COPY_POLY, RTM_DECOMP, RTM_MOD_DOWN, RTM_MOD_UP, RTM_DECOMP_MODUP,
-  RTM_RESCALE_POLY, RTM_COPY_CIPH, RTM_INIT_CIPH_SM_SC, RTM_INIT_CIPH_UP_SC, RTM_INIT_CIPH_DN_SC, RTM_BOOTSTRAP, RTM_BS_COPY,
-  RTM_BS_SETUP, RTM_BS_KEYGEN, RTM_BS_EVAL, RTM_BS_PARTIAL_SUM, RTM_BS_COEFF_TO_SLOT, RTM_BS_APPROX_MOD, RTM_BS_SLOT_TO_COEFF,
-  RTM_PT_ENCODE, RTM_PT_GET, RTM_LAST
-};
+typedef RTLIB_TIMING_ID RtmId;  // include/common/rtlib_timing.h (seen through rt_ant/rt_ant.h), ids in the reference's order
 bool rtm_enabled();
 void rtm_add(int id, uint64_t ns);
 uint64_t rtm_now();

@@ -152,6 +152,30 @@ void Tm_taken(const char* msg) {
   g_tm_stamp = cur;
 }
 
+// ---- io_lib.c:62-120 (common/io_api.h): the name / index table itself ----
+void Io_init(void) { io_init(); }
+void Io_fini(void) {
+  g_inputs.clear();
+  g_outputs.clear();
+  g_io_ready = false;
+}
+void Io_set_input(const char* name, size_t idx, void* ct) {
+  io_init();
+  io_at(g_inputs, name, idx) = ct;
+}
+void* Io_get_input(const char* name, size_t idx) {
+  io_init();
+  return io_at(g_inputs, name, idx);
+}
+void Io_set_output(const char* name, size_t idx, void* ct) {
+  io_init();
+  io_at(g_outputs, name, idx) = ct;
+}
+void* Io_get_output(const char* name, size_t idx) {
+  io_init();
+  return io_at(g_outputs, name, idx);
+}
+
 // ---- rtlib.c:41-87 ----
 static void prepare_one_image(TENSOR* input, const char* name, rt::u32 k) {
   if (k == 0) rt::pt_image_boundary();
@@ -392,7 +416,7 @@ void Pt_prefetch(uint32_t pt_idx) {
 // pt_mgr.c:128-159: a PLAINTEXT whose coefficients the caller only reads (Coeffs(&pt->_poly, ...) in Hw_modmul loops), valid
 // until Pt_free(pt_idx); here it stays valid until Pt_mgr_fini.  len / scale / level describe what the compiler stored.
 void* Pt_get(uint32_t pt_idx, size_t, uint32_t scale, uint32_t level) {
-  rt::RtmScope rtm(rt::RTM_PT_GET, false);
+  rt::RtmScope rtm(RTM_PT_GET, false);
   PtMgr::PtEntry& e = pt_load(pt_idx);
   RT_ASSERT(level == 0 || e.shell._poly._num_primes == level, "plaintext entry %u is stored at level %zu, asked for %u", pt_idx,
             e.shell._poly._num_primes, level);
@@ -589,11 +613,11 @@ void Dump_plain(PLAIN pt, size_t start, size_t len) {
   free(m);
 }
 void Pt_from_msg(void* pt, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
-  rt::RtmScope rtm(rt::RTM_PT_ENCODE);
+  rt::RtmScope rtm(RTM_PT_ENCODE);
   pt_encode((PLAIN)pt, index, len, scale, level);
 }
 void Pt_from_msg_validate(void* pt, float* buf, uint32_t index, size_t len, uint32_t scale, uint32_t level) {
-  rt::RtmScope rtm(rt::RTM_PT_ENCODE);
+  rt::RtmScope rtm(RTM_PT_ENCODE);
   float* data = pt_entry(index, len);
   for (uint32_t i = 0; i < len; ++i)
     RT_ASSERT(fabs(buf[i] - data[i]) < 0.000001, "Pt_from_msg_validate failed. index=%d, i=%d: %f != %f.", index, i, buf[i], data[i]);

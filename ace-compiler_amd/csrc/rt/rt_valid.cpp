@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "rt_internal.hpp"
+#include "common/rt_config.h"
 
 namespace rt {
 
@@ -233,6 +234,51 @@ int g_relu_n, g_relu_e2e_n, g_bts_n, g_conv_n, g_conv_e2e_n, g_gemm_n, g_gemm_e2
 
 extern "C" {
 
+// ---- common/rtlib_timing.h, trace.h, rt_config.h (declared there; the enum values are those of rt_internal.hpp RtmId) ----
+void Append_rtlib_timing(RTLIB_TIMING_ID id, uint64_t nsec) {
+  if ((int)id >= 0 && id < RTM_LAST) rtm_add((int)id, nsec);
+}
+void Report_rtlib_timing(void) { rtm_report(); }
+
+static FILE* g_trace_fp = nullptr;
+static bool g_trace_on = false, g_trace_env_read = false;
+void Set_trace_file(char* filename) {
+  if (g_trace_fp != nullptr && g_trace_fp != stdout) fclose(g_trace_fp);
+  g_trace_fp = (filename != nullptr && *filename) ? fopen(filename, "w") : nullptr;
+}
+FILE* Get_trace_file(void) {
+  if (g_trace_fp == nullptr && !g_trace_env_read) {  // RTLIB_TRACE_FILE names it the first time it is asked for
+    g_trace_env_read = true;
+    const char* e = getenv("RTLIB_TRACE_FILE");
+    if (e != nullptr && *e) g_trace_fp = fopen(e, "w");
+  }
+  return g_trace_fp != nullptr ? g_trace_fp : stdout;
+}
+void Close_trace_file(void) {
+  if (g_trace_fp != nullptr && g_trace_fp != stdout) fclose(g_trace_fp);
+  g_trace_fp = nullptr;
+}
+void Set_trace_on(bool v) { g_trace_on = v; }
+bool Is_trace_on(void) { return g_trace_on; }
+
+static int64_t g_config[2] = {1, 0};  // CONF_OP_FUSION_DECOMP_MODUP, CONF_BTS_CLEAR_IMAG
+static bool g_config_ready = false;
+void Init_rtlib_config(void) {
+  g_config[0] = 1;
+  g_config[1] = 0;
+  if (const char* e = getenv("OP_FUSION_DECOMP_MODUP")) g_config[0] = atoi(e) != 0;
+  if (const char* e = getenv("RT_BTS_CLEAR_IMAG")) g_config[1] = atoi(e) != 0;
+  g_config_ready = true;
+}
+int64_t Get_rtlib_config(RTLIB_CONFIG_ID id) {
+  if (!g_config_ready) Init_rtlib_config();
+  return (int)id >= 0 && (int)id < 2 ? g_config[id] : 0;
+}
+void Set_rtlib_config(RTLIB_CONFIG_ID id, int64_t value) {
+  if (!g_config_ready) Init_rtlib_config();
+  if ((int)id >= 0 && (int)id < 2) g_config[id] = value;
+}
+
 // ---- context.h ----
 size_t Get_part_size() { return ctx().alpha; }
 void Bootstrap_precom(uint32_t num_slots) { bootstrap_precom_slots(num_slots); }
@@ -328,7 +374,7 @@ void Print_cipher_poly(FILE* fp, const char* name, CIPHER ciph) {
   fprintf(fp, "@c1:\n");
   Print_poly_lite(fp, &ciph->_c1_poly);
 }
-void Dump_cipher_msg(const char* name, CIPHER ciph, uint32_t len) { Print_cipher_msg(stdout, name, ciph, len); }  // (no trace file here)
+void Dump_cipher_msg(const char* name, CIPHER ciph, uint32_t len) { Print_cipher_msg(Get_trace_file(), name, ciph, len); }  // cipher_eval.c:260
 
 // cipher_eval.c:264-290: the clear ReLU of the decrypted message, encrypted again at the ciphertext's level and scale degree
 CIPHER Real_relu(CIPHER ciph) {

@@ -27,6 +27,11 @@
 #define FALSE 0
 #endif
 
+/* what the reference's ant_api.h brings in besides the API below (error.h, rtlib_timing.h, trace.h through its own includes): the
+ * assertion and timing macros and the trace switch are visible to every program that includes rt_ant/rt_ant.h */
+#include "common/error.h"
+#include "common/rtlib_timing.h"
+#include "common/trace.h"
 /* DCMPLX as in the reference's include/util/fhe_types.h:33-40 (the same memory layout in both languages) */
 #ifdef __cplusplus
 #include <complex>

@@ -15,6 +15,8 @@
 
 #include "common/rtlib.h"
 #include "rt_ant/rt_ant.h"
+#include "common/io_api.h"    /* the input / output table behind Prepare_input / Set_output_data */
+#include "common/rt_config.h"
 
 #ifdef REF_BUILD
 #include "rtlib/context.h"
@@ -99,6 +101,15 @@ int main(int argc, char** argv) {
   Prepare_input(t, "in_b");
   Free_tensor(t);
   for (uint32_t i = 0; i < Slots; ++i) w[i] = (float)(cos(0.11 * i) * 0.75);
+  /* the facilities a program sees through rt_ant.h besides the operators: the IO table, run-time switches, timing marks, assertions */
+  fprintf(Txt, "io table: in_a %s, in_b %s\n", Io_get_input("in_a", 0) ? "set" : "empty", Io_get_input("in_b", 0) ? "set" : "empty");
+  Set_rtlib_config(CONF_BTS_CLEAR_IMAG, 1);
+  fprintf(Txt, "config: clear_imag %ld fusion %ld\n", (long)Get_rtlib_config(CONF_BTS_CLEAR_IMAG), (long)Get_rtlib_config(CONF_OP_FUSION_DECOMP_MODUP));
+  Set_rtlib_config(CONF_BTS_CLEAR_IMAG, 0);
+  RTLIB_TM_START(RTM_PT_GET, mark);
+  FMT_ASSERT(RTM_PT_GET + 1 == RTM_LAST && RTM_MAIN_GRAPH == 8, "timing ids differ from the reference's order");
+  RTLIB_TM_END(RTM_PT_GET, mark);
+  IS_TRUE(Is_trace_on() == false, "trace is off by default");
   CIPHERTEXT a = Get_input_data("in_a", 0), b = Get_input_data("in_b", 0);
   const uint32_t level = (uint32_t)Level(&a);
 
