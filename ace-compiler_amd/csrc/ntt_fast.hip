@@ -28,6 +28,10 @@
 #include "kernels.hpp"
 #include "ntt_fp.hpp"
 
+#ifndef ACEHIP_NTT_MIN_WG
+#define ACEHIP_NTT_MIN_WG 4  // workgroups per CU the wide passes' register allocation leaves room for (experiments: tools/kernel_ab.sh)
+#endif
+
 namespace acehip {
 
 struct Tw {
@@ -657,7 +661,7 @@ __device__ __forceinline__ void strided_pass(const DevCtx& c, u64* __restrict__ 
 }
 
 template <bool INVERSE, int SRC>
-__global__ __launch_bounds__(256, 4) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+__global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_strided_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
                                                            u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                            u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[256 * kRowPitch];
@@ -887,7 +891,7 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
 }
 
 template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8 = false, bool FP_OK = false>
-__global__ __launch_bounds__(256, 4) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
+__global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_contig_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride,
                                                           u32 level, u32 pos0, u32 pos_off, u32 skip_alpha, NttFuse f,
                                                           u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[16 * kBlkPitch];
