@@ -394,6 +394,8 @@ static void skip_encryptions(size_t k) {
 static size_t env_count(const char* name, size_t dflt) { return getenv(name) ? strtoul(getenv(name), NULL, 10) : dflt; }
 
 VALUE_LIST* Pre_encode_scheme(TENSOR* image, DATA_SCHEME* scheme); /* rtlib.c:20-32: exported, in no header */
+void        Ref_sampler_start(void);                                  /* tests/c/ref_sampler.c */
+void        Ref_sampler_stop(void);
 /* GEN_PARITY_BATCH=B, GEN_PARITY_ENC_SKIP=k: this run is image k of a batch of B under a program that knows nothing of batches --
  * the product's Prepare_input encrypts the tensor B times in a row from one stream (rt_io.cpp), image k takes the k-th */
 void Prepare_input(TENSOR* input, const char* name) {
@@ -409,6 +411,7 @@ void Prepare_input(TENSOR* input, const char* name) {
   skip_encryptions(batch - 1 - k);
   Free_value_list(vec);
   Free_plaintext(plain);
+  Ref_sampler_start(); /* REF_SAMPLER_OUT: profile from here to the first output (tests/c/ref_sampler.c) */
 }
 
 /* an encryption inside Main_graph (eg_fhertlib_bootstrap.inc): one for the whole batch on the product side */
@@ -420,6 +423,7 @@ CIPHER Encrypt(CIPHER res, PLAIN plain) {
 
 void Set_output_data(const char* name, size_t idx, CIPHER data) {
   static unsigned n_call = 0;
+  Ref_sampler_stop();
   const char*     prefix = getenv("GEN_PARITY_OUT");
   if (prefix) {
     char path[1200];
