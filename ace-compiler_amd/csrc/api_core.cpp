@@ -35,6 +35,17 @@ u32& acehip_stat_mult() {
   static thread_local u32 m = 1;
   return m;
 }
+bool& acehip_stat_mute() {
+  static thread_local bool m = false;
+  return m;
+}
+u32 replica_chunk() {
+  static const u32 v = [] {
+    const char* e = getenv("ACEHIP_REP_CHUNK");
+    return e ? (u32)atoi(e) : 0u;
+  }();
+  return v;
+}
 static const char* const kStatName[ST_COUNT] = {"ntt", "elementwise", "rotate", "decomp_modup", "key_inner_product",
                                                 "mod_down", "rescale", "key_switch", "encode", "zero_fill_executed", "elementwise_mul", "ntt_launched"};
 
@@ -473,7 +484,7 @@ int check_dev(acehip_ctx* c) {
   if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
     if (hipSetDevice(c->device) != hipSuccess) return fail(ACEHIP_EHIP, "hipSetDevice failed");
   }
-  acehip_stat_mult() = c->seln;
+  acehip_stat_mult() = c->stat_reps ? c->stat_reps : c->seln;  // (stat_reps: the whole selection while for_replica_chunks narrows it)
   return ACEHIP_OK;
 }
 int check_range(acehip_ctx* c, uint32_t level, uint32_t pos0, uint32_t n) {

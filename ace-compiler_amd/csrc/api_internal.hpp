@@ -94,6 +94,7 @@ struct acehip_ctx {
   // ---- replicas of the caller's polynomial arena (acehip_ctx_set_arena): image batches, simulated ranks.  dc.rep_lo / rep_span /
   // rep_stride describe the arena; launches cover replicas [sel0, sel0 + seln) (acehip_ctx_select)
   u32 n_replicas = 1, sel0 = 0, seln = 1;
+  u32 stat_reps = 0;  // replicas one call counts for in the statistics while its launches go out in chunks (0: seln)
   bool ws_external = false, scratch_external = false;  // workspace / hw scratch handed in by the caller (inside the arena)
   // ---- limb-sharded execution (api_shard.cpp): world ranks, limb gi belongs to rank gi % world.  hosted[h] = rank whose limbs
   // live in replica h of the arena: every rank of a simulation (ACEHIP_SHARD_SIM: exchanges are copies between replicas), or
@@ -115,7 +116,9 @@ struct acehip_ctx {
 enum { ST_NTT, ST_EW, ST_ROTATE, ST_MODUP, ST_KEYMAC, ST_MODDOWN, ST_RESCALE, ST_KEYSWITCH, ST_ENCODE, ST_ZERO_RUN, ST_EW_MUL, ST_NTT_ALL, ST_COUNT };
 acehip_stat* acehip_stat_slots();  // this thread's counters [ST_COUNT] (one host thread = one image stream)
 u32& acehip_stat_mult();  // replicas the current call covers (set by check_dev): an op on B images counts B times
+bool& acehip_stat_mute();  // replica chunks after the first of one call (for_replica_chunks): already counted
 inline void stat(int k, u64 units, u64 bytes) {
+  if (acehip_stat_mute()) return;
   acehip_stat* g = acehip_stat_slots();
   const u32 m = acehip_stat_mult();
   g[k].calls++;
@@ -146,6 +149,32 @@ struct DcList {
   const DevCtx* end() const { return d + n; }
 };
 DcList launch_dcs(const acehip_ctx* c);
+// A pipeline of several launches over the images of a batch, issued chunk by chunk: body() runs once per group of
+// ACEHIP_REP_CHUNK replicas (the selection narrowed to the group) instead of once over all selected replicas, so that what one
+// launch writes is still in the 256 MiB Infinity Cache when the next launch of the pipeline reads it -- the hand-off between the
+// two passes of a transform, the coefficient-domain limbs between an inverse transform, a conversion and the forward transform.
+// Replicas are independent, so the results are the same bits in any grouping.  0 / unset: one group (off); never when limb-sharded.
+u32 replica_chunk();
+template <class F>
+int for_replica_chunks(acehip_ctx* c, F&& body) {
+  const u32 chunk = replica_chunk();
+  if (chunk == 0 || c->sh_world > 1 || c->seln <= chunk) return body();
+  const u32 s0 = c->sel0, sn = c->seln;
+  int rc = 0;
+  c->stat_reps = sn;
+  acehip_stat_mult() = sn;
+  for (u32 r = 0; r < sn && rc >= 0; r += chunk) {
+    c->sel0 = s0 + r;
+    c->seln = sn - r < chunk ? sn - r : chunk;
+    acehip_stat_mute() = r != 0;
+    rc = body();
+  }
+  acehip_stat_mute() = false;
+  c->stat_reps = 0;
+  c->sel0 = s0;
+  c->seln = sn;
+  return rc;
+}
 inline bool sharded(const acehip_ctx* c) { return c->sh_world > 1; }
 inline bool dc_owns(const DevCtx& dc, u32 gi) { return dc.sh_world <= 1 || gi % dc.sh_world == dc.sh_rank; }
 // dst limb i = src limb i for i < n_limbs, limb i having prime gi0 + i (only the limbs the DevCtx owns; every replica it covers):

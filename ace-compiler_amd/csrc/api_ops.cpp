@@ -72,13 +72,19 @@ extern "C" {
 
 int acehip_ntt_forward(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, false, (hipStream_t)s);
+  (void)for_replica_chunks(c, [&] {
+    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, false, (hipStream_t)s);
+    return 0;
+  });
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
 int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, true, (hipStream_t)s);
+  (void)for_replica_chunks(c, [&] {
+    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, true, (hipStream_t)s);
+    return 0;
+  });
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
@@ -88,7 +94,10 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
   if (int e = check_range(c, level, pos0, n)) return e;
   if (n_polys == 0) return ACEHIP_OK;
   if (n_polys > 65535) return fail(ACEHIP_EINVAL, "acehip_ntt_batch: at most 65535 polynomials per launch");
-  for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+  (void)for_replica_chunks(c, [&] {
+    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+    return 0;
+  });
   stat(ST_NTT, (u64)n * n_polys, 16ull * c->hp.N * n * n_polys);
   return post_launch();
 }
@@ -165,7 +174,7 @@ int acehip_mod_down(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t l
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down: bad level");
   if (out == in) return fail(ACEHIP_EINVAL, "acehip_mod_down: out must not alias in");
-  if (c->dc.logN == 16) return do_mod_down_n(c, out, nullptr, in, nullptr, level, (hipStream_t)s);
+  if (c->dc.logN == 16) return for_replica_chunks(c, [&] { return do_mod_down_n(c, out, nullptr, in, nullptr, level, (hipStream_t)s); });
   stat(ST_MODDOWN, 1, 8ull * c->hp.N * (2 * level + c->hp.K));
   dbg_touch(out, (size_t)level * c->hp.N);
   dbg_touch(in, (size_t)(level + c->hp.K) * c->hp.N);
@@ -263,7 +272,7 @@ int acehip_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_mod_down2: bad level");
   if (!out0 || !out1 || !in0 || !in1 || out0 == in0 || out1 == in1 || out0 == in1 || out1 == in0 || out0 == out1)
     return fail(ACEHIP_EINVAL, "acehip_mod_down2: outputs must not alias inputs or each other");
-  return do_mod_down_n(c, out0, out1, in0, in1, level, (hipStream_t)s);
+  return for_replica_chunks(c, [&] { return do_mod_down_n(c, out0, out1, in0, in1, level, (hipStream_t)s); });
 }
 
 // ModRaise of bootstrapping (Transform_values_from_level0 ckks_bootstrap_context.c:1527-1551): limb 0 of each
@@ -449,14 +458,14 @@ static int do_rescale(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const
 int acehip_rescale(acehip_ctx* c, uint64_t* out, const uint64_t* in, uint32_t level, acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale: level must be in [2, L]");
-  return do_rescale(c, out, nullptr, in, nullptr, level, (hipStream_t)s);
+  return for_replica_chunks(c, [&] { return do_rescale(c, out, nullptr, in, nullptr, level, (hipStream_t)s); });
 }
 int acehip_rescale2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in0, const uint64_t* in1, uint32_t level,
                     acehip_stream s) {
   if (int e = check_dev(c)) return e;
   if (level < 2 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_rescale2: level must be in [2, L]");
   if (!out0 || !out1 || !in0 || !in1) return fail(ACEHIP_EINVAL, "acehip_rescale2: null polynomial");
-  return do_rescale(c, out0, out1, in0, in1, level, (hipStream_t)s);
+  return for_replica_chunks(c, [&] { return do_rescale(c, out0, out1, in0, in1, level, (hipStream_t)s); });
 }
 
 }  // extern "C"
@@ -628,8 +637,14 @@ long acehip_conv_mfma_tables(const acehip_ctx* c, uint32_t level, int32_t digit,
   return (long)f.size();
 }
 
+static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key, uint32_t level, acehip_stream s_);
 int acehip_key_switch(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key,
-                      uint32_t level, acehip_stream s_) {
+                      uint32_t level, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  return for_replica_chunks(c, [&] { return key_switch_impl(c, out0, out1, in, key, level, s); });
+}
+static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* in, const uint64_t* key,
+                           uint32_t level, acehip_stream s_) {
   if (int e = check_dev(c)) return e;
   if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_switch: bad level");
   const HostParams& hp = c->hp;
@@ -1035,11 +1050,11 @@ int acehip_modup_digits(acehip_ctx* c, uint64_t* ext, const uint64_t* in, uint32
   const u32 nd = c->hp.num_decomp(level);
   if (nd > 8) return fail(ACEHIP_EINVAL, "acehip_modup_digits: more than 8 digits");
   for (u32 d = 0; d < nd; ++d) tab[d] = ext + d * E;
-  return modup_digits_to(c, tab, in, level, s);
+  return for_replica_chunks(c, [&] { return modup_digits_to(c, tab, in, level, s); });
 }
 int acehip_modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t* in, uint32_t level, acehip_stream s) {
   if (!c || !h_ext) return fail(ACEHIP_EINVAL, "acehip_modup_digits_to: null argument");
-  return modup_digits_to(c, h_ext, in, level, s);
+  return for_replica_chunks(c, [&] { return modup_digits_to(c, h_ext, in, level, s); });
 }
 // Fast_switch_key_ext (ckks_evaluator.c:418-460): acc{0,1} = sum_d key{0,1}[d] * ext[d] over level+K limbs, no ModDown
 int acehip_key_inner_product(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, const uint64_t* key, const uint64_t* ext, uint32_t level, acehip_stream s) {
