@@ -78,18 +78,8 @@ def test_resnet20_image_batches_are_bit_identical(tmp_path):
     assert _logit_lines(out1) == _logit_lines(out2) == _logit_lines(out4) and len(_logit_lines(out1)) == 4
 
 
-def test_resnet110_sharded_is_bit_identical(tmp_path):
-    """BASELINE configs[4] as a workload: one image of the ACE-generated ResNet-110 (rtlib/ant/dataset/resnet110_cifar10_train.onnx.inc,
-    unchanged) with its limbs spread over 2 and over 8 simulated ranks -- output ciphertext byte-identical to the unsharded run
-    (the keys come from the same ACEHIP_SEED in every run: generated limb by limb, each rank its own)."""
-    exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
-    _need(exe)
-    env = {"ACEHIP_RT_DATA_SYNTH": "1"}
-    _, plain = _run(exe, ["1"], env, tmp_path, "plain", timeout=1500)
-    for world in (2, 8):
-        out, shard = _run(exe, ["1"], dict(env, ACEHIP_SHARD_SIM=str(world), ACEHIP_PROFILE="1"), tmp_path, "shard%d" % world, timeout=1500)
-        assert shard["0.0"] == plain["0.0"], "ResNet-110 output differs with %d ranks" % world
-        assert "limb-sharded world %d (simulated)" % world in out
+# (One image of the ACE-generated ResNet-110 -- BASELINE configs[4] -- unsharded and over 2 and 8 simulated ranks is checked against the REFERENCE's
+# own output ciphertext since round 4: tests/test_gpu_gen_parity.py::test_resnet110_output_ciphertext_is_byte_identical_to_the_reference_cpu_run.)
 
 
 def _mock_rccl(tmp):
