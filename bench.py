@@ -149,6 +149,33 @@ def price_image(mix, st):
     return sum(parts.values()), parts
 
 
+def profile_scaled_image(prof, dev, host):
+    """Seconds ONE core of this host needs for one image, from the flat profile of the reference's full run on the dev container
+    (profiles/cpu_resnet20_devbox.json r04_profile: seconds per function family over RTM_MAIN_GRAPH, tests/c/ref_sampler.c) -- every family
+    moved to this host by the ratio of the reference primitive that IS that family's inner loop, timed on both machines by the same
+    `ref_dump mix` (cold operands): transforms by Ftt_fwd / Ftt_inv, the multiply family by Hw_modmul, the add family by Hw_modadd, the
+    permutations by Hw_rotate, the conversions by what Decompose_modup + Reduce_rns_base + Rescale_poly cost beyond their transforms,
+    memset / memcpy by the measured rates, the encoder by Encode_at_level.  Exact on the dev container by construction; what it carries to
+    another host is how that host's core runs each inner loop.  None when either side lacks a figure (an older ref_dump)."""
+    need = ("ntt_fwd_s", "ntt_inv_s", "hw_modmul_s", "hw_modadd_s", "hw_rotate_s", "decomp_modup_all_digits_s", "mod_down_s", "rescale_s",
+            "encode_s", "memset_GBs", "memcpy_GBs")
+    if any(k not in dev or k not in host for k in need):
+        return None, None
+    l, K, nd = dev["level"], dev["K"], dev["num_decomp"]
+
+    def conv_self(m):  # the three composites minus their transforms: nd(l+K) in Decompose_modup of every digit, K+l in Reduce_rns_base, l in Rescale_poly
+        t = 0.5 * (m["ntt_fwd_s"] + m["ntt_inv_s"])
+        return m["decomp_modup_all_digits_s"] + m["mod_down_s"] + m["rescale_s"] - (nd * (l + K) + (K + l) + l) * t
+
+    ratio = {"ntt_fwd": host["ntt_fwd_s"] / dev["ntt_fwd_s"], "ntt_inv": host["ntt_inv_s"] / dev["ntt_inv_s"],
+             "mul": host["hw_modmul_s"] / dev["hw_modmul_s"], "add": host["hw_modadd_s"] / dev["hw_modadd_s"],
+             "permute": host["hw_rotate_s"] / dev["hw_rotate_s"], "conversion": max(0.05, conv_self(host)) / max(1e-9, conv_self(dev)),
+             "memset": dev["memset_GBs"] / host["memset_GBs"], "memcpy": dev["memcpy_GBs"] / host["memcpy_GBs"],
+             "encode": host["encode_s"] / dev["encode_s"]}
+    parts = {f: sec * ratio.get(f, 1.0) for f, sec in prof["by_family_s"].items()}
+    return sum(parts.values()), parts
+
+
 def cpu_baseline(have_model):
     """Reference rtlib (oracle/_ref/ref_dump, built from /root/reference by oracle/Makefile) timed on this host BEFORE the
     GPU is touched: (1) one process on one core, (2) one process per usable physical core of one socket, all at once
@@ -254,7 +281,7 @@ def finish_cpu_baseline(res, stats_per_image):
     res["one_core"]["images_per_s"] = round(1.0 / s1, 8)
     res["one_core"]["image_s_by_family"] = {k: round(v, 2) for k, v in parts.items()}
     res["sample"] += ("; images/s: `ref_dump mix 65536 34 51 50 3 20` (the reference's NTT, Hw_modmul / Hw_modadd / Hw_rotate, Decompose_modup, "
-                      "Reduce_rns_base, Rescale_poly and encode at the workload's own parameter set; ~10 s per process, alone and on all "
+                      "Reduce_rns_base, Rescale_poly, encode, memset and memcpy at the workload's own parameter set; ~10 s per process, alone and on all "
                       "measured cores at once; operands rotate through a 0.7 GB pool, as cold as in the program) pricing the per-image "
                       "call statistics of this run family by family")
     res["kind"] = "reference-primitives-priced"  # NOT a run of the program on this host: the reference's primitives timed here, priced
@@ -274,13 +301,43 @@ def finish_cpu_baseline(res, stats_per_image):
                                           "inside Bootstrap)",
                                   "hot_operand_pricing_predicted_over_measured": (round(price_image(d["mix_level20"], stats_per_image)[0] / full["image_s"], 3)
                                                                                    if d.get("mix_level20") else None)}
+            med = (d.get("mix_level20_cold_median") or {}).get("median")
+            if med:  # single `mix` runs on the shared dev VM scatter by +-14 %: the same check with the per-key median of nine runs, and its range
+                mc = res["model_check"]
+                mc["with_median_of_nine_mix_runs"] = round(price_image(med, stats_per_image)[0] / full["image_s"], 3)
+                mc["range_over_the_nine_runs"] = [round(price_image(dict(med, **d["mix_level20_cold_median"][k]), stats_per_image)[0] / full["image_s"], 3)
+                                                  for k in ("min", "max")]
+                prof = d.get("r04_profile")
+                if prof:
+                    mc["residual"] = ("what the call statistics of OUR run do not carry of the reference's work, from the flat profile of its full run "
+                                      "(profiles/r04_ref_resnet20_profile.txt): it executes %d limb-transforms for the image, our runtime launches %d "
+                                      "(digits raised once per rotated ciphertext, fused bootstrap), and spends %.1f %% of the image in libc's memset / memcpy "
+                                      "(calloc'ed temporaries, polynomial copies)"
+                                      % (prof["transforms_per_image"]["NTT"] + prof["transforms_per_image"]["INTT"],
+                                         int(stats_per_image.get("ntt_launched", (0, 0, 0))[1]),
+                                         100.0 * (prof["by_family_s"].get("memset", 0) + prof["by_family_s"].get("memcpy", 0)) / prof["main_graph_s"]))
+                    # third estimate, the one reported as `value`: the PROFILE of the full run moved to this host family by family
+                    per_core_p = [profile_scaled_image(prof, med, m)[0] for m in res["mix_loaded"]]
+                    one_p, parts_p = profile_scaled_image(prof, med, res["mix_one_core"])
+                    if one_p and all(per_core_p):
+                        res["priced_by_call_statistics"] = {"value": res["value"], "unit": "images/s", "image_s_per_core_loaded": res["image_s_per_core_loaded"],
+                                                            "note": "price_image(): this run's call statistics x the host's primitive timings; prices "
+                                                                    "less work than the reference does (model_check), i.e. an upper bound for the CPU"}
+                        res["value"] = round(sum(1.0 / t for t in per_core_p), 8)
+                        res["image_s_per_core_loaded"] = round(sum(per_core_p) / len(per_core_p), 2)
+                        res["one_core"]["image_s_profile_scaled"] = round(one_p, 2)
+                        res["one_core"]["image_s_profile_scaled_by_family"] = {k: round(v, 1) for k, v in parts_p.items()}
+                        res["value_method"] = ("flat profile of the reference's full run of the unchanged generated ResNet-20 on the dev container (%.0f s over "
+                                               "Main_graph, seconds per function family) x host/dev ratio of the reference primitive that is each family's "
+                                               "inner loop (`ref_dump mix`, cold operands, timed here on every loaded core and on the dev container), summed "
+                                               "over the loaded cores" % prof["main_graph_s"])
             # second estimate, anchored to a RUN: the dev container's measured seconds per image moved to this host by the ratio of the
             # two hosts' priced images (the pricing only transfers, its absolute error cancels)
             res["anchored_to_full_run"] = {
                 "one_core_image_s": round(full["image_s"] * s1 / pred, 1),
                 "value": round(sum(1.0 / (full["image_s"] * t / pred) for t in per_core), 8), "unit": "images/s",
                 "note": "measured dev-container seconds per image (1 thread) x priced(this host) / priced(dev container), summed over the "
-                        "loaded cores: the lower of the two CPU estimates, i.e. the GPU/CPU ratio from `value` is the conservative one"}
+                        "loaded cores (one ratio for the whole image; `value` moves every function family by its own)"}
     _extrapolate_socket(res)
 
 

@@ -542,11 +542,21 @@ static int do_mix(uint32_t N, size_t L, size_t q0, size_t sf, size_t dnum, size_
     Free_plaintext(pt);
   }
   double t_enc = (now_s() - t0) / reps;
+  /* clearing and copying a polynomial, cold: what calloc'ed temporaries and Copy_poly cost the reference inside a run (the flat profile of a
+   * whole ResNet-20 image, profiles/r04_ref_resnet20_profile.json, has 5.1 % of the image in libc's memset and 2.7 % in its memcpy) */
+  const size_t poly_bytes = sizeof(int64_t) * level * N;
+  int          mem_reps = reps * 16;
+  t0 = now_s();
+  for (int i = 0; i < mem_reps; i++) memset(r[i % POOL]._data, 0, poly_bytes);
+  double set_GBs = (double)poly_bytes * mem_reps / (now_s() - t0) / 1e9;
+  t0 = now_s();
+  for (int i = 0; i < mem_reps; i++) memcpy(r[i % POOL]._data, a[(i + 5) % POOL]._data, poly_bytes);
+  double cpy_GBs = (double)poly_bytes * mem_reps / (now_s() - t0) / 1e9;
   printf("{\"kind\": \"reference\", \"operands\": \"cold (rotating pool of %d polynomials)\", \"N\": %u, \"L\": %zu, \"dnum\": %zu, \"K\": %zu, "
          "\"level\": %zu, \"num_decomp\": %zu, \"reps\": %d, "
          "\"ntt_fwd_s\": %.9f, \"ntt_inv_s\": %.9f, \"hw_modmul_s\": %.9f, \"hw_modadd_s\": %.9f, \"hw_rotate_s\": %.9f, "
-         "\"decomp_modup_all_digits_s\": %.9f, \"mod_down_s\": %.9f, \"rescale_s\": %.9f, \"encode_s\": %.9f}\n",
-         POOL, N, L, dnum, K, level, nd, reps, t_fwd, t_inv, t_mul, t_add, t_rot, t_modup, t_md, t_rs, t_enc);
+         "\"decomp_modup_all_digits_s\": %.9f, \"mod_down_s\": %.9f, \"rescale_s\": %.9f, \"encode_s\": %.9f, \"memset_GBs\": %.4f, \"memcpy_GBs\": %.4f}\n",
+         POOL, N, L, dnum, K, level, nd, reps, t_fwd, t_inv, t_mul, t_add, t_rot, t_modup, t_md, t_rs, t_enc, set_GBs, cpy_GBs);
   return 0;
 }
 

@@ -2,11 +2,13 @@
 """Flat profile of a REFERENCE run sampled by tests/c/ref_sampler.c (REF_SAMPLER_OUT): samples -> functions -> the families that
 bench.py's price_image() prices.  Test / measurement infrastructure.
 
-    python3 tools/ref_profile_report.py <samples file> [--json out.json] [--top 40]
+    python3 tools/ref_profile_report.py <samples file> [--seconds CPU_S] [--json out.json] [--top 40]
 
 Every line of the samples file is "<module> <offset> <count> <nearest exported symbol>".  Offsets are bucketed with the module's own
 symbol table (`nm -n --defined-only`: static functions included; stripped system libraries fall back to the exported name the
-sampler wrote).  1 sample = 1 ms of CPU time (ITIMER_PROF: user + system, so page faults count where they are taken).
+sampler wrote, hot spots of libc without one are named by the instruction they sit on).  ITIMER_PROF counts user + system time, so
+page faults count where they are taken; the timer ticks with the kernel's HZ (4 ms here), so --seconds (the CPU time of the span, from
+the run's own RTM_MAIN_GRAPH line) sets what a sample weighs.
 """
 import bisect
 import collections
@@ -17,22 +19,39 @@ import sys
 
 # function -> family.  Names are the reference's (fhe-cmplr/rtlib/ant/{poly,util}/src); what a name does was read off its source.
 FAMILIES = [
-    ("ntt", ("Ftt_fwd", "Ftt_inv", "Ntt_", "Intt_", "Forward_transform", "Inverse_transform")),
-    ("hw_elementwise", ("Hw_modadd", "Hw_modmul", "Hw_modsub", "Hw_rotate", "Add_poly", "Sub_poly", "Multiply_poly", "Mul_poly", "Scalars_integer_multiply",
-                        "Rotate_poly", "Automorphism", "Add_int64", "Mul_int64", "Fast_mul", "Mod_mul", "Mod_add", "Poly_")),
-    ("base_conversion", ("Fast_convert", "Base_conv", "Reduce_rns_base", "Raise_rns_base", "Decompose", "Rescale_poly", "Mod_down", "Mod_up", "Switch_modulus",
-                         "Approx_switch", "Fast_base", "Precompute", "Barrett")),
-    ("encode", ("Embedding", "Encode", "Fft_", "Transform_values_to_rns", "Reverse_bits", "Cexp", "cexp", "sincos", "Rotation_group")),
-    ("memory", ("memset", "memcpy", "memmove", "malloc", "calloc", "free", "realloc", "mmap", "munmap", "brk", "_int_", "sysmalloc", "madvise", "Alloc_", "Free_", "Init_poly", "Copy_poly")),
+    ("ntt_fwd", ("Forward_transform", "Ftt_fwd", "Ntt_")),
+    ("ntt_inv", ("Inverse_transform", "Ftt_inv", "Intt_")),
+    ("mul", ("Multiply_add", "Multiply_ntt", "Hw_modmul", "Multiply_poly", "Mul_poly", "Scalars_integer_multiply", "Scalar_integer_multiply", "Mul_int64", "Fast_mul", "Mod_mul")),
+    ("add", ("Add_poly", "Sub_poly", "Hw_modadd", "Hw_modsub", "Add_int64", "Mod_add")),
+    ("permute", ("Automorphism", "Hw_rotate", "Rotate_poly")),
+    ("conversion", ("Decompose_modup", "Fast_base_conv", "Rescale_poly", "Reduce_rns_base", "Raise_rns_base", "Base_conv", "Decompose", "Switch_modulus", "Approx_switch",
+                    "Transform_values_from_level0")),
+    ("encode", ("Embedding", "Encode", "Fft_", "Transform_values_to_rns", "Reverse_bits", "Bit_reverse", "__muldc3", "Rotation_group", "__log2", "lround", "sincos", "cexp")),
+    ("memset", ("memset", "brk", "munmap", "mmap", "madvise", "calloc", "malloc", "free", "_int_", "sysmalloc")),
+    ("memcpy", ("memcpy", "memmove", "Copy_poly")),
 ]
 
 
 def family_of(name):
+    bare = name.lstrip("_")
     for fam, keys in FAMILIES:
         for k in keys:
-            if name.startswith(k) or ("_" + k) in name or name.lstrip("_").startswith(k):
+            if bare.startswith(k.lstrip("_")) or k in name:
                 return fam
     return "other"
+
+
+def libc_spot(module, off):
+    """A PC inside a stripped libc: name it by the instruction it sits on (the string instructions of the memset / memcpy bodies)."""
+    try:
+        out = subprocess.run(["objdump", "-d", module, "--start-address=%#x" % off, "--stop-address=%#x" % (off + 8)], capture_output=True, text=True).stdout
+    except OSError:
+        return None
+    if "rep stos" in out:
+        return "memset (rep stos)"
+    if "rep movs" in out:
+        return "memcpy (rep movs)"
+    return None
 
 
 def symtab(module):
@@ -55,8 +74,13 @@ def main():
     path = sys.argv[1]
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
     tabs, by_func, total = {}, collections.Counter(), 0
+    total_hint = 50  # (only spots with more samples than this are disassembled)
+    seconds = float(sys.argv[sys.argv.index("--seconds") + 1]) if "--seconds" in sys.argv else None
     for ln in open(path):
         if ln.startswith("#"):
+            h = ln.split()
+            if seconds is None and "cpu_s" in h:
+                seconds = float(h[h.index("cpu_s") + 1])
             continue
         mod, off, cnt, near = ln.split()
         off, cnt = int(off, 16), int(cnt)
@@ -72,26 +96,27 @@ def main():
                     name = names[k]
         if name is None:
             name = near if near != "?" else "?"
+        if name == "?" and os.path.basename(mod).startswith("libc") and cnt > total_hint:
+            name = libc_spot(os.path.realpath(mod), off) or "?"
         by_func[(os.path.basename(mod), name)] += cnt
     fam = collections.Counter()
     for (mod, name), c in by_func.items():
-        f = family_of(name)
-        if f == "other" and mod.startswith("libc"):
-            f = "memory" if any(k in name for k in ("mem", "alloc", "free", "brk", "map")) else "other"
-        if f == "other" and mod.startswith("libm"):
-            f = "encode"  # (the only libm callers on the path: the encoder's twiddles and the rounding of embedded values)
-        fam[f] += c
-    print("%d samples = %.1f s of CPU" % (total, total / 1e3))
+        fam[family_of(name)] += c
+    # ITIMER_PROF ticks with the kernel's timer (CONFIG_HZ), not with the requested period: --seconds gives the CPU time of the sampled span
+    # (the run's own RTM_MAIN_GRAPH line) and every sample weighs seconds / samples
+    w = (seconds / total) if seconds else 1e-3
+    print("%d samples = %.1f s of CPU (%.3f ms per sample)" % (total, total * w, w * 1e3))
     print("\nby family:")
     for f, c in fam.most_common():
-        print("  %-18s %9.1f s  %5.1f %%" % (f, c / 1e3, 100.0 * c / total))
+        print("  %-18s %9.1f s  %5.1f %%" % (f, c * w, 100.0 * c / total))
     print("\nby function:")
     for (mod, name), c in by_func.most_common(top):
-        print("  %-22s %-44s %9.1f s  %5.1f %%  [%s]" % (mod[:22], name[:44], c / 1e3, 100.0 * c / total, family_of(name)))
+        print("  %-22s %-44s %9.1f s  %5.1f %%  [%s]" % (mod[:22], name[:44], c * w, 100.0 * c / total, family_of(name)))
     if "--json" in sys.argv:
         out = sys.argv[sys.argv.index("--json") + 1]
-        json.dump({"samples": total, "seconds": total / 1e3, "by_family_s": {f: c / 1e3 for f, c in fam.most_common()},
-                   "by_function_s": [{"module": m, "function": n, "s": c / 1e3, "family": family_of(n)} for (m, n), c in by_func.most_common(200)]},
+        json.dump({"samples": total, "seconds": round(total * w, 1), "ms_per_sample": round(w * 1e3, 4),
+                   "by_family_s": {f: round(c * w, 1) for f, c in fam.most_common()},
+                   "by_function_s": [{"module": m, "function": n, "s": round(c * w, 1), "family": family_of(n)} for (m, n), c in by_func.most_common(40)]},
                   open(out, "w"), indent=1)
 
 
