@@ -25,7 +25,9 @@ EX = os.path.join(ROOT, "oracle", "_ref", "examples")
 SEED = 20261004
 EXAMPLES = ["add", "add_const", "mul_const", "rotate", "rotate_02", "relin", "relin_02", "gemm", "gemm_02", "conv2d", "avg_pool",
             "relu", "bootstrap", "bootstrap_02"]
-MODELS = {"resnet20": ("resnet20_cifar10_pre", "resnet20_pt_entries.txt"), "resnet110": ("resnet110_cifar10_train", "resnet110_pt_entries.txt")}
+MODELS = {"resnet20": ("resnet20_cifar10_pre", "resnet20_pt_entries.txt"), "resnet32": ("resnet32_cifar10_pre", "resnet32_pt_entries.txt"),
+          "resnet32c100": ("resnet32_cifar100_pre", "resnet32c100_pt_entries.txt"), "resnet44": ("resnet44_cifar10_pre", "resnet44_pt_entries.txt"),
+          "resnet56": ("resnet56_cifar10_pre", "resnet56_pt_entries.txt"), "resnet110": ("resnet110_cifar10_train", "resnet110_pt_entries.txt")}
 
 
 def sha(path):
@@ -123,12 +125,17 @@ def main():
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refgen"])
             data["api_extras"] = {name: run_extras(args, tmp) for name, args in EXTRAS_SETS.items()}
             print(data["api_extras"])
-        for key in MODELS:
+        if any(k in what for k in ("examples", "ksw", "extras")):
+            json.dump(data, open(OUT, "w"), indent=1, sort_keys=True)
+            print("wrote", OUT)
+        for key in MODELS:  # (hours of one core each: the fixture file is read again and written right after every model)
             if key in what:
-                data.setdefault("models", {})[key] = run_model(key, tmp)
-                print(key, data["models"][key])
-    json.dump(data, open(OUT, "w"), indent=1, sort_keys=True)
-    print("wrote", OUT)
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(EX, "refgen_model_" + MODELS[key][0])])
+                res = run_model(key, tmp)
+                data = json.load(open(OUT)) if os.path.exists(OUT) else data
+                data.setdefault("models", {})[key] = res
+                json.dump(data, open(OUT, "w"), indent=1, sort_keys=True)
+                print(key, res, "\nwrote", OUT)
 
 
 if __name__ == "__main__":

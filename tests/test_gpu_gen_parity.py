@@ -260,6 +260,33 @@ def test_resnet110_output_ciphertext_is_byte_identical_to_the_reference_cpu_run(
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+# The other generated programs of the reference's dataset directory (rtlib/ant/dataset/resnet{32,44,56}_cifar10_pre.onnx.inc,
+# resnet32_cifar100_pre.onnx.inc, unchanged): one image each against the reference rtlib's CPU run with the injected key set
+# (0.9 / 1.3 / 1.6 h of one core each in the dev container; sigma per depth so that the logits keep real digits,
+# profiles/r04ae_sigma_sweep_more_models.txt).  A model without a fixture entry yet is skipped.
+# ------------------------------------------------------------------------------------------------------------------------------
+OTHER_MODELS = ["resnet32", "resnet32c100", "resnet44", "resnet56"]
+
+
+@pytest.mark.parametrize("key", OTHER_MODELS)
+def test_other_dataset_model_is_byte_identical_to_the_reference_cpu_run(key, tmp_path):
+    import model_weights
+
+    m = FIX.get("models", {}).get(key)
+    if m is None:
+        pytest.skip("tests/golden/gen_parity.json has no %s entry (tests/golden/gen_gen_parity.py %s)" % (key, key))
+    exe = os.path.join(EX_DIR, "model_" + model_weights.PROGRAM[key])
+    wfile, meta = model_weights.ensure(key, m["weights"]["sigma"])
+    if meta["md5"] != m["weights"]["md5"]:
+        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    env = {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(m["enc_seed"])}
+    out, got = _run(exe, ["1"], env, tmp_path, key, timeout=1500)
+    assert got == m["outputs"], "%s output ciphertext differs from the reference rtlib's CPU run" % key
+    assert _logits9(out) == [["%.9f" % v for v in m["logits9"]]]
+    assert max(abs(v) for v in m["logits9"]) > 0.02   # real digits
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 # The part of the reference's rt_ant surface that no checked-in generated program calls (tests/c/api_extras.c): Upscale_ciph /
 # Downscale_ciph, the with-scale encoders, the message-level validation helpers, the diagnostics -- same bytes, same text.
 # ------------------------------------------------------------------------------------------------------------------------------

@@ -12,8 +12,14 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRIES = {"resnet20": "resnet20_pt_entries.txt", "resnet110": "resnet110_pt_entries.txt"}
-SIGMA = {"resnet20": 0.2, "resnet110": 0.01}
+ENTRIES = {"resnet20": "resnet20_pt_entries.txt", "resnet32": "resnet32_pt_entries.txt", "resnet32c100": "resnet32c100_pt_entries.txt",
+           "resnet44": "resnet44_pt_entries.txt", "resnet56": "resnet56_pt_entries.txt", "resnet110": "resnet110_pt_entries.txt"}
+# the generated program of each key (rtlib/ant/dataset/<name>.onnx.inc)
+PROGRAM = {"resnet20": "resnet20_cifar10_pre", "resnet32": "resnet32_cifar10_pre", "resnet32c100": "resnet32_cifar100_pre",
+           "resnet44": "resnet44_cifar10_pre", "resnet56": "resnet56_cifar10_pre", "resnet110": "resnet110_cifar10_train"}
+# (the deeper the network, the smaller the largest sigma that stays in range: profiles/r04a_sigma_sweep.txt, r04ae_sigma_sweep_more_models.txt;
+#  ResNet-110 leaves the range at every sigma tried, profiles/r04f_sigma_sweep_resnet110.txt)
+SIGMA = {"resnet20": 0.2, "resnet32": 0.2, "resnet32c100": 0.2, "resnet44": 0.15, "resnet56": 0.12, "resnet110": 0.01}
 SEED = 2
 
 

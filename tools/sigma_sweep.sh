@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: logits of a generated ResNet on synthetic weight files of growing sigma (tools/model_weights.py) -- picks SIGMA
-#   tools/sigma_sweep.sh <resnet20|resnet110> sigma...
+#   tools/sigma_sweep.sh <resnet20|resnet32|resnet32c100|resnet44|resnet56|resnet110> sigma...
 set -e
 mkdir -p gpurun_out
 KEY=$1; shift
-case $KEY in resnet20) EXE=model_resnet20_cifar10_pre;; resnet110) EXE=model_resnet110_cifar10_train;; esac
+EXE=model_$(python3 -c "import sys; sys.path.insert(0, 'tools'); import model_weights; print(model_weights.PROGRAM['$KEY'])")
 for s in "$@"; do
   f=$(python3 tools/model_weights.py $KEY $s | python3 -c "import sys,ast; print(ast.literal_eval(sys.stdin.read())[0])")
   echo "$KEY sigma $s"
