@@ -30,13 +30,34 @@ constexpr u32 kMaxPrimes = ACEHIP_HW_STAGE ? 96 : 1;   // per-prime constants st
 struct V4 {
   ulong2 lo, hi;
 };
+// cache-policy experiment (tools/kernel_ab.sh): ACEHIP_HW_NT & 1: operand loads non-temporal, & 2: result stores non-temporal.
+// Measured (profiles/r04ag_kernel_ab_hw_nt.txt, kernel seconds per 24 images): 2.506 default, 2.589 / 2.520 / 2.597 with 1 / 2 / 3: off.
+#ifndef ACEHIP_HW_NT
+#define ACEHIP_HW_NT 0
+#endif
+typedef u64 hw_u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulong2 ld2(const u64* p) {
+#if ACEHIP_HW_NT & 1
+  const hw_u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const hw_u64x2_t*>(p));
+  return ulong2{v.x, v.y};
+#else
+  return *reinterpret_cast<const ulong2*>(p);
+#endif
+}
+__device__ __forceinline__ void st2(u64* p, const ulong2& v) {
+#if ACEHIP_HW_NT & 2
+  __builtin_nontemporal_store(hw_u64x2_t{v.x, v.y}, reinterpret_cast<hw_u64x2_t*>(p));
+#else
+  *reinterpret_cast<ulong2*>(p) = v;
+#endif
+}
 __device__ __forceinline__ V4 ld4(const u64* p) {
-  if (kHwLanes == 2) return V4{*reinterpret_cast<const ulong2*>(p), ulong2{0, 0}};
-  return V4{*reinterpret_cast<const ulong2*>(p), *reinterpret_cast<const ulong2*>(p + 2)};
+  if (kHwLanes == 2) return V4{ld2(p), ulong2{0, 0}};
+  return V4{ld2(p), ld2(p + 2)};
 }
 __device__ __forceinline__ void st4(u64* p, const V4& v) {
-  *reinterpret_cast<ulong2*>(p) = v.lo;
-  if (kHwLanes == 4) *reinterpret_cast<ulong2*>(p + 2) = v.hi;
+  st2(p, v.lo);
+  if (kHwLanes == 4) st2(p + 2, v.hi);
 }
 template <typename F>
 __device__ __forceinline__ V4 map2(const V4& a, const V4& b, F f) {
