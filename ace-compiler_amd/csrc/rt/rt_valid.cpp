@@ -27,7 +27,8 @@ void encode_value_with_scale(PLAINTEXT* res, double value, u32 level, double sca
   const u32 N = c.N;
   init_plaintext(res, N / 2, level, 0, scale, sf_degree);
   const int MAX_BITS_IN_WORD = 61, MAX_LOG_STEP = 60;
-  const int32_t log_scale = (int32_t)ceil(log2(fabs(value * scale)));
+  const double mag = fabs(value * scale);
+  const int32_t log_scale = mag >= 1.0 ? (int32_t)ceil(log2(mag)) : 0;  // (below 1 the value fits a word anyway; log2(0) is not asked for)
   const int32_t log_valid = log_scale <= MAX_BITS_IN_WORD ? log_scale : MAX_BITS_IN_WORD;
   const int32_t log_approx = log_scale - log_valid;
   const double scaled = value / pow(2, log_approx) * scale;
@@ -94,6 +95,7 @@ typedef std::complex<double> dcmplx;
 
 // Print_msg_range cipher_eval.c:171-203: extremes of the real and of the imaginary parts with their positions
 void print_msg_range(FILE* fp, const std::vector<cplx>& m) {
+  if (m.empty()) return;
   double max_r = m[0].real(), min_r = max_r, max_i = m[0].imag(), min_i = max_i;
   uint32_t max_rp = 0, min_rp = 0, max_ip = 0, min_ip = 0;
   for (uint32_t i = 1; i < m.size(); ++i) {
@@ -130,6 +132,7 @@ double* add_impl(const double* a, const double* b, uint64_t len) {
   return r;
 }
 double* relu_impl(const double* m, uint64_t len) {  // :126-141 (also reports the value range it saw)
+  if (len == 0) return (double*)malloc(sizeof(double));
   double lo = m[0], hi = m[0];
   double* r = (double*)malloc(sizeof(double) * len);
   for (uint64_t i = 0; i < len; ++i) {
