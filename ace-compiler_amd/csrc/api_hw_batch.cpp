@@ -92,6 +92,7 @@ static void plan_append(const HwBatchOp& o, u32 seg) {
 // ACEHIP_HW_TRAFFIC=1: limb loads / stores the elementwise launches actually perform, per op kind (the kernel's forwarding
 // rules replayed on the host), printed at exit -- where the bytes of the generated per-limb code go
 static std::atomic<u64> g_hw_traffic[9][4];  // [kind][ops, limb loads, limb stores, loads of memory all replicas share]
+static std::atomic<u64> g_hw_what_if[3];     // limb loads the same launches would make with 3, 4, 8 register entries instead of 2
 static bool hw_traffic_on() {
   static const bool on = [] {
     const bool v = getenv("ACEHIP_HW_TRAFFIC") != nullptr;
@@ -107,6 +108,8 @@ static bool hw_traffic_on() {
           ts += w;
         }
         fprintf(stderr, "[hw traffic] total limb loads %llu stores %llu\n", (unsigned long long)tl, (unsigned long long)ts);
+        fprintf(stderr, "[hw traffic] what if the kernel kept more results in registers: limb loads with 3 entries %llu, 4 entries %llu, 8 entries %llu\n",
+                (unsigned long long)g_hw_what_if[0], (unsigned long long)g_hw_what_if[1], (unsigned long long)g_hw_what_if[2]);
       });
     return v;
   }();
@@ -168,6 +171,33 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg, const DevCtx& d
         if (!zeroed.emplace(o.res, 1).second) fate_rezero++;
       } else if (zeroed.erase(o.res)) fate_over[kind]++;
     }
+  }
+  for (int w = 0; w < 3; ++w) {  // the same rule (a result replaces its own limb's entry, otherwise pushes the others down) with more entries
+    const int cap = w == 0 ? 3 : (w == 1 ? 4 : 8);
+    u64 loads = 0;
+    for (u32 sgm = 0; sgm < n_seg; ++sgm) {
+      const u64* e[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      auto miss = [&](const u64* x) {
+        for (int i = 0; i < cap; ++i)
+          if (e[i] == x) return false;
+        return true;
+      };
+      for (u32 k = args.seg_start[sgm]; k < args.seg_start[sgm + 1]; ++k) {
+        const HwBatchOp& o = args.op[k];
+        const u32 kind = o.kind & HW_OP_KIND_MASK;
+        if (kind != HW_OP_ZERO) {
+          loads += miss(o.a);
+          if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) loads += miss(o.b);
+          if (kind == HW_OP_MULADD) loads += miss(o.res);
+        }
+        int at = cap - 1;
+        for (int i = 0; i < cap; ++i)
+          if (e[i] == o.res) at = i;
+        for (int i = at; i > 0; --i) e[i] = e[i - 1];
+        e[0] = o.res;
+      }
+    }
+    g_hw_what_if[w] += loads;
   }
   for (u32 sgm = 0; sgm < n_seg; ++sgm) {
     const u64 *r0 = nullptr, *r1 = nullptr;  // the kernel's two register entries
