@@ -699,10 +699,11 @@ def main():
         # the REFERENCE rtlib was given for its CPU run of this program (tests/golden/gen_parity.json), the weights are that run's
         # file, and the first timed batch of every stream carries that run's image, encrypted with that run's randomness, in batch
         # position (stream index): its output ciphertext must hash to the reference's digest -- byte-identical to the CPU rtlib.
-        if not r110:
-            fix = reference_fixture("resnet20")
+        vkey = "resnet110" if r110 else "resnet20"  # (both have a reference run in the fixture: 2.6 h / 0.6 h of one CPU core)
+        if True:
+            fix = reference_fixture(vkey)
             if fix is None:
-                verify_note = "tests/golden/gen_parity.json has no resnet20 entry"
+                verify_note = "tests/golden/gen_parity.json has no %s entry" % vkey
             elif os.environ.get("ACEHIP_SEED", str(fix["seed"])) != str(fix["seed"]) or "ACEHIP_RT_DATA_FILE" in os.environ:
                 fix, verify_note = None, "ACEHIP_SEED / ACEHIP_RT_DATA_FILE set by the caller: not the fixture's keys or weights"
             else:
@@ -710,7 +711,7 @@ def main():
                 import model_weights
                 import tempfile
 
-                wfile, wmeta = model_weights.ensure("resnet20", fix["weights"]["sigma"])
+                wfile, wmeta = model_weights.ensure(vkey, fix["weights"]["sigma"])
                 os.environ["ACEHIP_RT_DATA_FILE"] = wfile
                 os.environ["ACEHIP_SEED"] = str(fix["seed"])
                 weights_note = "synthetic weights N(0,%g) (tools/make_weight_file.py, md5 %s)" % (fix["weights"]["sigma"], wmeta["md5"][:8])
@@ -783,8 +784,9 @@ def main():
             metric = "encrypted images/sec (ResNet-110 CIFAR-10, N=2^16) -- secondary measurement, not the BASELINE headline"
             workload = ("the workload of BASELINE configs[4] (ACE-compiled ResNet-110/CIFAR-10, resnet110_cifar10_train.onnx.inc: N=2^16, "
                         "36 464 weight plaintexts) run as REPLICAS: whole images per GPU, %d concurrent image streams per GPU x batches of %d images; "
-                        "synthetic image and weights (with N(0,0.05) weights a 110-layer network leaves the range of the bootstrap on "
-                        "both runtimes, so the logits are not meaningful: only the work is measured)" % (n_streams, n_batch))
+                        "synthetic image and %s (with synthetic weights a 110-layer network leaves the range of the bootstrap on "
+                        "both runtimes, so the logits are not meaningful: the work is measured, and the bytes are checked against the "
+                        "reference's CPU run)" % (n_streams, n_batch, weights_note))
     elif args.roofline_only:
         def step():
             return None
@@ -827,7 +829,7 @@ def main():
     barrier()
     elapsed = ranks.max_over_ranks(elapsed_local)
     verification = None
-    if use_model and not r110:
+    if use_model:
         verification = {"verified": None, "note": verify_note}
         if fix is not None:
             import glob

@@ -223,6 +223,9 @@ def test_bench_resnet110_workload_line():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["unit"] == "images/s" and d["value"] > 0 and "ResNet-110" in d["metric"] and "REPLICAS" in d["config"]["workload"]
+    # the timed image is the fixture's: its output ciphertext hashes to the digest of the reference rtlib's own 2.6-hour CPU run
+    if d["verification"].get("note") is None:
+        assert d["verified"] is True, d["verification"]
 
 
 @pytest.mark.parametrize("name", ["add", "add_const", "mult_const", "conv2d_keep_shape"])
