@@ -724,6 +724,7 @@ def main():
         gate = threading.Barrier(n_streams + 1)
         cmd = {"op": None}
         stream_logits = [None] * n_streams
+        stream_digests = [[] for _ in range(n_streams)]
         stream_stats = [None] * n_streams
         stream_err = []
 
@@ -738,8 +739,18 @@ def main():
                     if op == "step":
                         for j in range(cmd["n"]):               # images back to back: streams are not kept in lock step
                             # the FIRST batch of a verified region carries the fixture's image in position i of stream i's batch
-                            v = (i % n_batch, fix["enc_seed"], "%s_s%d" % (verify_prefix, i)) if (cmd.get("verify") and j == 0) else None
+                            # EVERY batch of a verified region carries the fixture's image, in position (stream + batch number) of the batch
+                            slot = (i + j) % n_batch
+                            v = (slot, fix["enc_seed"], "%s_s%d" % (verify_prefix, i)) if cmd.get("verify") else None
                             stream_logits[i] = one_image(v)
+                            if v is not None:  # hash the image's output ciphertext now (the next batch reuses the file names)
+                                import glob as _glob
+                                import hashlib as _hashlib
+
+                                path = "%s.%d" % (v[2], slot)
+                                stream_digests[i].append(_hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None)
+                                for f in _glob.glob(v[2] + ".*"):
+                                    os.remove(f)
                     elif op == "reset":
                         read_stats(reset=True)                 # statistics are per thread as well
                     elif op == "stats":
@@ -835,21 +846,17 @@ def main():
             import glob
             import hashlib
 
-            got = []
-            for i in range(n_streams):
-                path = "%s_s%d.%d" % (verify_prefix, i, i % n_batch)
-                got.append(hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None)
-            for f in glob.glob(verify_prefix + "_s*"):
-                os.remove(f)
-            ok_here = 1.0 if all(g == fix["digest"] for g in got) else 0.0
+            got = [g for i in range(n_streams) for g in stream_digests[i]]
+            ok_here = 1.0 if (len(got) == n_streams * args.steps and all(g == fix["digest"] for g in got)) else 0.0
             ok_all = -ranks.max_over_ranks(-ok_here)
             verification = {
                 "verified": bool(ok_all),
-                "what": "inside the timed region: the first batch of every image stream of every rank carries the fixture's image (batch "
-                        "position = stream index) under the fixture's key set and encryption randomness; sha256 of its output ciphertext "
-                        "(ACEHCT01) against the digest of the REFERENCE rtlib's CPU run of the same unchanged program "
-                        "(tests/golden/gen_parity.json, tests/c/gen_parity_ref.c)",
-                "reference_digest": fix["digest"], "digests_rank0": got, "streams_checked_per_rank": n_streams, "ranks": world}
+                "what": "inside the timed region: EVERY batch of every image stream of every rank carries the fixture's image (batch "
+                        "position = stream index + batch number, modulo the batch size) under the fixture's key set and encryption "
+                        "randomness; sha256 of its output ciphertext (ACEHCT01) against the digest of the REFERENCE rtlib's CPU run of the "
+                        "same unchanged program (tests/golden/gen_parity.json, tests/c/gen_parity_ref.c)",
+                "reference_digest": fix["digest"], "batches_checked_rank0": len(got), "batches_matching_rank0": sum(g == fix["digest"] for g in got),
+                "streams_per_rank": n_streams, "ranks": world}
     value = world * n_streams * n_batch * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cache_run = None
