@@ -161,6 +161,16 @@ def test_resnet20_batches_of_3_and_12_and_three_threads_match_the_reference(tmp_
     assert len(files) == 3 and all(_sha(f) == MODEL["outputs"]["0.0"] for f in files)
 
 
+def test_resnet20_batch_issued_in_replica_groups_matches_the_reference(tmp_path):
+    """ACEHIP_REP_CHUNK (api_internal.hpp for_replica_chunks, an experiment that stays switched off): the transform pipelines of a
+    12-image batch issued in groups of 5, 5 and 2 images -- the images are independent, so every output must keep its bytes"""
+    env = _model_env()
+    _, plain = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="12"), tmp_path, "g0", timeout=1500)
+    _, grouped = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="12", ACEHIP_REP_CHUNK="5"), tmp_path, "g5", timeout=1500)
+    assert plain["0.0"] == MODEL["outputs"]["0.0"]
+    assert grouped == plain and len(set(plain.values())) == 12
+
+
 def test_resnet20_logits_with_independent_keys_agree_to_ckks_precision(tmp_path):
     """the tolerance-level check, now with digits: OUR random keys and encryption randomness (no seed), same weights and image --
     the logits agree with the reference's to 5e-3 of the largest one.  (Independent keys mean independent CKKS noise: every one of the
