@@ -269,6 +269,26 @@ def test_resnet110_output_ciphertext_is_byte_identical_to_the_reference_cpu_run(
     assert _logits9(out) == [["%.9f" % v for v in MODEL110["logits9"]]]
 
 
+def test_resnet110_sharded_over_two_processes_matches_the_reference_cpu_run(tmp_path):
+    """configs[4] with ranks that are PROCESSES: the limbs of one ResNet-110 image spread over two processes that exchange them through the
+    RCCL entry points (tests/c/mock_rccl.c serves them on the one-GPU test box; on a node the same program dlopens librccl) -- both
+    ranks end with the output ciphertext of the reference rtlib's CPU run, and limbs did travel"""
+    import hashlib
+
+    from test_gpu_batch_shard import _mock_rccl, _run_ranks
+
+    exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
+    if not os.path.exists(exe):
+        pytest.skip("workloads/_gen/examples not built")
+    env = dict(_model110_env(), ACEHIP_RCCL_LIB=_mock_rccl(tmp_path))
+    assert str(FIX["seed"]) == "20261004"  # (_run_ranks seeds the ranks with it)
+    for r, (out, dumps) in enumerate(_run_ranks(exe, ["1"], 2, env, tmp_path, "r110mp2", timeout=1500)):
+        got = {k: hashlib.sha256(v).hexdigest() for k, v in dumps.items()}
+        assert got == MODEL110["outputs"], "rank %d: ResNet-110 output differs from the reference rtlib's CPU run" % r
+        line = [ln for ln in out.splitlines() if "limb exchanges:" in ln]
+        assert line and int(line[0].split("limb exchanges:")[1].split()[0]) > 0 and "(simulated)" not in out, out[-1500:]
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # The other generated programs of the reference's dataset directory (rtlib/ant/dataset/resnet{32,44,56}_cifar10_pre.onnx.inc,
 # resnet32_cifar100_pre.onnx.inc, unchanged): one image each against the reference rtlib's CPU run with the injected key set
