@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from .build import LIB, build
+from .build import LIB, build, source_fingerprint
 
 _u32, _u64, _vp, _i32 = C.c_uint32, C.c_uint64, C.c_void_p, C.c_int32
 
@@ -16,6 +16,7 @@ class AceHipError(RuntimeError):
 
 # (name, restype, argtypes) for every symbol declared in include/acehip.h
 SYMBOLS = [
+    ("acehip_source_fingerprint", C.c_char_p, []),
     ("acehip_last_error", C.c_char_p, []),
     ("acehip_device_count", C.c_int, []),
     ("acehip_ctx_create", _vp, [_u32, _u32, _u32, _u32, _u32, C.c_int]),
@@ -142,13 +143,18 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB
-    if not os.path.exists(p):
-        build()
+    if path is None:
+        build()  # (re)builds when the library is missing or carries another fingerprint than the sources beside it
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if path is None:  # the in-tree library must have been built from the in-tree sources: never run a stale binary silently
+        got, want = lib.acehip_source_fingerprint().decode(), source_fingerprint()
+        if got != want:
+            raise RuntimeError("libacehip.so was built from other sources (fingerprint %s) than ace-compiler_amd/csrc + include "
+                               "(%s): rebuild with `python -m ace_compiler_amd.build --force`" % (got, want))
     if path is None:
         _lib = lib
     return lib

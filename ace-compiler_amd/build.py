@@ -13,6 +13,7 @@
 
 Objects are compiled one per source into lib/obj/ and reused by the shared libraries and the archives.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -25,7 +26,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacehip.so")
 SOURCES = ["kernels.hip", "ntt_fast.hip", "keyswitch.hip", "rt_kernels.hip", "embed.hip", "hw_batch.hip", "shard.hip", "api_core.cpp", "api_hw_batch.cpp", "api_ops.cpp", "api_shard.cpp", "host_params.cpp"]
-HEADERS = ["kernels.hpp", "api_internal.hpp", "device_arith.hpp", "host_params.hpp", "rou_table.inc", os.path.join("..", "..", "include", "acehip.h")]
+# every header / include file of csrc/ (an object is rebuilt when ANY of them changes: cheaper than tracking who includes what)
+HEADERS = sorted(n for n in os.listdir(CSRC) if n.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "acehip.h")]
 ROCM_LIB = "/opt/rocm/lib"
 # keyswitch.hip: the matrix-core base conversion reads its MFMA results with VALU instructions right away; with the results in
 # VGPRs (instead of the accumulator half of the register file) that needs no v_accvgpr_read per value
@@ -46,6 +48,73 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# ---- staleness is decided by CONTENT, not by mtime (the .so files are untracked build outputs that travel with a snapshot of the
+# tree: a library older or newer than the sources beside it must never be loaded silently).
+#  * every object has a sidecar <obj>.dep = sha256 of its source, the headers it may include and its command line; it is rebuilt
+#    when that differs;
+#  * both shared libraries embed the fingerprint of ALL sources (tools/csrc_fingerprint.py: csrc/**, include/**) as the string
+#    "ACEHIP_SRC_FPR=<16 hex>" and export it (acehip_source_fingerprint / acehip_rt_source_fingerprint); needs_build() reads it out
+#    of the file, binding.load_library() compares it with the sources after dlopen, and the shim's Prepare_context aborts when the
+#    two libraries disagree.
+FPR_TAG = b"ACEHIP_SRC_FPR="
+
+
+def source_fingerprint():
+    root = os.path.dirname(HERE)
+    h = hashlib.sha256()
+    files = []
+    for top in (os.path.join(root, "include"), CSRC):
+        for d, _, names in os.walk(top):
+            files += [os.path.join(d, n) for n in names if n.endswith((".h", ".hip", ".hpp", ".cpp", ".inc"))]
+    for p in sorted(files):
+        h.update(os.path.relpath(p, root).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def embedded_fingerprint(lib):
+    """the fingerprint a built library carries (None: no library / an old one without the tag)"""
+    try:
+        data = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = data.find(FPR_TAG)
+    return data[i + len(FPR_TAG):i + len(FPR_TAG) + 16].decode("ascii", "replace") if i >= 0 else None
+
+
+def _dep_hash(cmd, deps):
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for d in deps:
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
+def _stale(obj, cmd, deps):
+    try:
+        return not os.path.exists(obj) or open(obj + ".dep").read() != _dep_hash(cmd, deps)
+    except OSError:
+        return True
+
+
+def _compile(cmd, obj, deps, verbose):
+    _run(cmd, verbose)
+    with open(obj + ".dep", "w") as f:
+        f.write(_dep_hash(cmd, deps))
+
+
+def _fingerprint_object(symbol, verbose):
+    """one tiny C object that carries the fingerprint string and exports it through `symbol`"""
+    fpr = source_fingerprint()
+    src, obj = os.path.join(OBJDIR, "_%s.c" % symbol), os.path.join(OBJDIR, "_%s.o" % symbol)
+    text = ('/* written by ace-compiler_amd/build.py */\nstatic const char fpr_[] = "%s%s";\n'
+            'const char* %s(void) { return fpr_ + %d; }\n' % (FPR_TAG.decode(), fpr, symbol, len(FPR_TAG)))
+    if not os.path.exists(obj) or not os.path.exists(src) or open(src).read() != text:
+        with open(src, "w") as f:
+            f.write(text)
+        _run([shutil.which("gcc") or "gcc", "-O1", "-fPIC", "-c", src, "-o", obj], verbose)
+    return obj
+
+
 def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd))
@@ -64,25 +133,27 @@ def _hip_objects(force, verbose):
     for src in SOURCES:
         s, o = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".", "_") + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
+        cmd = [hipcc()] + flags + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        if force or _stale(o, cmd, [s] + hdrs):
+            jobs.append((cmd, o, [s] + hdrs))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            list(ex.map(lambda c: _run(c, verbose), jobs))
+            list(ex.map(lambda j: _compile(j[0], j[1], j[2], verbose), jobs))
     return objs, bool(jobs)
 
 
 def needs_build():
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + hdrs)
+    """the library is missing or was built from other sources than the ones beside it"""
+    return embedded_fingerprint(LIB) != source_fingerprint()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     objs, _ = _hip_objects(force, verbose)
-    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, verbose)
+    fobj = _fingerprint_object("acehip_source_fingerprint", verbose)
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [fobj], verbose)
     return LIB
 
 
@@ -114,13 +185,16 @@ def build_rt(force=False, verbose=False):
     for src in RT_SOURCES:
         s, o = os.path.join(RT_DIR, src), os.path.join(OBJDIR, "rt_" + src.replace(".", "_") + ".o")
         rt_objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            # -ffp-contract=off: the FP64 canonical embedding must round like the reference's (no FMA fusion)
-            jobs.append([cxx, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-c", s, "-o", o])
+        # -ffp-contract=off: the FP64 canonical embedding must round like the reference's (no FMA fusion)
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-c", s, "-o", o]
+        if force or _stale(o, cmd, [s] + hdrs):
+            jobs.append((cmd, o, [s] + hdrs))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            list(ex.map(lambda c: _run(c, verbose), jobs))
-    if force or _newer(RT_LIB, rt_objs + [LIB]):
+            list(ex.map(lambda j: _compile(j[0], j[1], j[2], verbose), jobs))
+    rt_fobj = _fingerprint_object("acehip_rt_source_fingerprint", verbose)
+    rt_objs.append(rt_fobj)
+    if force or jobs or embedded_fingerprint(RT_LIB) != source_fingerprint() or _newer(RT_LIB, [LIB]):
         _run([cxx, "-shared", "-fPIC", "-o", RT_LIB] + rt_objs + ["-L", LIBDIR, "-lacehip", "-Wl,-rpath,$ORIGIN"], verbose)
     # libFHErt_common: the reference link line names it too; everything lives in libFHErt_ant here
     stub_c, stub_o = os.path.join(OBJDIR, "_common_stub.c"), os.path.join(OBJDIR, "_common_stub.o")
@@ -134,10 +208,11 @@ def build_rt(force=False, verbose=False):
         _run(["ar", "rcs", RT_COMMON_ARCHIVE, stub_o], verbose)
         os.remove(stub_c)
     # static archive of every object + the ld script under the reference's archive name
-    if force or _newer(RT_OBJS_ARCHIVE, rt_objs + hip_objs) or not os.path.exists(RT_ARCHIVE):
+    hip_fobj = os.path.join(OBJDIR, "_acehip_source_fingerprint.o")
+    if force or _newer(RT_OBJS_ARCHIVE, rt_objs + hip_objs + [hip_fobj]) or not os.path.exists(RT_ARCHIVE):
         if os.path.exists(RT_OBJS_ARCHIVE):
             os.remove(RT_OBJS_ARCHIVE)
-        _run(["ar", "rcs", RT_OBJS_ARCHIVE] + rt_objs + hip_objs, verbose)
+        _run(["ar", "rcs", RT_OBJS_ARCHIVE] + rt_objs + hip_objs + [hip_fobj], verbose)
         with open(RT_ARCHIVE, "w") as f:
             f.write("/* GNU ld script standing in for the archive name of the reference link line (scripts/perf.py:202-207):\n"
                     "   the objects are in libFHErt_ant_objs.a; a HIP program also needs the HIP runtime and the C++ runtime, which a\n"

@@ -332,6 +332,11 @@ void Prepare_context() {
   }
   CKKS_PARAMS* prm = Get_context_params();
   RT_ASSERT(prm != nullptr, "Get_context_params() returned NULL");
+  // both libraries carry the fingerprint of the sources they were built from (ace-compiler_amd/build.py): a shim next to a kernel
+  // library of another revision is a build accident that must not run
+  RT_ASSERT(strcmp(acehip_source_fingerprint(), acehip_rt_source_fingerprint()) == 0,
+            "libFHErt_ant (sources %s) and libacehip (sources %s) were built from different revisions: rebuild both "
+            "(python -m ace_compiler_amd.build --force)", acehip_rt_source_fingerprint(), acehip_source_fingerprint());
   RT_ASSERT(acehip_device_count() > 0, "no MI355X visible: the rt_ant HIP provider has no CPU fallback");
   auto* c = new Context();
   c->prm = prm;

@@ -302,6 +302,14 @@ struct HwqStats {
   size_t res_limbs = 0, res_limbs_freed = 0;  // distinct result limbs per flush; those whose block was already freed
 };
 thread_local HwqStats g_hwq_stats;
+// ACEHIP_PROFILE: limbs a handed-over queue stored that a LATER queue loads again although no direct launch in between
+// named them (what keeping such ops queued across declared launches can save at most)
+struct ReloadStats {
+  std::map<const u64*, size_t> stored;  // limb -> index of the hand-over that wrote it
+  size_t loads = 0, reloads = 0, reload_dist[6] = {};  // distance in hand-overs: 1, 2, <=4, <=8, <=16, more
+  size_t erased_by_touch = 0, cleared = 0;
+};
+thread_local ReloadStats g_reload;
 // ---- lazy zero fills ----
 // Generated code zero-fills a result (Init_ciph_*, Alloc_poly) long before the first per-limb op accumulates into it:
 // a rotation with its key-switch lies in between, whose direct launches hand the queue over.  Issued there, the fill is
@@ -325,6 +333,13 @@ void hw_stats_print() {
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
   printf("[ACEHIP] hw queue: %zu distinct result limbs, %zu of them in blocks freed before the flush\n", s.res_limbs, s.res_limbs_freed);
   muc_stats_print();
+  {
+    const ReloadStats& r = g_reload;
+    printf("[ACEHIP] hw queue: %zu limb loads named by queued ops; %zu of them re-load a limb an EARLIER hand-over stored with no direct launch naming it in between "
+           "(hand-overs apart 1:%zu 2:%zu <=4:%zu <=8:%zu <=16:%zu more:%zu); %zu stored limbs consumed by declared launches, %zu map resets by undeclared ones\n",
+           r.loads, r.reloads, r.reload_dist[0], r.reload_dist[1], r.reload_dist[2], r.reload_dist[3], r.reload_dist[4], r.reload_dist[5],
+           r.erased_by_touch, r.cleared);
+  }
   const LazyStats& z = g_lazy_stats;
   printf("[ACEHIP] lazy zero fills: %zu limbs deferred; %zu met their first consumer in the queue, %zu issued for a launch, %zu dropped (block freed or rewritten)\n",
          z.deferred, z.met_consumer, z.materialised, z.dropped);
@@ -600,6 +615,45 @@ void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
   static const bool lazy_on = getenv("ACEHIP_LAZY_ZERO") == nullptr || atoi(getenv("ACEHIP_LAZY_ZERO")) != 0;
   // (limb-sharded execution: a deferred fill does not remember which rank owns its limb, so nothing is deferred there)
   lazy_meet_queue(touch, n_touch, defer && lazy_on && ctx().shard_world <= 1);
+  if (ctx().profile) {
+    ReloadStats& rl = g_reload;
+    const size_t Nw = ctx().N;
+    if (!defer) {
+      rl.cleared += !rl.stored.empty();
+      rl.stored.clear();
+    } else {
+      for (size_t i = 0; i < n_touch; ++i) {
+        if (!touch[i].p || !touch[i].words) continue;
+        const u64* lo = (const u64*)touch[i].p;
+        for (auto it = rl.stored.lower_bound(lo - (Nw - 1)); it != rl.stored.end() && it->first < lo + touch[i].words;) {
+          it = rl.stored.erase(it);
+          rl.erased_by_touch++;
+        }
+      }
+    }
+  }
+  if (ctx().profile && !g_hwq.empty()) {
+    ReloadStats& rl = g_reload;
+    const size_t idx = g_hwq_stats.flushes + 1;
+    std::set<const u64*> seen;  // first reference inside this queue only
+    auto load = [&](const void* p) {
+      const u64* x = (const u64*)p;
+      if (!x || !seen.insert(x).second) return;
+      rl.loads++;
+      auto it = rl.stored.find(x);
+      if (it == rl.stored.end()) return;
+      rl.reloads++;
+      const size_t d = idx - it->second;
+      rl.reload_dist[d <= 1 ? 0 : d == 2 ? 1 : d <= 4 ? 2 : d <= 8 ? 3 : d <= 16 ? 4 : 5]++;
+    };
+    for (const auto& o : g_hwq) {
+      if (o.op != ACEHIP_HW_ZERO) load(o.a);
+      if (op_has_b(o.op)) load(o.b);
+      if (o.op == ACEHIP_HW_MULADD) load(o.res);
+      seen.insert(o.res);
+    }
+    for (const auto& o : g_hwq) rl.stored[o.res] = idx;
+  }
   if (g_hwq.empty()) {
     limbo_release();
     return;

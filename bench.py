@@ -585,6 +585,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="model workloads only: run although the timed images cannot be checked against the reference's CPU-run digest "
+                         "(without it a run that cannot verify, or whose digests differ, prints its line and EXITS NON-ZERO)")
     ap.add_argument("--workload", choices=["auto", "resnet20", "resnet110", "keyswitch"], default="auto",
                     help="auto / resnet20: the headline (BASELINE configs[3]); resnet110: the workload of configs[4] (ACE-generated "
                          "ResNet-110) as replicas x image streams on each GPU -- a secondary measurement, not the headline; "
@@ -711,12 +714,12 @@ def main():
                 import model_weights
                 import tempfile
 
-                wfile, wmeta = model_weights.ensure(vkey, fix["weights"]["sigma"])
+                wfile, wmeta = model_weights.ensure(vkey, fix["weights"]["sigma"], fix["weights"].get("gen", "numpy"))
                 os.environ["ACEHIP_RT_DATA_FILE"] = wfile
                 os.environ["ACEHIP_SEED"] = str(fix["seed"])
                 weights_note = "synthetic weights N(0,%g) (tools/make_weight_file.py, md5 %s)" % (fix["weights"]["sigma"], wmeta["md5"][:8])
                 if wmeta["md5"] != fix["weights"]["md5"]:
-                    fix, verify_note = None, "this numpy writes a different weight file than the fixture's (md5 %s vs %s)" % (wmeta["md5"], fix["weights"]["md5"])
+                    fix, verify_note = None, "generator %s writes a different weight file here than the fixture's (md5 %s vs %s)" % (wmeta["gen"], wmeta["md5"], fix["weights"]["md5"])
                 else:
                     verify_prefix = os.path.join(tempfile.gettempdir(), "acehip_bench_verify_%d_r%d" % (os.getpid(), rank))
         fhe, _ = load_model_runtime(local_rank)
@@ -1086,6 +1089,12 @@ def main():
                 json.dump(shard_leg, open(os.path.join(ROOT, "gpurun_out", "limb_sharded_leg.json"), "w"), indent=1)
     ranks.close()
     rt.close()
+    # a model run that did not prove its timed images byte-identical to the reference's CPU run is not a result (the line above says
+    # why: "verified" / "verification.note"); --no-verify is for experiments that change keys, weights or kernels on purpose
+    if use_model and not (args.no_verify or os.environ.get("ACEHIP_BENCH_NO_VERIFY")) and (verification is None or verification.get("verified") is not True):
+        sys.stderr.write("[bench] NOT VERIFIED against the reference digest (%s): exit 3 (--no-verify to run anyway)\n" %
+                         ((verification or {}).get("note") or "digests differ"))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

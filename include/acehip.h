@@ -36,6 +36,10 @@ typedef void*             acehip_stream; /* hipStream_t */
 
 const char* acehip_last_error(void);
 int         acehip_device_count(void);
+/* 16 hex digits: sha256 over the sources (ace-compiler_amd/csrc, include) this library was built from, embedded by the build
+ * (ace-compiler_amd/build.py).  The Python binding compares it with the sources beside the library, the rt_ant shim with its own
+ * (acehip_rt_source_fingerprint, include/rt_ant/rt_api.h): a stale binary is an error, never a silent run.  No reference counterpart. */
+const char* acehip_source_fingerprint(void);
 
 /* ---- context: Prepare_context -> Init_ckks_parameters_with_prime_size (src/rtlib/context.c:29-86,
  * src/util/ckks_parameters.c:60-101, src/util/crt.c:574-585).  Generates the q/p prime chains, psi,

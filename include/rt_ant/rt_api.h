@@ -11,6 +11,9 @@ void       Set_output_data(const char* name, size_t idx, CIPHER data);
  * lazily in batches.  Code that touches that memory itself (HIP / acehip_* calls on the raw pointers) calls
  * this first: it submits everything still queued and waits for the device. */
 void       Acehip_rt_sync(void);
+/* Extension: fingerprint of the sources this library was built from (16 hex digits, embedded by the build); Prepare_context aborts
+ * when it differs from libacehip's acehip_source_fingerprint() -- the two libraries of one build always agree. */
+const char* acehip_rt_source_fingerprint(void);
 /* Extension: a thread other than the one that called Prepare_context attaches to that context on its first API
  * call (shared keys; own scratch, pool, queue, HIP stream); before it ends it may give those back. */
 void       Acehip_rt_thread_release(void);

@@ -36,7 +36,7 @@ def _run(exe, args, env_extra, tmp, tag, timeout=900):
 
 def _need(exe):
     if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples not built (needs /root/reference: make -C workloads)")
+        pytest.fail("workloads/_gen/examples not built (needs /root/reference: make -C workloads) -- build outputs of the dev container that must travel with the snapshot")
 
 
 @pytest.mark.parametrize("name", ["rotate", "relin", "conv2d", "bootstrap", "bootstrap_02"])
@@ -196,7 +196,7 @@ def test_bench_shard_mode_one_rank_joins_rccl():
 
     lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet20.so")
     if not os.path.exists(lib):
-        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+        pytest.fail("workloads/_gen/models not built (needs /root/reference: tools/build_models.py) -- build outputs of the dev container that must travel with the snapshot")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--workload", "resnet20", "--batch", "2",
                         "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=900, env=env)
@@ -216,7 +216,7 @@ def test_bench_limb_sharded_leg_runs_after_the_headline_line():
 
     lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet20.so")
     if not os.path.exists(lib):
-        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+        pytest.fail("workloads/_gen/models not built (needs /root/reference: tools/build_models.py) -- build outputs of the dev container that must travel with the snapshot")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["ACEHIP_BENCH_FORCE_SHARD_LEG"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--streams", "1", "--batch", "2", "--steps", "1",

@@ -21,7 +21,7 @@ EXAMPLES = ["add", "add_const", "mul_const", "rotate", "rotate_02", "relin", "re
 def test_reference_generated_example(name):
     exe = os.path.join(EX_DIR, "eg_" + name)
     if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples not built (needs /root/reference: make -C workloads examples)")
+        pytest.fail("workloads/_gen/examples not built (needs /root/reference: make -C workloads examples) -- build outputs of the dev container that must travel with the snapshot")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SUCESS!" in r.stdout
@@ -136,7 +136,7 @@ def test_reference_style_openmp_main_shares_one_context():
 
     exe = os.path.join(EX_DIR, "modelomp_resnet20_cifar10_pre")
     if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples/modelomp_* not built (needs /root/reference: make -C workloads models)")
+        pytest.fail("workloads/_gen/examples/modelomp_* not built (needs /root/reference: make -C workloads models) -- build outputs of the dev container that must travel with the snapshot")
     env = dict(os.environ, OMP_NUM_THREADS="3", GPU_MAX_HW_QUEUES="8", ACEHIP_RT_DATA_SYNTH="1")
     r = subprocess.run([exe, "6"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -195,7 +195,7 @@ def test_resnet110_workload_runs_on_one_gpu():
 
     exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
     if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples/model_* not built (needs /root/reference: make -C workloads models)")
+        pytest.fail("workloads/_gen/examples/model_* not built (needs /root/reference: make -C workloads models) -- build outputs of the dev container that must travel with the snapshot")
     env = dict(os.environ, ACEHIP_RT_DATA_SYNTH="1")
     r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -217,7 +217,7 @@ def test_bench_resnet110_workload_line():
 
     lib = os.path.join(ROOT, "workloads", "_gen", "models", "libmodel_resnet110.so")
     if not os.path.exists(lib):
-        pytest.skip("workloads/_gen/models not built (needs /root/reference: tools/build_models.py)")
+        pytest.fail("workloads/_gen/models not built (needs /root/reference: tools/build_models.py) -- build outputs of the dev container that must travel with the snapshot")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "resnet110", "--no-cpu-baseline", "--streams", "1",
                         "--batch", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -237,6 +237,6 @@ def test_ckks_level_provider_programs(name):
     expected output (tolerance 1e-2) and prints SUCCESS!."""
     exe = os.path.join(EX_DIR, "egseal_" + name)
     if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples/egseal_* not built (needs /root/reference: make -C workloads provider)")
+        pytest.fail("workloads/_gen/examples/egseal_* not built (needs /root/reference: make -C workloads provider) -- build outputs of the dev container that must travel with the snapshot")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SUCCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -213,7 +213,7 @@ def test_pt_get_serves_reference_plaintext_file(stub, cfg, tmp_path):
     else:
         ref = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
         if not os.path.exists(ref):
-            pytest.skip("oracle/_ref/ref_dump not built (needs /root/reference)")
+            pytest.fail("oracle/_ref/ref_dump not built (needs /root/reference) -- a build output of the dev container that must travel with the snapshot")
         path = str(tmp_path / "pt.bin")
         subprocess.check_call([ref, "ptfile"] + (gen % path).split())
     stub.Stub_set_data_file.argtypes = [C.c_char_p, C.c_int]

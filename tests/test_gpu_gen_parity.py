@@ -40,8 +40,10 @@ def _sha(path):
 
 
 def _run(exe, args, env_extra, tmp, tag, timeout=900):
-    if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples not built (needs /root/reference: make -C workloads)")
+    # a committed fixture + a missing workload binary is a FAILURE under -m gpu: the binaries are build outputs of the dev container
+    # (__graft_entry__.build -> make -C workloads) that travel with the snapshot; a box without them proves nothing and must say so
+    assert os.path.exists(exe), "%s is missing: the generated programs were not built (make -C workloads; needs /root/reference) " \
+                                "or did not travel -- the parity evidence cannot be produced" % os.path.relpath(exe, ROOT)
     prefix = os.path.join(str(tmp), tag)
     env = dict(os.environ, ACEHIP_SEED=str(FIX["seed"]), ACEHIP_DUMP_OUTPUT=prefix, **env_extra)
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout, env=env)
@@ -109,14 +111,21 @@ MODEL = FIX.get("models", {}).get("resnet20")
 MODEL_EXE = os.path.join(EX_DIR, "model_resnet20_cifar10_pre")
 
 
-def _model_env(extra=None):
+def _weights_of(key, m):
+    """the weight file the reference run of fixture entry m used, regenerated here; a different md5 is a FAILURE (the entry's
+    generator -- "ih12": integer-only, tools/make_weight_file.py -- must write the same bytes everywhere; "numpy" entries of rounds 1-4
+    depend on numpy's stream and say so when it moves)"""
     import model_weights
 
-    if MODEL is None:
-        pytest.skip("tests/golden/gen_parity.json has no resnet20 entry (tests/golden/gen_gen_parity.py resnet20)")
-    wfile, meta = model_weights.ensure("resnet20", MODEL["weights"]["sigma"])
-    if meta["md5"] != MODEL["weights"]["md5"]:
-        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    wfile, meta = model_weights.ensure(key, m["weights"]["sigma"], m["weights"].get("gen", "numpy"))
+    assert meta["md5"] == m["weights"]["md5"], "the synthetic weight file of %s (generator %s) has md5 %s here, the reference run used %s" % (
+        key, meta["gen"], meta["md5"], m["weights"]["md5"])
+    return wfile
+
+
+def _model_env(extra=None):
+    assert MODEL is not None, "tests/golden/gen_parity.json has no resnet20 entry (tests/golden/gen_gen_parity.py resnet20)"
+    wfile = _weights_of("resnet20", MODEL)
     env = {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(MODEL["enc_seed"])}
     env.update(extra or {})
     return env
@@ -224,8 +233,7 @@ def test_key_switch_base_forms_match_the_reference(name, tmp_path):
     our results have the bytes of the reference's BASE forms.  The fixture also records which of the reference's OPT forms are NOT
     bit-equal to its own base forms (ModDown hoisted over a sum, ModDown merged with Rescale, both plus a hoisted ModUp): a runtime
     must not "optimise" into those -- only the hoisted ModUp keeps the bits, and that one the runtime does (rt_poly.cpp ModupCache)."""
-    if not KSW:
-        pytest.skip("tests/golden/gen_parity.json has no ksw_variants entry (tests/golden/gen_gen_parity.py ksw)")
+    assert KSW, "tests/golden/gen_parity.json has no ksw_variants entry (tests/golden/gen_gen_parity.py ksw)"
     exe = _build_ksw(tmp_path)
     d = tmp_path / "out"
     d.mkdir()
@@ -249,13 +257,8 @@ MODEL110 = FIX.get("models", {}).get("resnet110")
 
 
 def _model110_env():
-    import model_weights
-
-    if MODEL110 is None:
-        pytest.skip("tests/golden/gen_parity.json has no resnet110 entry (tests/golden/gen_gen_parity.py resnet110)")
-    wfile, meta = model_weights.ensure("resnet110", MODEL110["weights"]["sigma"])
-    if meta["md5"] != MODEL110["weights"]["md5"]:
-        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    assert MODEL110 is not None, "tests/golden/gen_parity.json has no resnet110 entry (tests/golden/gen_gen_parity.py resnet110)"
+    wfile = _weights_of("resnet110", MODEL110)
     return {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(MODEL110["enc_seed"])}
 
 
@@ -278,8 +281,7 @@ def test_resnet110_sharded_over_two_processes_matches_the_reference_cpu_run(tmp_
     from test_gpu_batch_shard import _mock_rccl, _run_ranks
 
     exe = os.path.join(EX_DIR, "model_resnet110_cifar10_train")
-    if not os.path.exists(exe):
-        pytest.skip("workloads/_gen/examples not built")
+    assert os.path.exists(exe), "workloads/_gen/examples/model_resnet110_cifar10_train is missing (make -C workloads)"
     env = dict(_model110_env(), ACEHIP_RCCL_LIB=_mock_rccl(tmp_path))
     assert str(FIX["seed"]) == "20261004"  # (_run_ranks seeds the ranks with it)
     for r, (out, dumps) in enumerate(_run_ranks(exe, ["1"], 2, env, tmp_path, "r110mp2", timeout=1500)):
@@ -293,7 +295,7 @@ def test_resnet110_sharded_over_two_processes_matches_the_reference_cpu_run(tmp_
 # The other generated programs of the reference's dataset directory (rtlib/ant/dataset/resnet{32,44,56}_cifar10_pre.onnx.inc,
 # resnet32_cifar100_pre.onnx.inc, unchanged): one image each against the reference rtlib's CPU run with the injected key set
 # (0.9 / 1.3 / 1.6 h of one core each in the dev container; sigma per depth so that the logits keep real digits,
-# profiles/r04ae_sigma_sweep_more_models.txt).  A model without a fixture entry yet is skipped.
+# profiles/r04ae_sigma_sweep_more_models.txt).  A model without a fixture entry fails.
 # ------------------------------------------------------------------------------------------------------------------------------
 OTHER_MODELS = ["resnet32", "resnet32c100", "resnet44", "resnet56"]
 
@@ -303,12 +305,9 @@ def test_other_dataset_model_is_byte_identical_to_the_reference_cpu_run(key, tmp
     import model_weights
 
     m = FIX.get("models", {}).get(key)
-    if m is None:
-        pytest.skip("tests/golden/gen_parity.json has no %s entry (tests/golden/gen_gen_parity.py %s)" % (key, key))
+    assert m is not None, "tests/golden/gen_parity.json has no %s entry (tests/golden/gen_gen_parity.py %s)" % (key, key)
     exe = os.path.join(EX_DIR, "model_" + model_weights.PROGRAM[key])
-    wfile, meta = model_weights.ensure(key, m["weights"]["sigma"])
-    if meta["md5"] != m["weights"]["md5"]:
-        pytest.skip("this numpy writes a different synthetic weight file than the one the reference run used")
+    wfile = _weights_of(key, m)
     env = {"ACEHIP_RT_DATA_FILE": wfile, "MODEL_DATA_FILE": wfile, "MODEL_ENC_SEED": str(m["enc_seed"])}
     out, got = _run(exe, ["1"], env, tmp_path, key, timeout=1500)
     assert got == m["outputs"], "%s output ciphertext differs from the reference rtlib's CPU run" % key
@@ -325,8 +324,7 @@ EXTRAS = FIX.get("api_extras", {})
 
 @pytest.mark.parametrize("name", sorted(EXTRAS) or ["(no fixture)"])
 def test_api_extras_match_the_reference(name, tmp_path):
-    if not EXTRAS:
-        pytest.skip("tests/golden/gen_parity.json has no api_extras entry (tests/golden/gen_gen_parity.py extras)")
+    assert EXTRAS, "tests/golden/gen_parity.json has no api_extras entry (tests/golden/gen_gen_parity.py extras)"
     import ace_compiler_amd  # noqa: F401
 
     bmod = sys.modules["ace_compiler_amd.build"]

@@ -196,7 +196,7 @@ def test_generated_keys_and_encryption_have_the_reference_structure(name, made):
 @pytest.mark.parametrize("name", ["n64_ternary", "n4096_hw192"])
 def test_reference_accepts_our_keys_and_ciphertexts(name, made):
     if not os.path.exists(REF_EXE):
-        pytest.skip("oracle/_ref/ct_parity_ref not built (needs /root/reference: make -C oracle ref)")
+        pytest.fail("oracle/_ref/ct_parity_ref not built (needs /root/reference: make -C oracle ref) -- a build output of the dev container that must travel with the snapshot")
     r = subprocess.run([REF_EXE, "load", made[name]] + CONFIGS[name].split(), capture_output=True, text=True, timeout=1800)
     tail = r.stdout[-6000:] + r.stderr[-2000:]
     assert r.returncode == 0, tail

@@ -9,5 +9,5 @@
 export ACEHIP_BENCH_NO_VERIFY=1
 cp gpurun_exp/libacehip_ablate.so ace-compiler_amd/lib/libacehip.so
 for m in 0 1 2 4 8 16 32 64 128 255; do
-  echo "ABLATE $m: $(ACEHIP_ABLATE=$m timeout 300 python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"
+  echo "ABLATE $m: $(ACEHIP_ABLATE=$m timeout 300 python bench.py --no-verify --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"
 done

@@ -1,6 +1,9 @@
 """The synthetic weight files of the generated ResNets: one place that says which file a test, the bench and the reference
-run use (tools/make_weight_file.py: numpy default_rng(seed) * sigma, regenerated bit-identically wherever the same numpy runs,
-so the file itself never travels or gets committed -- its md5 does, tests/golden/gen_parity.json).
+run use.  The file itself never travels or gets committed (0.2-1.1 GB each) -- its md5 does (tests/golden/gen_parity.json) and it is
+regenerated where it is needed by tools/make_weight_file.py.  Generator per model (GEN below; the fixture records which one the
+reference run used): "ih12" = integer-only (SplitMix64 lanes summed to an Irwin-Hall variate; the same bytes under every numpy,
+libm and CPU), "numpy" = default_rng(seed).standard_normal (rounds 1-4: the same bytes only where numpy's stream is the same; a model
+moves to "ih12" when its reference run -- 0.6-2.6 h of one core and 44 GB -- has been repeated on the new file).
 
 sigma: N(0, 0.05) (rounds 1-3) makes activations shrink layer by layer and the logits end up at 1e-3.  SIGMA below was picked
 on the GPU (profiles/r04a_sigma_sweep.txt) as the largest value that keeps every bootstrap input of the 20-layer network inside
@@ -21,11 +24,14 @@ PROGRAM = {"resnet20": "resnet20_cifar10_pre", "resnet32": "resnet32_cifar10_pre
 #  ResNet-110 leaves the range at every sigma tried, profiles/r04f_sigma_sweep_resnet110.txt)
 SIGMA = {"resnet20": 0.2, "resnet32": 0.2, "resnet32c100": 0.2, "resnet44": 0.15, "resnet56": 0.12, "resnet110": 0.01}
 SEED = 2
+GEN = {"resnet20": "numpy", "resnet32": "numpy", "resnet32c100": "numpy", "resnet44": "numpy", "resnet56": "numpy", "resnet110": "numpy"}
 
 
-def path_of(key, sigma=None):
+def path_of(key, sigma=None, gen=None):
     sigma = SIGMA[key] if sigma is None else sigma
-    return os.path.join(ROOT, "workloads", "_gen", "weights", "%s_seed%d_sigma%g.msg" % (key, SEED, sigma))
+    gen = GEN[key] if gen is None else gen
+    tag = "" if gen == "numpy" else "_" + gen
+    return os.path.join(ROOT, "workloads", "_gen", "weights", "%s_seed%d_sigma%g%s.msg" % (key, SEED, sigma, tag))
 
 
 def md5(path):
@@ -36,20 +42,22 @@ def md5(path):
     return h.hexdigest()
 
 
-def ensure(key, sigma=None):
-    """-> (path, {"sigma", "seed", "md5"}); writes the file when it is not there yet"""
+def ensure(key, sigma=None, gen=None):
+    """-> (path, {"sigma", "seed", "md5", "gen"}); writes the file when it is not there yet"""
     sigma = SIGMA[key] if sigma is None else sigma
-    p = path_of(key, sigma)
+    gen = GEN[key] if gen is None else gen
+    p = path_of(key, sigma, gen)
     if not os.path.exists(p):
         os.makedirs(os.path.dirname(p), exist_ok=True)
         tmp = p + ".tmp.%d" % os.getpid()
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_weight_file.py"), "--entries",
-                               os.path.join(ROOT, "tests", "golden", ENTRIES[key]), "--out", tmp, "--seed", str(SEED), "--sigma", repr(sigma)],
+                               os.path.join(ROOT, "tests", "golden", ENTRIES[key]), "--out", tmp, "--seed", str(SEED), "--sigma", repr(sigma),
+                               "--gen", gen],
                               stdout=subprocess.DEVNULL)
         os.replace(tmp, p)
-    return p, {"sigma": sigma, "seed": SEED, "md5": md5(p)}
+    return p, {"sigma": sigma, "seed": SEED, "md5": md5(p), "gen": gen}
 
 
 if __name__ == "__main__":
     k = sys.argv[1] if len(sys.argv) > 1 else "resnet20"
-    print(ensure(k, float(sys.argv[2]) if len(sys.argv) > 2 else None))
+    print(ensure(k, float(sys.argv[2]) if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else None))
