@@ -83,6 +83,7 @@ SYMBOLS = [
     ("acehip_encode_batch", C.c_int, [_vp, _vp, _vp, _u32, C.c_int, C.c_size_t, _u32, C.c_double, _u32, _u32, _vp]),
     ("acehip_encode_status", C.c_int, [_vp]),
     ("acehip_sample_uniform", C.c_int, [_vp, _vp, _u32, _u32, _u32, _u64, _vp]),
+    ("acehip_sample_uniform_keyed", C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     ("acehip_mul_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_add_scalars", C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     ("acehip_modup_digits", C.c_int, [_vp, _vp, _vp, _u32, _vp]),

@@ -139,7 +139,7 @@ acehip_ctx* acehip_ctx_create(uint32_t N, uint32_t L, uint32_t q0_bits, uint32_t
   if (hp.logN == 16) {  // FP64 butterflies for the 48..50-bit scaling primes (ntt_fp.hpp); ACEHIP_NTT_FP=0: integer classes only
     const char* e = getenv("ACEHIP_NTT_FP");
     bool any = false;
-    for (u32 i = 0; i < T; ++i) any = any || hp.primes[i].q < 1266637395197952ull;  // kFpPrimeMax
+    for (u32 i = 0; i < T; ++i) any = any || hp.primes[i].q < ((1ull << 50) + (1ull << 43));  // kFpPrimeMax (ntt_fp.hpp)
     if ((!e || atoi(e) != 0) && any) {
       std::vector<double> twd((size_t)T * hp.N);
       for (size_t i = 0; i < twd.size(); ++i) twd[i] = (double)hp.rou[i];  // (exact wherever the class is used: w < q < 2^53)

@@ -697,6 +697,63 @@ void hw_run_rotate(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t
 }
 }  // namespace
 
+// ---- stage order: elementwise ops and gathers of one list sorted into as few alternating runs as their dependencies allow ----
+// A list runs as alternating elementwise / rotation runs (below).  In program order every Hw_rotate cuts the elementwise run it
+// sits in, and with it every accumulation chain that continues behind it -- although the chain usually has nothing to do with that
+// gather (the queue of the rt_ant shim now stays open across the direct launches of a key-switch, csrc/rt/rt_poly.cpp "keeping ops
+// queued", so one list holds the tails of several rotations: add d0 + c0, gather, multiply by a plaintext, accumulate).  Every op
+// gets a stage: elementwise ops even, gathers odd, at least the stage of every earlier op it depends on through memory (read after
+// write, write after write, write after read), rounded up to its own parity.  Ops are then issued stage by stage, program order kept
+// inside a stage: two ops that conflict are never swapped (equal stages keep their order inside one run, whose analysis -- hw_run_ew,
+// hw_run_rotate -- sees them in program order), everything else is independent.  Lists with partially overlapping limbs are left alone.
+static bool hw_stage_order(acehip_ctx* c, const acehip_hw_op* ops, size_t n, std::vector<acehip_hw_op>& out) {
+  static thread_local HwScratch hs;
+  static thread_local std::vector<int> last_w, max_r, stage;
+  static thread_local std::vector<u32> count;
+  const u64 span = (u64)c->hp.N * 8;
+  size_t cap = 64;
+  while (cap < 6 * n) cap <<= 1;
+  if (hs.table.size() < cap) hs.table.resize(cap);
+  std::memset(hs.table.data(), 0, cap * sizeof(HwScratch::Slot));
+  const u64 mask = cap - 1;
+  hs.parent.clear();
+  hs.node_ptr.clear();
+  last_w.clear();
+  max_r.clear();
+  stage.resize(n);
+  int top = 0;
+  bool in_order = true;
+  for (size_t k = 0; k < n; ++k) {
+    const acehip_hw_op& o = ops[k];
+    const bool rot = o.op == ACEHIP_HW_ROTATE;
+    const u32 nr = hw_node(hs, (u64)o.res, span, mask);
+    const u32 na = hw_has_a(o.op) ? hw_node(hs, (u64)o.a, span, mask) : UINT32_MAX - 1;
+    const u32 nb = hw_has_b(o.op) ? hw_node(hs, (u64)o.b, span, mask) : UINT32_MAX - 1;
+    if (nr == UINT32_MAX || na == UINT32_MAX || nb == UINT32_MAX) return false;
+    last_w.resize(hs.parent.size(), -1);
+    max_r.resize(hs.parent.size(), -1);
+    int s = rot ? 1 : 0;
+    if (na < UINT32_MAX - 1) s = std::max(s, last_w[na]);
+    if (nb < UINT32_MAX - 1) s = std::max(s, last_w[nb]);
+    s = std::max(s, std::max(last_w[nr], max_r[nr]));
+    if ((s & 1) != (rot ? 1 : 0)) ++s;
+    stage[k] = s;
+    if (na < UINT32_MAX - 1) max_r[na] = std::max(max_r[na], s);
+    if (nb < UINT32_MAX - 1) max_r[nb] = std::max(max_r[nb], s);
+    last_w[nr] = s;
+    max_r[nr] = o.op == ACEHIP_HW_MULADD ? s : -1;  // (a multiply-add reads the limb it rewrites)
+    if (k && s < stage[k - 1]) in_order = false;
+    top = std::max(top, s);
+  }
+  if (in_order) return false;  // program order is stage order already
+  count.assign((size_t)top + 2, 0);
+  for (size_t k = 0; k < n; ++k) count[(size_t)stage[k] + 1]++;
+  for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
+  out.resize(n);
+  for (size_t k = 0; k < n; ++k) out[count[(size_t)stage[k]]++] = ops[k];
+  return true;
+}
+
 static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hipStream_t st, const acehip_hw_range* dead, size_t n_dead);
 // Limb-sharded execution: every rank gets the list (SPMD) and runs the ops on the limbs it owns -- prime_gi names the limb
 // of every op (ACEHIP_HW_ANY_RANK: an op on memory that is not a limb of the chain, run by everyone).
@@ -743,6 +800,10 @@ static int hw_batch_run_one(acehip_ctx* c, const acehip_hw_op* ops, size_t n, hi
     if (o.op == ACEHIP_HW_ROTATE && limbs_overlap(o.res, o.a, span))
       return fail(ACEHIP_EINVAL, "acehip_hw_batch: in-place rotation is not supported");
   }
+  // fewer, longer runs where the dependencies allow it (ACEHIP_HW_STAGES=0: program order, as before round 5)
+  static const bool stages_on = [] { const char* e = getenv("ACEHIP_HW_STAGES"); return !e || atoi(e) != 0; }();
+  static thread_local std::vector<acehip_hw_op> staged;
+  if (stages_on && n_rot && n_rot < n && hw_stage_order(c, ops, n, staged)) ops = staged.data();
   // the list runs as alternating rotation / elementwise runs.  Memory the caller gave up is dead for a run only where no
   // later run reads it: walking the runs backwards, keep[0, run.n_keep) = the given-up limbs that runs after it read
   static thread_local std::vector<std::pair<u64, u64>> ranges;

@@ -154,6 +154,9 @@ DcList launch_dcs(const acehip_ctx* c);
 // launch writes is still in the 256 MiB Infinity Cache when the next launch of the pipeline reads it -- the hand-off between the
 // two passes of a transform, the coefficient-domain limbs between an inverse transform, a conversion and the forward transform.
 // Replicas are independent, so the results are the same bits in any grouping.  0 / unset: one group (off); never when limb-sharded.
+// The narrowing is written into the context (sel0 / seln / stat_reps) for the duration of the loop: like acehip_ctx_select itself it
+// assumes ONE host thread per acehip_ctx, which is how every caller uses a context (the rt_ant shim gives each thread its own;
+// include/acehip.h "Threads").  An error of a group ends the loop and is returned.
 u32 replica_chunk();
 template <class F>
 int for_replica_chunks(acehip_ctx* c, F&& body) {

@@ -72,19 +72,21 @@ extern "C" {
 
 int acehip_ntt_forward(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  (void)for_replica_chunks(c, [&] {
-    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, false, (hipStream_t)s);
-    return 0;
-  });
+  if (int e = for_replica_chunks(c, [&] {
+        for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, false, (hipStream_t)s);
+        return 0;
+      }))
+    return e;
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
 int acehip_ntt_inverse(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
-  (void)for_replica_chunks(c, [&] {
-    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, true, (hipStream_t)s);
-    return 0;
-  });
+  if (int e = for_replica_chunks(c, [&] {
+        for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, true, (hipStream_t)s);
+        return 0;
+      }))
+    return e;
   stat(ST_NTT, n, 16ull * c->hp.N * n);
   return post_launch();
 }
@@ -94,10 +96,11 @@ int acehip_ntt_batch(acehip_ctx* c, uint64_t* d, size_t poly_stride, uint32_t n_
   if (int e = check_range(c, level, pos0, n)) return e;
   if (n_polys == 0) return ACEHIP_OK;
   if (n_polys > 65535) return fail(ACEHIP_EINVAL, "acehip_ntt_batch: at most 65535 polynomials per launch");
-  (void)for_replica_chunks(c, [&] {
-    for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
-    return 0;
-  });
+  if (int e = for_replica_chunks(c, [&] {
+        for (const DevCtx& dc : launch_dcs(c)) launch_ntt(dc, d, level, pos0, n, inverse != 0, (hipStream_t)s, 0, n_polys, poly_stride);
+        return 0;
+      }))
+    return e;
   stat(ST_NTT, (u64)n * n_polys, 16ull * c->hp.N * n * n_polys);
   return post_launch();
 }
@@ -210,7 +213,12 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
         launch_ntt_fused(dc, pc + z * PK, 0, 0, hp.K, true, s, 0, 1, PK, 0, fi);
       }
       const std::vector<XItem> x = p_limbs_of(z);
-      if (int e = shard_exchange_begin(c, x.data(), x.size(), s)) return e;
+      if (int e = shard_exchange_begin(c, x.data(), x.size(), s)) {
+        // broadcasts of z = 0 may already be queued on the exchange stream and write into the workspace: order s behind them
+        // before anything else reuses it (the error is what the caller sees; the hand-back must still happen)
+        (void)shard_exchange_end(c, s);
+        return e;
+      }
     }
     if (int e = shard_exchange_end(c, s)) return e;
   } else {
@@ -748,6 +756,15 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
 int acehip_values_to_rns(acehip_ctx* c, uint64_t* d, const int64_t* vals, uint32_t level, uint32_t pos0, uint32_t n, acehip_stream s) {
   if (int e = check_range(c, level, pos0, n)) return e;
   for (const DevCtx& dc : launch_dcs(c)) launch_values_to_rns(dc, d, vals, level, pos0, n, (hipStream_t)s);
+  return post_launch();
+}
+int acehip_sample_uniform_keyed(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, const uint32_t* h_key, acehip_stream s) {
+  if (int e = check_range(c, level, pos0, n)) return e;
+  if (!h_key || !d) return fail(ACEHIP_EINVAL, "acehip_sample_uniform_keyed: null argument");
+  if (c->hp.N % 4 != 0) return fail(ACEHIP_EINVAL, "acehip_sample_uniform_keyed: N must be a multiple of 4");
+  ChaChaKey k;
+  std::memcpy(k.w, h_key, sizeof k.w);
+  for (const DevCtx& dc : launch_dcs(c)) launch_sample_uniform_keyed(dc, d, level, pos0, n, k, (hipStream_t)s);
   return post_launch();
 }
 int acehip_sample_uniform(acehip_ctx* c, uint64_t* d, uint32_t level, uint32_t pos0, uint32_t n, uint64_t seed, acehip_stream s) {

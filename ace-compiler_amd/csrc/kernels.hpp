@@ -293,6 +293,10 @@ void launch_center(const DevCtx& c, int64_t* out, const u64* in, u32 gi, hipStre
 void launch_values_to_rns(const DevCtx& c, u64* out, const int64_t* vals, u32 level, u32 pos0, u32 n_limbs, hipStream_t s);
 // uniform residues from a counter-based generator (Sample_uniform_poly polynomial.c:1349-1371)
 void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, u64 seed, hipStream_t s);
+struct ChaChaKey {
+  u32 w[8];
+};
+void launch_sample_uniform_keyed(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, const ChaChaKey& key, hipStream_t s);
 struct LimbConsts {
   u64 w[64];
 };

@@ -504,12 +504,67 @@ __global__ __launch_bounds__(256, ACEHIP_BSGS_MIN_WG) void bsgs_inner_kernel(Dev
   }
 }
 
+// The same inner products with ONE coefficient per lane: half the registers per lane (G = 16: 64 instead of 128 for the resident
+// inputs), twice the lanes.  The two-coefficient form of G = 16 needs 168 VGPRs at three waves per SIMD and spills 16 of them into
+// scratch inside the diagonal loop (ISA metadata of round 4: vgpr_spill_count 16, private_segment_fixed_size 20); this form has no
+// spills at ACEHIP_BSGS1_MIN_WG waves.  Which one runs for g > 8: ACEHIP_BSGS16_CPL (tools/kernel_ab.sh decides).
+#ifndef ACEHIP_BSGS1_MIN_WG
+#define ACEHIP_BSGS1_MIN_WG 4
+#endif
+#ifndef ACEHIP_BSGS16_CPL
+#define ACEHIP_BSGS16_CPL 2
+#endif
+template <int G>
+__global__ __launch_bounds__(256, ACEHIP_BSGS1_MIN_WG) void bsgs_inner1_kernel(DevCtx c, BsgsArgs a, u32 level) {
+  const RepBlk rb = rep_block(c, (c.N + 255) / 256, level + c.K);
+  const u32 pos = rb.y;
+  const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const u32 rep = rb.rep;
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, ml = P.prec128_lo, mh = P.prec128_hi;
+  const size_t ct_off = (size_t)pos * c.N;
+  const size_t pt_off = pos < level ? ct_off : (size_t)(a.pt_q_alloc + (pos - level)) * c.N;
+  const u32 i = rb.x * 256 + threadIdx.x;
+  if (i >= c.N) return;
+  u64 r0[G], r1[G];
+  const u32 sh = __builtin_clz(c.N) + 1;  // 32 - log2(N)
+  const u32 b0 = __brev(i) >> sh;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (j < (int)a.g) {
+      const u32 k = a.in_auto[j];
+      const u64 *in0 = reb(c, a.in0[j], rep), *in1 = reb(c, a.in1[j], rep);
+      const u32 px = k == 0 ? i : __brev((((2 * b0 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
+      r0[j] = in0[ct_off + px];
+      r1[j] = in1[ct_off + px];
+    }
+  }
+  for (u32 bi = 0; bi < a.b; ++bi) {
+    U128 s0{0, 0}, s1{0, 0};
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const u64* pt = j < (int)a.g ? reb(c, a.pt[bi * a.g + j], rep) : nullptr;
+      if (pt != nullptr) {
+        const u64 p = pt[pt_off + i];
+        mac128(s0, r0[j], p);
+        mac128(s1, r1[j], p);
+      }
+    }
+    reb(c, a.out0[bi], rep)[ct_off + i] = reduce128(s0, q, ml, mh);
+    reb(c, a.out1[bi], rep)[ct_off + i] = reduce128(s1, q, ml, mh);
+  }
+}
+
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
   ACEHIP_ABLATE(ABL_BSGS);
   dim3 grid(((c.N / 2 + 255) / 256) * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
   else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
-  else               hipLaunchKernelGGL((bsgs_inner_kernel<16>), grid, block, 0, s, c, a, level);
+  else if (ACEHIP_BSGS16_CPL == 1) {
+    dim3 grid1(((c.N + 255) / 256) * (level + c.K) * c.nrep);
+    hipLaunchKernelGGL((bsgs_inner1_kernel<16>), grid1, block, 0, s, c, a, level);
+  } else             hipLaunchKernelGGL((bsgs_inner_kernel<16>), grid, block, 0, s, c, a, level);
 }
 
 __global__ __launch_bounds__(256) void moddown_tail2_kernel(DevCtx c, u64* __restrict__ out0, u64* __restrict__ out1,

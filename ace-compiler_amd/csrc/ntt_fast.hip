@@ -808,7 +808,7 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
   fp_load_tw(TWD, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = fp_from_u64(lds[b * kBlkPitch + 17 * lo4 + i]);
+  for (int i = 0; i < 16; ++i) x[i] = fp_red(fp_from_u64(lds[b * kBlkPitch + 17 * lo4 + i]), k);  // canonical -> |v| <= 0.51q (ntt_fp.hpp)
   fp_radix16_inv_321(x, t1, t2, t3, k);
   fp_radix16_inv_0(x, t0, k);
   __syncthreads();

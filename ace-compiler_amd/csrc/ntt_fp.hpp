@@ -1,17 +1,23 @@
-// ntt_fp.hpp -- a second arithmetic for the butterflies of the register-tiled NTT passes (ntt_fast.hip): FP64 for primes below 2^50.17.
+// ntt_fp.hpp -- a second arithmetic for the butterflies of the register-tiled NTT passes (ntt_fast.hip): FP64 for primes below 2^50 + 2^43.
 //
 // The passes are bound by VALU issue as much as by memory: a forward butterfly of the SMALL integer class costs 15
 // instructions, 9 of them v_mad_u64_u32.  The 48..50-bit scaling primes (33 of the 34 q-limbs of the generated ResNets) also fit the
 // FP64 pipe, which issues at the same rate: residues are integers below 2^53, exactly representable, and
 //     h = x*w;  l = fma(x, w, -h);            x*w = h + l exactly (one rounding, recovered by the fma)
 //     f = rndne(h * (1/q));  r = fma(-f, q, h);  t = r + l      t = x*w - f*q: an integer congruent to x*w, every step exact
-// is a twiddle product in 6 instructions.  Range: with |x| <= B*q, |t| <= (0.5 + 0.375*B)*q (half a quotient unit from the rounding,
-// B/4 from the two roundings of h*(1/q), B/8 from l).  Forward (Cooley-Tukey): X' = X + t, Y' = X - t, no reduction for the FOUR stages
-// of a radix-16 round -- inputs below 0.51q grow to 1.2q, 2.15q, 3.46q, 5.26q < 2^53/q = 7.1 (q < 1.125 * 2^50) -- then
-// v - rndne(v/q)*q (3 instructions) brings every value back to |v| <= 0.51q: 8 + 48/32 = 9.5 instructions per butterfly.  Inverse
-// (Gentleman-Sande): sums double per stage, so the eight sums of the second stage are reduced as well: 1.02q, 2.04q -> 0.51q, 2.53q,
-// 5.06q.  Measured register-resident against the integer class (tools/ubench_bf_fp64.hip, profiles/r04b_*): 1.52x the butterflies per
-// second, bit-identical results.
+// is a twiddle product in 6 instructions.  Range, with rho = q / 2^50 <= 1.0079 (kFpPrimeMax) and |x| <= B*q: the computed quotient
+// h*(1/q) carries three roundings of a value of size B*q, i.e. an absolute error of 3 * 2^-53 * B * q = 0.375*rho*B, so
+// |t| <= (0.5 + 0.375*rho*B)*q; every intermediate must stay an integer below 2^53 = (8/rho)*q >= 7.93q.
+// Forward (Cooley-Tukey): X' = X + t, Y' = X - t, no reduction for the FOUR stages of a radix-16 round.  The FIRST round of a transform
+// starts from canonical residues in [0, q) (B = 1, not centred): 1.88q, 3.09q, 4.76q, 7.06q < 7.93q; every later round starts from
+// |v| <= 0.51q: 1.21q, 2.16q, 3.49q, 5.31q.  Then v - rndne(v/q)*q (3 instructions) brings every value back to |v| <= 0.51q:
+// 8 + 48/32 = 9.5 instructions per butterfly.  Inverse (Gentleman-Sande): sums double per stage, so the eight sums of the second stage
+// are reduced as well -- from |v| <= 0.51q: 1.02q, 2.04q -> 0.51q, 2.55q, 5.09q.  From uncentred residues the last sums could reach
+// 8.04q, so the first inverse round CENTRES its input (one fp_red per value on load: contig_inv_body_fp).
+// (Round 4 admitted primes up to 1.125 * 2^50 with a bound that assumed centred inputs everywhere: the shipped primes -- 2^50 +- 2^26 --
+// were safe, the admitted range was not; found in review, fixed by the cap and the centring above.)
+// Measured register-resident against the integer class (tools/ubench_bf_fp64.hip, profiles/r04b_*): 1.52x the butterflies per second,
+// bit-identical results.
 //
 // Between the two passes of a transform the intermediate lies in memory as FP64 bit patterns (|v| <= 0.51q); both passes decide the
 // class from the prime alone, so they always agree.  The first pass converts canonical residues on load (2 v_cvt_f64_u32 + 1 fma), the
@@ -21,7 +27,7 @@
 
 namespace acehip {
 
-constexpr u64 kFpPrimeMax = 1266637395197952ull;  // 1.125 * 2^50: 5.26q (forward) and 5.06q (inverse) stay below 2^53
+constexpr u64 kFpPrimeMax = (1ull << 50) + (1ull << 43);  // rho <= 1.0079: 7.06q (forward from [0,q)) and 5.09q (inverse) stay below 2^53
 
 struct FpK {
   double q, qinv;

@@ -10,6 +10,7 @@
 #include <cctype>
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/random.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -20,24 +21,56 @@ static RT_DATA_INFO* rt_data_info() { return Get_rt_data_info ? Get_rt_data_info
 
 namespace rt {
 
-// Randomness layout.  Every KEY draws from a generator of its own, derived from the context's key seed and the key's
-// identity (secret 1, public 2, relinearisation 3, automorphism key k: 2^34 + k) -- a key is the same whichever thread makes
-// it and in whatever order keys are asked for, so a fixed ACEHIP_SEED names one key set (tests/c/gen_parity_ref.c derives the
-// same set on the CPU and injects it into the reference).  ENCRYPTION draws from the calling thread's stream (Context::rng),
-// which Acehip_rt_seed_encryptor re-seeds.
+// Randomness layout (rt_rng.hpp).  Every KEY draws from a generator of its own, named by the key's identity (secret 1, public 2,
+// relinearisation 3, automorphism key k: 2^34 + k) -- a key is the same whichever thread makes it and in whatever order keys are
+// asked for.  ENCRYPTION draws from the calling thread's stream (Context::rng).  Normal operation: all of these are ChaCha20 streams
+// of ONE 256-bit master key from getrandom(2) (Context::master_key; the reference: BLAKE2Xb seeded from /dev/urandom, prng.c:33-69).
+// Test mode (ACEHIP_SEED): std::mt19937_64 generators derived from the 64-bit seed exactly as in rounds 1-4, so that a fixed seed
+// names one key set (tests/c/gen_parity_ref.c derives the same set on the CPU and injects it into the reference);
+// Acehip_rt_seed_encryptor puts a thread's encryption stream into test mode as well.
+void Rng::abort_unseeded() { RT_ASSERT(false, "random generator used before Prepare_context seeded it"); }
 static u64 splitmix(u64 z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-std::mt19937_64 key_rng(u64 tag) {
+Rng key_rng(u64 tag) {
   RT_ASSERT(g_primary != nullptr, "no prepared context");
-  return std::mt19937_64(splitmix(g_primary->key_seed ^ splitmix(tag)));
+  Rng r;
+  if (g_primary->drbg) r.key(g_primary->master_key, 'K', tag);
+  else r.seed(splitmix(g_primary->key_seed ^ splitmix(tag)));  // test mode
+  return r;
+}
+void sample_uniform_dev(u64* d, u32 level, u32 pos0, u32 n, Rng& rng) {
+  Context& c = ctx();
+  if (rng.test_mode()) {  // the 64-bit counter-based sampler the fixtures were made with
+    HIPCHK(acehip_sample_uniform(c.hip, d, level, pos0, n, rng(), nullptr));
+  } else {
+    uint32_t k[8];
+    rng.draw_key(k);
+    HIPCHK(acehip_sample_uniform_keyed(c.hip, d, level, pos0, n, k, nullptr));
+  }
+}
+// 256 bits from the operating system; no weaker fallback
+static void os_random(void* out, size_t bytes) {
+  unsigned char* p = (unsigned char*)out;
+  size_t got = 0;
+  while (got < bytes) {
+    const ssize_t r = getrandom(p + got, bytes - got, 0);
+    if (r < 0 && errno == EINTR) continue;
+    if (r <= 0) break;
+    got += (size_t)r;
+  }
+  if (got < bytes) {  // (a kernel without the system call: the device it is a front end of)
+    FILE* f = fopen("/dev/urandom", "rb");
+    RT_ASSERT(f != nullptr && fread(p + got, 1, bytes - got, f) == bytes - got, "no entropy source: getrandom() and /dev/urandom both failed");
+    fclose(f);
+  }
 }
 
 // Sample_triangle random_sample.c:78-97: -1 w.p. 1/4, +1 w.p. 1/4, 0 w.p. 1/2
-void sample_triangle(std::vector<int64_t>& v, std::mt19937_64& rng) {
+void sample_triangle(std::vector<int64_t>& v, Rng& rng) {
   for (auto& x : v) {
     const u64 r = rng() & 3;
     x = r == 0 ? -1 : (r == 1 ? 1 : 0);
@@ -45,7 +78,7 @@ void sample_triangle(std::vector<int64_t>& v, std::mt19937_64& rng) {
 }
 
 // Sample_ternary random_sample.c:99-150: exactly `hamming_weight` non-zeros, signs roughly balanced
-void sample_ternary(std::vector<int64_t>& v, size_t hw, std::mt19937_64& rng) {
+void sample_ternary(std::vector<int64_t>& v, size_t hw, Rng& rng) {
   const size_t n = v.size();
   if (hw == 0) {
     for (auto& x : v) x = (int64_t)(rng() % 3) - 1;
@@ -82,7 +115,7 @@ static u64 p_mod(u64 q) {  // P mod q
 // Generate_switching_key ckks_key_generator.c:127-200:  b_j = -a_j*old + e_j + P*new [digit j limbs]
 SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt, u64 tag) {
   Context& c = ctx();
-  std::mt19937_64 rng = key_rng(tag);
+  Rng rng = key_rng(tag);
   const u32 T = c.L + c.K;
   const size_t N = c.N, poly_words = (size_t)T * N;
   auto* sk = new SwitchKeyStore();
@@ -96,7 +129,7 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt, 
   for (u32 j = 0; j < c.dnum; ++j) {
     u64* b = sk->data + ((size_t)j * 2 + 0) * poly_words;
     u64* a = sk->data + ((size_t)j * 2 + 1) * poly_words;
-    HIPCHK(acehip_sample_uniform(c.hip, a, c.L, 0, T, rng(), nullptr));              // a_j (NTT domain)
+    sample_uniform_dev(a, c.L, 0, T, rng);                        // a_j (NTT domain)
     q_ew(ACEHIP_HW_MUL, b, a, old_key_ntt, c.L, 0, T);            // a_j * old
     for (u32 i = 0; i < T; ++i) scal[i] = (i < c.L && i / c.alpha == j) ? p_mod(c.primes[i]) : 0;
     q_scalars(ACEHIP_HW_MULC, pm, new_key_ntt, scal.data(), c.L, 0, T);  // P*new on digit j
@@ -172,35 +205,40 @@ u32 ensure_rot_key(int32_t rotation) {
 // ACEHIP_SHARD=1: the processes of a launcher (torchrun, mpirun: RANK / WORLD_SIZE / LOCAL_RANK in the environment) are the ranks
 // of ONE limb-sharded computation: each owns the limbs gi % WORLD_SIZE == RANK on its own GPU.  Rank 0 creates the RCCL id and
 // publishes it in a file only this job's ranks look for; a caller that has its own channel passes the id with
-// Acehip_rt_shard_connect instead.  All ranks must use the same ACEHIP_SEED (every key derives from it); without one it is taken
-// from the id.
+// Acehip_rt_shard_connect instead.  All ranks must derive the same keys: the same ACEHIP_SEED (test mode), or -- without one --
+// the master key rank 0 draws from the OS and puts into the record.
 //
 // The rendezvous file.  Name (unless ACEHIP_SHARD_ID_FILE names one): <dir>/acehip_rccl_<uid>_<job>.id with <dir> = $XDG_RUNTIME_DIR,
-// $TMPDIR or /tmp and <job> = the launcher's run id (TORCHELASTIC_RUN_ID) when there is one, MASTER_PORT and the launcher's pid
-// (the ranks of one launch are children of one process) -- two jobs on one node, or a retry on the same port, look for different
-// files.  Content: magic, a token derived from the same job identity, the 128-byte id; a reader accepts only a regular file of its
-// own user with the right token that is younger than five minutes.  Rank 0 creates it with O_CREAT | O_EXCL | O_NOFOLLOW, mode
+// $TMPDIR or /tmp and <job> = what the launcher gave every rank: its run id (TORCHELASTIC_RUN_ID) when there is one, MASTER_ADDR,
+// MASTER_PORT and WORLD_SIZE (the parent's pid only when the launcher set none of these: ranks started through per-rank wrapper
+// scripts have different parents) -- two jobs on one node look for different files, and a retry on the same port is told apart by
+// the record's time stamp.  Content: magic, a token derived from the same job identity, rank 0's clock, the 128-byte id, the 256-bit master key of the
+// job's randomness; a reader accepts only a regular file of its own user with the right token that is younger than five minutes and
+// was not written long before the reader itself started.  Rank 0 creates it with O_CREAT | O_EXCL | O_NOFOLLOW, mode
 // 0600, under a temporary name and renames it into place; it is removed once every rank has joined.  The join itself is bounded
 // (acehip_ctx_shard_rccl, ACEHIP_RCCL_INIT_TIMEOUT_S): a rank whose peers never arrive exits with an error instead of hanging.
-static void shard_connect(u32 rank, u32 world, const unsigned char* id) {
+static void shard_connect(u32 rank, u32 world, const unsigned char* id, const u32* master_key) {
   Context& c = ctx();
   const int rc = acehip_ctx_shard_rccl(c.hip, rank, world, id, 128);
   RT_ASSERT(rc >= 0, "acehip_ctx_shard_rccl: %s", acehip_last_error());
   c.shard_world = world;
   c.shard_rank = rank;
-  if (getenv("ACEHIP_SEED") == nullptr) {  // the same randomness on every rank
-    u64 seed = 0x9E3779B97F4A7C15ull;
-    for (int i = 0; i < 128; ++i) seed = (seed ^ id[i]) * 0x100000001B3ull;
-    c.key_seed = seed;
-    c.rng.seed(seed);
-    c.seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
+  if (getenv("ACEHIP_SEED") == nullptr) {  // the same randomness on every rank: rank 0's master key, out of the 0600 record
+    memcpy(c.master_key, master_key, sizeof c.master_key);
+    c.drbg = true;
+    c.rng.key(c.master_key, 'E', 0);
   }
 }
 static std::string shard_job_identity() {
+  // what the LAUNCHER gave every rank: its run id, its rendezvous address and port, the world size.  (The parent's pid is the
+  // same for all ranks only when no wrapper script sits between the launcher and the rank: it is used only when the launcher
+  // identified the job by nothing else.)
   std::string job;
   const char* run = getenv("TORCHELASTIC_RUN_ID");
+  const char *addr = getenv("MASTER_ADDR"), *port = getenv("MASTER_PORT"), *world = getenv("WORLD_SIZE");
   if (run && *run && strcmp(run, "none") != 0) job += std::string(run) + "_";
-  job += std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + std::to_string((long)getppid());
+  if (port && *port) job += std::string(addr && *addr ? addr : "localhost") + "_" + port + "_w" + (world ? world : "1");
+  else if (job.empty()) job = "ppid" + std::to_string((long)getppid());
   for (char& ch : job)
     if (!isalnum((unsigned char)ch) && ch != '_' && ch != '-') ch = '_';
   return job;
@@ -234,18 +272,24 @@ void shard_connect_if_asked() {
   struct Record {
     char magic[8];
     u64 token;
+    int64_t created_s;           // rank 0's clock when it wrote the record: readers refuse one that predates their own start
     unsigned char id[128];
+    u32 master_key[8];           // the randomness every rank derives its (identical) keys from; the file is 0600 and short-lived
   } rec;
+  memset(&rec, 0, sizeof rec);
   unsigned char id[128];
+  static const time_t process_start = time(nullptr);  // (first use: Prepare_context, seconds after the process began)
   if (rank == 0) {
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
     unlink(path.c_str());  // (left behind by a run that died between publishing and joining)
     unlink(tmp.c_str());
     const int n = acehip_rccl_unique_id(id, sizeof id);
     RT_ASSERT(n == 128, "acehip_rccl_unique_id: %s", acehip_last_error());
-    memcpy(rec.magic, "ACEHRCCL", 8);
+    memcpy(rec.magic, "ACEHRCC2", 8);
     rec.token = token;
+    rec.created_s = (int64_t)time(nullptr);
     memcpy(rec.id, id, 128);
+    os_random(rec.master_key, sizeof rec.master_key);
     const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
     RT_ASSERT(fd >= 0, "cannot create %s: %s", tmp.c_str(), strerror(errno));
     const bool ok = write(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && fsync(fd) == 0;
@@ -260,8 +304,10 @@ void shard_connect_if_asked() {
       const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
       if (fd >= 0) {  // (an older file, another user's, or another job's token: not this run's -- keep waiting for rank 0)
         struct stat st;
+        // (a record written more than two minutes before THIS process started belongs to an earlier launch that died before joining)
         if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && time(nullptr) - st.st_mtime < 300 &&
-            read(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && memcmp(rec.magic, "ACEHRCCL", 8) == 0 && rec.token == token) {
+            read(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && memcmp(rec.magic, "ACEHRCC2", 8) == 0 && rec.token == token &&
+            rec.created_s >= (int64_t)process_start - 120) {
           memcpy(id, rec.id, 128);
           got = true;
         }
@@ -274,7 +320,8 @@ void shard_connect_if_asked() {
     }
     RT_ASSERT(got, "rank %u: no RCCL id for this job in %s within %d s", rank, path.c_str(), limit_s);
   }
-  shard_connect(rank, world, id);
+  shard_connect(rank, world, id, rec.master_key);
+  memset(&rec, 0, sizeof rec);
   if (rank == 0) unlink(path.c_str());  // (every rank has joined: ncclCommInitRank returns only then)
 }
 
@@ -284,7 +331,7 @@ void generate_keys() {
   const size_t N = c.N;
   // secret key (Generate_secret_key :69-83)
   c.sk_coef.assign(N, 0);
-  std::mt19937_64 sk_rng = key_rng(KEY_TAG_SECRET), pk_rng = key_rng(KEY_TAG_PUBLIC);
+  Rng sk_rng = key_rng(KEY_TAG_SECRET), pk_rng = key_rng(KEY_TAG_PUBLIC);
   sample_ternary(c.sk_coef, c.hamming, sk_rng);
   POLYNOMIAL s{};
   poly_alloc(&s, c.N, c.L, c.K);
@@ -294,7 +341,7 @@ void generate_keys() {
   // public key (Generate_public_key :85-125): pk1 = a, pk0 = -a*s + e
   c.pk0 = dalloc((size_t)c.L * N, false);
   c.pk1 = dalloc((size_t)c.L * N, false);
-  HIPCHK(acehip_sample_uniform(c.hip, c.pk1, c.L, 0, c.L, pk_rng(), nullptr));
+  sample_uniform_dev(c.pk1, c.L, 0, c.L, pk_rng);
   POLYNOMIAL e{};
   poly_alloc(&e, c.N, c.L, 0);
   std::vector<int64_t> tri(N);
@@ -368,12 +415,10 @@ void Prepare_context() {
     c->key_seed = seed;
     c->rng.seed(seed);
     c->seed_rng.seed(seed ^ 0x9E3779B97F4A7C15ull);
-  } else {
-    std::random_device rd;
-    std::seed_seq s1{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()}, s2{rd(), rd(), rd(), rd(), rd(), rd(), rd(), rd()};
-    c->rng.seed(s1);
-    c->seed_rng.seed(s2);
-    c->key_seed = ((u64)rd() << 32) ^ rd() ^ ((u64)rd() << 17);
+  } else {  // normal operation: 256 bits from the OS key every stream (limb-sharded ranks get rank 0's: shard_connect)
+    os_random(c->master_key, sizeof c->master_key);
+    c->drbg = true;
+    c->rng.key(c->master_key, 'E', 0);
   }
   // canonical-embedding tables (Precompute_fft ntt.c:587-610), m = 2N
   const size_t m = 2ull * c->N;
@@ -505,6 +550,10 @@ void Acehip_rt_thread_release(void) { thread_release(); }
 void Acehip_rt_sync(void) { rt::sync(); }
 void Acehip_rt_next_input(void) { pt_image_boundary(); }
 void Acehip_rt_seed_encryptor(uint64_t seed) { ctx().rng.seed(seed); }
+// test hook: the block function every stream of rt_rng.hpp is made of (RFC 8439 2.3.2 has the known answer)
+void acehip_rt_debug_chacha20_block(const uint32_t* key, uint32_t counter, const uint32_t* nonce, uint32_t* out) {
+  rt::ChaCha20::block(key, counter, nonce, out);
+}
 
 // Extension: image batches.  B images run through every launch of this thread (Run_main_graph is called ONCE per batch): the
 // GPU form of the reference's image-parallel loop (rtlib/ant/dataset/resnet_cifar.main.inc:77-116), where the threads share

@@ -23,6 +23,7 @@
 #include "common/rt_stat.h"
 #include "rt_ant/ant_api.h"
 #include "rt_ant/rt_api.h"
+#include "rt_rng.hpp"
 
 #define RT_ASSERT(cond, ...)                              \
   do {                                                    \
@@ -112,9 +113,15 @@ struct Context {
   std::map<u32, SwitchKeyStore*> auto_keys;   // automorphism index -> key
   std::map<int32_t, u32> rot2auto;            // rotation -> automorphism index
   std::vector<int64_t> sk_coef;               // ternary secret, host copy (signed)
-  std::mt19937_64 rng;                        // this thread's encryption randomness (Acehip_rt_seed_encryptor re-seeds it)
-  u64 key_seed = 0;                           // primary context: every key's generator derives from it (rt_context.cpp key_rng)
-  std::mt19937_64 seed_rng;                   // primary context only: seeds of attaching threads, used under shared_mu
+  // Randomness (rt_rng.hpp).  drbg: every stream is ChaCha20 under master_key (256 bits from getrandom) -- one per key identity
+  // (key_rng) and one per encrypting thread (rng; enc_streams counts them, primary context, under shared_mu).  Otherwise the TEST
+  // mode of ACEHIP_SEED: key_seed / seed_rng as in rounds 1-4, bit for bit (the committed fixtures depend on it).
+  Rng rng;                                    // this thread's encryption randomness (Acehip_rt_seed_encryptor re-seeds it: test mode)
+  bool drbg = false;
+  u32 master_key[8] = {};
+  u64 enc_streams = 0;
+  u64 key_seed = 0;                           // test mode, primary context: every key's generator derives from it (rt_context.cpp key_rng)
+  Rng seed_rng;                               // test mode, primary context: seeds of attaching threads, used under shared_mu
   // FFT tables for the canonical embedding of decode (ntt.c:587-610): m = 2N
   std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
   std::vector<u32> rot_group;     // 5^i mod 2N
@@ -247,10 +254,12 @@ void copy_limbs(u64* dst, const u64* src, size_t words, u32 nq = NQ_ANY, u32 fir
 double wall_s();
 
 // ---- sampling (random_sample.c) ----
-void sample_triangle(std::vector<int64_t>& v, std::mt19937_64& rng);                         // :78-97
-void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight, std::mt19937_64& rng);   // :99-150
+void sample_triangle(std::vector<int64_t>& v, Rng& rng);                         // :78-97
+void sample_ternary(std::vector<int64_t>& v, size_t hamming_weight, Rng& rng);   // :99-150
 constexpr u64 KEY_TAG_SECRET = 1, KEY_TAG_PUBLIC = 2, KEY_TAG_RELIN = 3, KEY_TAG_AUTO = 1ull << 34;
-std::mt19937_64 key_rng(u64 tag);  // the generator of one key: a function of the context's key seed and the key's identity
+Rng key_rng(u64 tag);  // the generator of one key: a function of the context's master key (test mode: key seed) and the key's identity
+// limbs [pos0, pos0 + n) of a polynomial extended at `level`, uniform in [0, q): the public `a` of a key, drawn on the device
+void sample_uniform_dev(u64* d, u32 level, u32 pos0, u32 n, Rng& rng);
 
 // ---- keys (ckks_key_generator.c) ----
 void generate_keys();

@@ -37,7 +37,9 @@ static void attach_thread() {
   c->hip = acehip_ctx_create(p->prm->_poly_degree, (uint32_t)p->prm->_mul_depth + 1, (uint32_t)p->prm->_first_mod_size,
                              (uint32_t)p->prm->_scaling_mod_size, (uint32_t)p->prm->_num_q_parts, dev);
   RT_ASSERT(c->hip != nullptr, "acehip_ctx_create failed: %s", acehip_last_error());
-  c->rng.seed(p->seed_rng() ^ (u64)(uintptr_t)c);  // encryption noise of this thread (seed_rng: never touched outside shared_mu)
+  // encryption noise of this thread: its own ChaCha20 stream of the master key (test mode: a seed from seed_rng; both under shared_mu)
+  if (p->drbg) c->rng.key(p->master_key, 'E', ++p->enc_streams);
+  else c->rng.seed(p->seed_rng() ^ (u64)(uintptr_t)c);
   c->weight_plain_cnt = c->weight_plain_bytes = 0;
   c->t_encode = c->t_main = c->t_issue = c->t_bootstrap = 0;
   c->n_bootstrap = 0;
@@ -305,11 +307,16 @@ thread_local HwqStats g_hwq_stats;
 // ACEHIP_PROFILE: limbs a handed-over queue stored that a LATER queue loads again although no direct launch in between
 // named them (what keeping such ops queued across declared launches can save at most)
 struct ReloadStats {
-  std::map<const u64*, size_t> stored;  // limb -> index of the hand-over that wrote it
+  std::map<const u64*, std::pair<size_t, u32>> stored;  // limb -> (index of the hand-over that wrote it, kind of the op that did)
   size_t loads = 0, reloads = 0, reload_dist[6] = {};  // distance in hand-overs: 1, 2, <=4, <=8, <=16, more
+  size_t pair[3][9][9] = {};  // [distance <= 2, <= 16, more][producer kind][consumer kind]
   size_t erased_by_touch = 0, cleared = 0;
 };
 thread_local ReloadStats g_reload;
+bool reload_diag_on() {  // ACEHIP_PROFILE_RELOADS=1 with ACEHIP_PROFILE=1 (a std::map per limb: slow)
+  static const bool on = getenv("ACEHIP_PROFILE_RELOADS") != nullptr;
+  return on && ctx().profile;
+}
 // ---- lazy zero fills ----
 // Generated code zero-fills a result (Init_ciph_*, Alloc_poly) long before the first per-limb op accumulates into it:
 // a rotation with its key-switch lies in between, whose direct launches hand the queue over.  Issued there, the fill is
@@ -323,6 +330,11 @@ struct LazyStats {
   size_t deferred = 0, met_consumer = 0, materialised = 0, dropped = 0;
 };
 thread_local LazyStats g_lazy_stats;
+struct KeepStats {
+  size_t launches = 0, kept_some = 0, ops_kept = 0, ops_submitted = 0, forced_full = 0, limbo_pinned = 0;
+  double t_split = 0, t_limbo = 0, t_submit = 0;  // host seconds (ACEHIP_PROFILE)
+};
+thread_local KeepStats g_keep_stats;
 }
 static void muc_stats_print();
 void hw_stats_print() {
@@ -333,13 +345,26 @@ void hw_stats_print() {
          s.by_kind[7], s.by_kind[8], s.hist[0], s.hist[1], s.hist[2], s.hist[3], s.hist[4], s.hist[5], s.hist[6], s.hist[7]);
   printf("[ACEHIP] hw queue: %zu distinct result limbs, %zu of them in blocks freed before the flush\n", s.res_limbs, s.res_limbs_freed);
   muc_stats_print();
-  {
+  if (reload_diag_on()) {
     const ReloadStats& r = g_reload;
     printf("[ACEHIP] hw queue: %zu limb loads named by queued ops; %zu of them re-load a limb an EARLIER hand-over stored with no direct launch naming it in between "
            "(hand-overs apart 1:%zu 2:%zu <=4:%zu <=8:%zu <=16:%zu more:%zu); %zu stored limbs consumed by declared launches, %zu map resets by undeclared ones\n",
            r.loads, r.reloads, r.reload_dist[0], r.reload_dist[1], r.reload_dist[2], r.reload_dist[3], r.reload_dist[4], r.reload_dist[5],
            r.erased_by_touch, r.cleared);
+    static const char* const kn[9] = {"add", "mul", "rot", "copy", "zero", "sub", "muladd", "mulc", "addc"};
+    static const char* const dn[3] = {"<=2", "<=16", ">16"};
+    for (int d = 0; d < 3; ++d)
+      for (int a = 0; a < 9; ++a)
+        for (int b = 0; b < 9; ++b)
+          if (r.pair[d][a][b] * 200 > r.reloads)
+            printf("[ACEHIP] reload %s hand-overs apart: stored by %s, loaded by %s: %zu\n", dn[d], kn[a], kn[b], r.pair[d][a][b]);
   }
+  printf("[ACEHIP] queue kept open: %zu declared launches met a non-empty queue, %zu of them left ops queued (%zu limb-ops kept, %zu handed over); "
+         "%zu took everything because of the size bounds; %zu freed blocks pinned by kept ops\n",
+         g_keep_stats.launches, g_keep_stats.kept_some, g_keep_stats.ops_kept, g_keep_stats.ops_submitted, g_keep_stats.forced_full,
+         g_keep_stats.limbo_pinned);
+  printf("[ACEHIP] queue kept open, host seconds: choosing what a launch needs %.3f, pinned freed blocks %.3f, handing lists to the library %.3f\n",
+         g_keep_stats.t_split, g_keep_stats.t_limbo, g_keep_stats.t_submit);
   const LazyStats& z = g_lazy_stats;
   printf("[ACEHIP] lazy zero fills: %zu limbs deferred; %zu met their first consumer in the queue, %zu issued for a launch, %zu dropped (block freed or rewritten)\n",
          z.deferred, z.met_consumer, z.materialised, z.dropped);
@@ -611,48 +636,137 @@ void lazy_meet_queue(const Touch* touch, size_t n_touch, bool defer) {
     g_hwq.resize(w);
   }
 }
-void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
-  static const bool lazy_on = getenv("ACEHIP_LAZY_ZERO") == nullptr || atoi(getenv("ACEHIP_LAZY_ZERO")) != 0;
-  // (limb-sharded execution: a deferred fill does not remember which rank owns its limb, so nothing is deferred there)
-  lazy_meet_queue(touch, n_touch, defer && lazy_on && ctx().shard_world <= 1);
-  if (ctx().profile) {
-    ReloadStats& rl = g_reload;
-    const size_t Nw = ctx().N;
-    if (!defer) {
-      rl.cleared += !rl.stored.empty();
-      rl.stored.clear();
-    } else {
-      for (size_t i = 0; i < n_touch; ++i) {
-        if (!touch[i].p || !touch[i].words) continue;
-        const u64* lo = (const u64*)touch[i].p;
-        for (auto it = rl.stored.lower_bound(lo - (Nw - 1)); it != rl.stored.end() && it->first < lo + touch[i].words;) {
-          it = rl.stored.erase(it);
-          rl.erased_by_touch++;
-        }
-      }
+// ---- keeping ops queued across declared launches (round 5) ----
+// A direct launch used to take the WHOLE queue with it (every queued op had to be on the device before the launch, whose operands
+// nobody knew).  With the operand list of HIPCHK_T the launch only needs the ops it depends on: walking the queue backwards,
+// an op is SUBMITTED when it conflicts with the launch or with an op already marked (it writes a limb they read or write, or
+// reads a limb they write: marked ops and the launch run BEFORE the ops that stay, so every such pair would be swapped); everything
+// else STAYS queued, in program order, and runs with a later hand-over -- after the launch, which by construction neither reads nor
+// writes anything those ops touch.  The tails of consecutive rotations (d0 + c0, gather, plaintext product, accumulation) then meet
+// in ONE list, where the library sorts them into few long runs (api_hw_batch.cpp hw_stage_order) and accumulators stay in registers.
+// Blocks the program freed while ops that name them are still queued stay in the pool's limbo (never reused, never given to the
+// library as dead) until the last such op has been handed over.  Safety net: ACEHIP_POISON=1 overwrites the result limbs of kept
+// pure overwrites with non-residues and compares what a launch touched with its declared list (check_declared).
+// ACEHIP_HW_KEEP=0 restores the old behaviour (everything is submitted).
+thread_local std::set<const u64*> g_keep_poisoned;  // result limbs of kept ops that hold poison right now (ACEHIP_POISON)
+constexpr size_t kKeepMaxOps = 6000;
+inline bool op_reads_res(u32 op) { return op == ACEHIP_HW_MULADD; }
+// g_hwq -> (g_hwq = the ops to submit now, kept = the ops that stay), both in program order
+void split_for_launch(const Touch* touch, size_t n_touch, std::vector<acehip_hw_op>& kept) {
+  const size_t N = ctx().N, n = g_hwq.size();
+  static thread_local PtrSet s_read, s_write;
+  static thread_local std::vector<char> sub;
+  sub.assign(n, 0);
+  size_t n_sub = 0;
+  // one interval around everything the launch names, one around everything the submitted ops name: most queued ops lie outside both
+  const u64 *t_lo = (const u64*)~(uintptr_t)0, *t_hi = nullptr, *s_lo = (const u64*)~(uintptr_t)0, *s_hi = nullptr;
+  for (size_t i = 0; i < n_touch; ++i)
+    if (touch[i].p && touch[i].words) {
+      t_lo = std::min(t_lo, (const u64*)touch[i].p);
+      t_hi = std::max(t_hi, (const u64*)touch[i].p + touch[i].words);
     }
+  auto hits_launch = [&](const u64* p) { return p + N > t_lo && p < t_hi && touches(touch, n_touch, p, N); };
+  auto near_s = [&](const u64* p) { return p >= s_lo && p < s_hi; };
+  for (size_t k = n; k-- > 0;) {
+    const acehip_hw_op& o = g_hwq[k];
+    const u64* a = o.op != ACEHIP_HW_ZERO ? o.a : nullptr;
+    const u64* b = op_has_b(o.op) ? (const u64*)o.b : nullptr;
+    // against the launch: every declared range counts as read AND written
+    bool hit = hits_launch(o.res) || (a && hits_launch(a)) || (b && hits_launch(b));
+    // against the ops behind it that are submitted
+    if (!hit && n_sub)
+      hit = (near_s(o.res) && (s_read.has(o.res) || s_write.has(o.res))) || (a && near_s(a) && s_write.has(a)) || (b && near_s(b) && s_write.has(b));
+    if (!hit) continue;
+    if (n_sub == 0) {
+      s_read.reset(3 * n);
+      s_write.reset(n);
+    }
+    sub[k] = 1;
+    ++n_sub;
+    s_write.insert(o.res);
+    if (a) s_read.insert(a);
+    if (b) s_read.insert(b);
+    if (op_reads_res(o.op)) s_read.insert(o.res);
+    for (const u64* p : {(const u64*)o.res, a, b})
+      if (p) {
+        s_lo = std::min(s_lo, p);
+        s_hi = std::max(s_hi, p + 1);
+      }
   }
-  if (ctx().profile && !g_hwq.empty()) {
+  if (n_sub == n) return;
+  kept.reserve(n - n_sub);
+  if (n_sub == 0) {
+    kept.swap(g_hwq);
+    return;
+  }
+  size_t w = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (sub[k]) g_hwq[w++] = g_hwq[k];
+    else kept.push_back(g_hwq[k]);
+  }
+  g_hwq.resize(w);
+}
+// limbo blocks that no op of `kept` names are released / may be declared dead; the others stay (returns how many stay)
+size_t limbo_split(const std::vector<acehip_hw_op>& kept, std::vector<LimboBlock>& stay) {
+  stay.clear();
+  if (kept.empty() || pool_limbo.empty()) return 0;
+  // blocks sorted by address; every pointer the kept ops name marks the block it lies in
+  static thread_local std::vector<char> pinned;
+  std::sort(pool_limbo.begin(), pool_limbo.end(), [](const LimboBlock& x, const LimboBlock& y) { return x.first < y.first; });
+  pinned.assign(pool_limbo.size(), 0);
+  const u64 *lo = pool_limbo.front().first, *hi = pool_limbo.back().first + pool_limbo.back().second;
+  size_t n_pinned = 0;
+  auto mark = [&](const u64* p) {
+    if (p < lo || p >= hi) return;
+    size_t a = 0, b = pool_limbo.size();
+    while (a < b) {  // last block that starts at or below p
+      const size_t m = (a + b) / 2;
+      if (pool_limbo[m].first <= p) a = m + 1;
+      else b = m;
+    }
+    if (a > 0 && p < pool_limbo[a - 1].first + pool_limbo[a - 1].second && !pinned[a - 1]) {
+      pinned[a - 1] = 1;
+      ++n_pinned;
+    }
+  };
+  for (const acehip_hw_op& o : kept) {
+    mark(o.res);
+    if (o.op != ACEHIP_HW_ZERO) mark(o.a);
+    if (op_has_b(o.op)) mark((const u64*)o.b);
+    if (n_pinned == pool_limbo.size()) break;
+  }
+  size_t w = 0;
+  for (size_t i = 0; i < pool_limbo.size(); ++i) {
+    if (pinned[i]) stay.push_back(pool_limbo[i]);
+    else pool_limbo[w++] = pool_limbo[i];
+  }
+  pool_limbo.resize(w);
+  return stay.size();
+}
+// hands g_hwq (all of it) to the library
+void submit_all() {
+  if (reload_diag_on() && !g_hwq.empty()) {
     ReloadStats& rl = g_reload;
     const size_t idx = g_hwq_stats.flushes + 1;
     std::set<const u64*> seen;  // first reference inside this queue only
-    auto load = [&](const void* p) {
+    auto load = [&](const void* p, u32 by) {
       const u64* x = (const u64*)p;
       if (!x || !seen.insert(x).second) return;
       rl.loads++;
       auto it = rl.stored.find(x);
       if (it == rl.stored.end()) return;
       rl.reloads++;
-      const size_t d = idx - it->second;
+      const size_t d = idx - it->second.first;
       rl.reload_dist[d <= 1 ? 0 : d == 2 ? 1 : d <= 4 ? 2 : d <= 8 ? 3 : d <= 16 ? 4 : 5]++;
+      rl.pair[d <= 2 ? 0 : d <= 16 ? 1 : 2][it->second.second][by]++;
     };
     for (const auto& o : g_hwq) {
-      if (o.op != ACEHIP_HW_ZERO) load(o.a);
-      if (op_has_b(o.op)) load(o.b);
-      if (o.op == ACEHIP_HW_MULADD) load(o.res);
+      if (o.op != ACEHIP_HW_ZERO) load(o.a, o.op);
+      if (op_has_b(o.op)) load(o.b, o.op);
+      if (o.op == ACEHIP_HW_MULADD) load(o.res, o.op);
       seen.insert(o.res);
     }
-    for (const auto& o : g_hwq) rl.stored[o.res] = idx;
+    for (const auto& o : g_hwq) rl.stored[o.res] = {idx, o.op};
   }
   if (g_hwq.empty()) {
     limbo_release();
@@ -689,9 +803,94 @@ void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
   if (discard)
     for (const auto& b : pool_limbo) dead.push_back(acehip_hw_range{b.first, b.second});
   const int rc = acehip_hw_batch_discard(ctx().hip, g_hwq.data(), g_hwq.size(), dead.data(), dead.size(), nullptr);
+  if (!g_keep_poisoned.empty())
+    for (const auto& o : g_hwq) g_keep_poisoned.erase(o.res);
   g_hwq.clear();
   RT_ASSERT(rc >= 0, "acehip_hw_batch failed: %s", acehip_last_error());
   limbo_release();
+}
+// the hand-over in front of a direct launch: all of the queue, or -- when the launch declares its operands -- the part it needs
+void queue_submit(const Touch* touch, size_t n_touch, bool defer) {
+  static const bool lazy_on = getenv("ACEHIP_LAZY_ZERO") == nullptr || atoi(getenv("ACEHIP_LAZY_ZERO")) != 0;
+  static const bool keep_on = getenv("ACEHIP_HW_KEEP") == nullptr || atoi(getenv("ACEHIP_HW_KEEP")) != 0;
+  // (limb-sharded execution: a deferred fill does not remember which rank owns its limb, so nothing is deferred there)
+  // (with ops kept queued a zero fill that nothing needs yet simply stays in the queue like any other op -- with its owner, so also
+  // under limb-sharded execution; the separate set of deferred fills is what ACEHIP_HW_KEEP=0 falls back to)
+  lazy_meet_queue(touch, n_touch, defer && lazy_on && !keep_on && ctx().shard_world <= 1);
+  if (reload_diag_on()) {
+    ReloadStats& rl = g_reload;
+    const size_t Nw = ctx().N;
+    if (!defer) {
+      rl.cleared += !rl.stored.empty();
+      rl.stored.clear();
+    } else {
+      for (size_t i = 0; i < n_touch; ++i) {
+        if (!touch[i].p || !touch[i].words) continue;
+        const u64* lo = (const u64*)touch[i].p;
+        for (auto it = rl.stored.lower_bound(lo - (Nw - 1)); it != rl.stored.end() && it->first < lo + touch[i].words;) {
+          it = rl.stored.erase(it);
+          rl.erased_by_touch++;
+        }
+      }
+    }
+  }
+  static thread_local std::vector<acehip_hw_op> kept;
+  static thread_local std::vector<LimboBlock> stay;
+  kept.clear();
+  stay.clear();
+  if (defer && keep_on && !g_hwq.empty()) {
+    g_keep_stats.launches++;
+    // (a bound on what waits: the analysis is linear in the queue per launch, and pinned limbo blocks are arena memory)
+    size_t limbo_words = 0;
+    for (const auto& b : pool_limbo) limbo_words += b.second;
+    // ... and on how long: an op that has waited through keep_run launches is re-examined by none of the following ones
+    // (measured, profiles/r05h_*: per-limb kernel time of a 12-image batch 2.50 s without keeping, 2.35 / 2.30 / 2.27 s with runs of
+    //  8 / 16 / unbounded; host time per launch grows with the run -- unbounded costs a single-image stream 70 % more wall time, a run
+    //  of 8 costs it 2 % -- so single images use 8 and batches, whose launches are long enough to hide the host, 16)
+    static const u32 keep_run_env = [] { const char* e = getenv("ACEHIP_HW_KEEP_RUN"); return e && atoi(e) > 0 ? (u32)atoi(e) : 0u; }();
+    const u32 keep_run = keep_run_env ? keep_run_env : (batch_size() > 1 ? 16u : 8u);
+    static thread_local u32 run = 0;
+    if (g_hwq.size() > kKeepMaxOps || (g_arena.words && limbo_words > g_arena.words / 4) || ++run > keep_run) {
+      g_keep_stats.forced_full++;
+      run = 0;
+    } else {
+      const bool prof = ctx().profile;
+      const double t0 = prof ? wall_s() : 0;
+      split_for_launch(touch, n_touch, kept);
+      const double t1 = prof ? wall_s() : 0;
+      g_keep_stats.ops_kept += kept.size();
+      g_keep_stats.ops_submitted += g_hwq.size();
+      g_keep_stats.kept_some += !kept.empty();
+      g_keep_stats.limbo_pinned += limbo_split(kept, stay);
+      if (prof) {
+        g_keep_stats.t_split += t1 - t0;
+        g_keep_stats.t_limbo += wall_s() - t1;
+      }
+    }
+  }
+  {
+    const bool prof = ctx().profile;
+    const double t0 = prof ? wall_s() : 0;
+    submit_all();
+    if (prof) g_keep_stats.t_submit += wall_s() - t0;
+  }
+  if (!kept.empty()) {
+    g_hwq.swap(kept);
+    pool_limbo.insert(pool_limbo.end(), stay.begin(), stay.end());
+    if (poison_on()) {  // the first op that names a limb overwrites it without reading it: until then the limb holds garbage on purpose
+      static thread_local PtrSet seen;
+      seen.reset(3 * g_hwq.size());
+      const size_t N = ctx().N;
+      for (const acehip_hw_op& o : g_hwq) {
+        const u64* a = o.op != ACEHIP_HW_ZERO ? o.a : nullptr;
+        const u64* b = op_has_b(o.op) ? (const u64*)o.b : nullptr;
+        if (a) seen.insert(a);
+        if (b) seen.insert(b);
+        const bool reads_res = op_reads_res(o.op);
+        if (seen.insert(o.res) && !reads_res && g_keep_poisoned.insert(o.res).second) poison(o.res, N);
+      }
+    }
+  }
 }
 }  // namespace
 void hw_flush() {
@@ -774,7 +973,10 @@ void hw_queue(u32 op, u32 prime_gi, u64* res, const u64* a, const void* b, size_
   for (size_t l = 0; l < n_limbs; ++l)
     g_hwq.push_back(acehip_hw_op{op, prime_gi, res + l * N, a ? a + l * N : nullptr,
                                  b ? (const void*)((const u64*)b + l * N) : nullptr});
-  if (g_hwq.size() >= 8192) hw_flush_site(__FILE__, __LINE__);
+  if (g_hwq.size() >= 8192) {  // (nothing else follows: no operands to declare, the raised digits stay valid)
+    note_site(__FILE__, __LINE__);
+    queue_submit();
+  }
 }
 static inline u32 limb_gi(u32 pos, u32 level) { return pos < level ? pos : ctx().L + (pos - level); }
 void q_ew(u32 op, u64* r, const u64* a, const u64* b, u32 level, u32 pos0, u32 n) {
@@ -834,6 +1036,21 @@ u64* dalloc(size_t words, bool zero, u32 nq) {
         for (u64* q : kv.second) arena_give(q, kv.first);
       pool_free[BK_ARENA].clear();
       p = arena_take(words);
+    }
+    if (!p && (!g_hwq.empty() || !pool_limbo.empty())) {
+      // blocks freed while ops that name them wait in the queue are pinned (pool_limbo): hand everything over and look again
+      queue_submit();
+      std::lock_guard<std::mutex> lk(pool_mu);
+      auto it = pool_free[BK_ARENA].find(words);
+      if (it != pool_free[BK_ARENA].end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+      } else {
+        for (auto& kv : pool_free[BK_ARENA])
+          for (u64* q : kv.second) arena_give(q, kv.first);
+        pool_free[BK_ARENA].clear();
+        p = arena_take(words);
+      }
     }
     if (!p && g_arena.nrep == 1) {  // one replica: a separate allocation serves as well; reuse those first
       std::lock_guard<std::mutex> lk(pool_mu);

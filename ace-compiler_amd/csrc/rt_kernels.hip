@@ -67,6 +67,43 @@ void launch_sample_uniform(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n
   hipLaunchKernelGGL(sample_uniform_kernel, grid, block, 0, s, c, out, level, pos0, seed);
 }
 
+// uniform in [0,q) under a 256-bit key: one ChaCha20 block (RFC 8439 2.3: constants | key | counter | nonce, 20 rounds, + input) per four
+// coefficients, each of its four 128-bit quarters reduced mod q (124 bits kept: bias < 2^-60).  counter = t (coefficients 4t .. 4t+3),
+// nonce = (limb position, "UNIF", 0): every (key, position, t) names one block, whatever the launch shape.
+__device__ __forceinline__ u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define ACEHIP_QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+__global__ __launch_bounds__(256) void sample_uniform_keyed_kernel(DevCtx c, u64* out, u32 level, u32 pos0, ChaChaKey key) {
+  const u32 pos = pos0 + blockIdx.y;
+  if (!owns(c, limb_prime(pos, level, c.L))) return;
+  out = reb(c, out, c.rep0 + blockIdx.z);  // (every replica gets the same sample)
+  const DevPrime& P = c.primes[limb_prime(pos, level, c.L)];
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (4 * t >= c.N) return;
+  const u32 s0 = 0x61707865u, s1 = 0x3320646eu, s2 = 0x79622d32u, s3 = 0x6b206574u, s13 = pos, s14 = 0x554E4946u, s15 = 0;
+  u32 x0 = s0, x1 = s1, x2 = s2, x3 = s3, x4 = key.w[0], x5 = key.w[1], x6 = key.w[2], x7 = key.w[3], x8 = key.w[4], x9 = key.w[5],
+      x10 = key.w[6], x11 = key.w[7], x12 = t, x13 = s13, x14 = s14, x15 = s15;
+  for (int i = 0; i < 10; ++i) {
+    ACEHIP_QR(x0, x4, x8, x12) ACEHIP_QR(x1, x5, x9, x13) ACEHIP_QR(x2, x6, x10, x14) ACEHIP_QR(x3, x7, x11, x15)
+    ACEHIP_QR(x0, x5, x10, x15) ACEHIP_QR(x1, x6, x11, x12) ACEHIP_QR(x2, x7, x8, x13) ACEHIP_QR(x3, x4, x9, x14)
+  }
+  const u32 w[16] = {x0 + s0, x1 + s1, x2 + s2, x3 + s3, x4 + key.w[0], x5 + key.w[1], x6 + key.w[2], x7 + key.w[3], x8 + key.w[4],
+                     x9 + key.w[5], x10 + key.w[6], x11 + key.w[7], x12 + t, x13 + s13, x14 + s14, x15 + s15};
+  u64* o = out + (size_t)pos * c.N + 4 * (size_t)t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u64 lo = (u64)w[4 * j] | ((u64)w[4 * j + 1] << 32), hi = (u64)w[4 * j + 2] | ((u64)w[4 * j + 3] << 32);
+    o[j] = reduce128(U128{lo, hi >> 4}, P.q, P.prec128_lo, P.prec128_hi);
+  }
+}
+#undef ACEHIP_QR
+void launch_sample_uniform_keyed(const DevCtx& c, u64* out, u32 level, u32 pos0, u32 n_limbs, const ChaChaKey& key, hipStream_t s) {
+  ACEHIP_ABLATE(ABL_OTHER);
+  if (n_limbs == 0) return;
+  dim3 grid((c.N / 4 + 255) / 256, n_limbs, c.nrep), block(256);
+  hipLaunchKernelGGL(sample_uniform_keyed_kernel, grid, block, 0, s, c, out, level, pos0, key);
+}
+
 __global__ __launch_bounds__(256) void mul_scalars_kernel(DevCtx c, u64* r, const u64* a, LimbConsts w, u32 level, u32 pos0) {
   const u32 pos = pos0 + blockIdx.y;
   if (!owns(c, limb_prime(pos, level, c.L))) return;

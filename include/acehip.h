@@ -16,6 +16,9 @@
  * acehip_last_error() returns a message for the calling thread.  (The reference aborts via
  * FMT_ASSERT, include/common/error.h:23-29; the rt_ant shim on top of this ABI does the same.)
  * All launches are asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Threads: an acehip_ctx is used by ONE host thread at a time (replica selection, workspace and statistics live in it); host
+ * threads that work concurrently each create their own context on the same device -- tables and keys are read-only device memory
+ * that several contexts may share (this is what the rt_ant shim does for the reference's one-thread-per-image main()).
  */
 #ifndef ACEHIP_H
 #define ACEHIP_H
@@ -256,6 +259,12 @@ int acehip_encode_status(acehip_ctx* ctx);
 /* uniformly random residues (Sample_uniform_poly polynomial.c:1349-1371; the generator differs from the
  * reference's BLAKE2 PRNG: key material is random by construction, parity is per operator) */
 int acehip_sample_uniform(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, uint64_t seed, acehip_stream stream);
+/* the same under a 256-bit key (the form key generation uses outside the ACEHIP_SEED test mode; the reference: Sample_uniform_poly over
+ * its BLAKE2Xb PRNG, prng.c:33-69): coefficients 4t .. 4t+3 of limb position `pos` are the four 128-bit quarters of the ChaCha20 block
+ * (RFC 8439 2.3) with this key, block counter t and nonce (pos, "UNIF", 0), each reduced mod the limb's prime (bias < 2^-60).
+ * h_key: eight 32-bit words on the HOST. */
+int acehip_sample_uniform_keyed(acehip_ctx* ctx, uint64_t* d_poly, uint32_t level, uint32_t pos0, uint32_t n_limbs, const uint32_t* h_key,
+                                acehip_stream stream);
 /* d_res[pos] = d_a[pos] * h_scalars[pos - pos0] mod prime(pos); h_scalars is a HOST array of n_limbs words
  * (Scalars_integer_multiply_poly polynomial.c:234-268, Scalar_integer_multiply_poly :198) */
 int acehip_mul_scalars(acehip_ctx* ctx, uint64_t* d_res, const uint64_t* d_a, const uint64_t* h_scalars, uint32_t level, uint32_t pos0, uint32_t n_limbs, acehip_stream stream);

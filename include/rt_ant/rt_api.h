@@ -14,6 +14,10 @@ void       Acehip_rt_sync(void);
 /* Extension: fingerprint of the sources this library was built from (16 hex digits, embedded by the build); Prepare_context aborts
  * when it differs from libacehip's acehip_source_fingerprint() -- the two libraries of one build always agree. */
 const char* acehip_rt_source_fingerprint(void);
+/* Extension (test hook): the ChaCha20 block function (RFC 8439 2.3) behind the runtime's random streams -- 8 key words, block
+ * counter, 3 nonce words -> 16 output words.  Keys and encryption randomness are ChaCha20 streams of a 256-bit master key from
+ * getrandom(2) (the reference: BLAKE2Xb over /dev/urandom, src/util/prng.c:33-69); ACEHIP_SEED selects a reproducible TEST mode. */
+void        acehip_rt_debug_chacha20_block(const uint32_t* key, uint32_t counter, const uint32_t* nonce, uint32_t* out);
 /* Extension: a thread other than the one that called Prepare_context attaches to that context on its first API
  * call (shared keys; own scratch, pool, queue, HIP stream); before it ends it may give those back. */
 void       Acehip_rt_thread_release(void);

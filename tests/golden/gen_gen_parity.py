@@ -96,7 +96,7 @@ def run_model(key, tmp):
     t0 = time.time()
     r = subprocess.run([os.path.join(EX, "refgen_model_" + name), "1"], capture_output=True, text=True, env=env)
     wall = time.time() - t0
-    log = os.path.join(ROOT, "profiles", "r04_ref_%s_seeded.log" % key)
+    log = os.path.join(ROOT, "profiles", "r05_ref_%s_seeded.log" % key)
     open(log, "w").write(r.stdout + "\n--- stderr ---\n" + r.stderr)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     m = re.search(r"logits9:((?: -?\d+\.\d+)+)", r.stdout)

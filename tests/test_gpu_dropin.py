@@ -72,6 +72,43 @@ def test_deferred_zero_fills_are_never_seen_late(tmp_path):
     assert outs[("1", "1")] == outs[("0", "1")] == outs[("0", "0")]
 
 
+def test_ops_kept_queued_across_declared_launches_are_never_misordered(tmp_path):
+    """tests/c/keep_queue.c: generated-style code whose per-limb ops stay queued while later key-switches / rescales run (rt_poly.cpp
+    "keeping ops queued"): accumulations across rotations, write-after-read / read-after-write / write-after-write against direct
+    launches, readers of blocks freed in the meantime.  Correct against the clear computation; bit-identical slot by slot with the
+    mechanism off (ACEHIP_HW_KEEP=0), with the library's stage order off (ACEHIP_HW_STAGES=0) and under ACEHIP_POISON=1; ops really
+    do stay queued; and an operand left out of a declared list on purpose (ACEHIP_POISON_SELFTEST=1) aborts under poison."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "keep_queue")
+    inc = os.path.join(ROOT, "include")
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c", "keep_queue.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe]
+    subprocess.check_call(cmd)
+    outs = {}
+    for tag, extra in (("keep", {}), ("off", {"ACEHIP_HW_KEEP": "0"}), ("nostage", {"ACEHIP_HW_STAGES": "0"}),
+                       ("all_off", {"ACEHIP_HW_KEEP": "0", "ACEHIP_HW_STAGES": "0", "ACEHIP_LAZY_ZERO": "0", "ACEHIP_HW_DISCARD": "0"}),
+                       ("poison", {"ACEHIP_POISON": "1"}), ("batch3", {"ACEHIP_BATCH": "3"})):
+        env = dict(os.environ, ACEHIP_SEED="99", ACEHIP_PROFILE="1", **extra)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "SUCESS!" in r.stdout, tag + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith("slot ")]
+        assert len(outs[tag]) == 64 - 5 - 4
+        kept = [ln for ln in r.stdout.splitlines() if "queue kept open" in ln]
+        assert kept, r.stdout[-1500:]
+        n_kept = int(kept[0].split("(")[1].split()[0])
+        assert (n_kept > 0) == (extra.get("ACEHIP_HW_KEEP") != "0"), kept[0]
+    assert outs["keep"] == outs["off"] == outs["nostage"] == outs["all_off"] == outs["poison"] == outs["batch3"]
+    # the safety net: one input of the paired Mod_down missing from its declared list -> the ops that produce it stay queued, the
+    # launch reads memory nobody wrote, and the poison check names the undeclared range and aborts
+    env = dict(os.environ, ACEHIP_SEED="99", ACEHIP_POISON="1", ACEHIP_POISON_SELFTEST="1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "does not declare" in r.stderr, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_raised_digits_are_never_reused_stale(tmp_path):
     """tests/c/modup_reuse.c: rotations spelled at the polynomial level like the generated Rotate(); the same ciphertext
     rotated three times (digits raised once), then changed in place by queued ops, rewritten at the same address by direct

@@ -205,3 +205,64 @@ def test_reference_accepts_our_keys_and_ciphertexts(name, made):
     for step in ("add", "sub", "add_plain", "plain", "mul_plain", "mul_plain_rescaled", "mul3", "relin", "relin_rescaled", "mul", "modswitch",
                  "rot_1", "rot_low_1"):
         assert "MATCH %s\n" % step in r.stdout, tail
+
+
+def test_keyed_uniform_sampler_is_chacha20_reduced_mod_q():
+    """acehip_sample_uniform_keyed (the device sampler behind the public `a` polynomials outside the ACEHIP_SEED test mode): coefficients
+    4t..4t+3 of limb position pos = the four 128-bit quarters of the ChaCha20 block (key, counter t, nonce (pos, 'UNIF', 0)), top four bits
+    dropped, reduced mod the limb's prime -- recomputed here with Python integers (RFC 8439 block function of tests/test_valid_helpers.py);
+    and the samples look uniform (mean and variance of x / q over a limb)."""
+    import ctypes as C
+
+    import ace_compiler_amd as A
+    from test_valid_helpers import _chacha_block_py
+
+    N, L = 4096, 5
+    rt = A.AceHip(N, L, 60, 50, 2, device=0)
+    T = L + rt.K
+    key = [0x03020100 + 0x04040404 * i for i in range(8)]
+    d = rt.buf(T * N)
+    rt.check(rt.lib.acehip_sample_uniform_keyed(rt.h, d.ptr, L, 0, T, (C.c_uint32 * 8)(*key), None))
+    got = d.download((T, N))
+    for pos in (0, 3, T - 1):
+        q = int(rt.primes[pos])
+        for t in (0, 1, 77, N // 4 - 1):
+            w = _chacha_block_py(key, t, [pos, 0x554E4946, 0])
+            for j in range(4):
+                lo = w[4 * j] | (w[4 * j + 1] << 32)
+                hi = w[4 * j + 2] | (w[4 * j + 3] << 32)
+                assert int(got[pos, 4 * t + j]) == (((hi >> 4) << 64) | lo) % q, (pos, t, j)
+        x = got[pos].astype(np.float64) / q
+        assert abs(x.mean() - 0.5) < 0.02 and abs(x.var() - 1 / 12) < 0.01
+    # another key, another stream; the same key, the same stream
+    d2 = rt.buf(T * N)
+    rt.check(rt.lib.acehip_sample_uniform_keyed(rt.h, d2.ptr, L, 0, T, (C.c_uint32 * 8)(*key), None))
+    assert np.array_equal(d2.download((T, N)), got)
+    key[0] ^= 1
+    rt.check(rt.lib.acehip_sample_uniform_keyed(rt.h, d2.ptr, L, 0, T, (C.c_uint32 * 8)(*key), None))
+    assert not np.array_equal(d2.download((T, N)), got)
+    rt.close()
+
+
+def test_unseeded_runs_use_fresh_randomness_and_still_decrypt(product_exe, tmp_path):
+    """without ACEHIP_SEED every stream is ChaCha20 under 256 bits from getrandom(): two runs make different keys, and each run still
+    decrypts its own ciphertexts to the messages (in_a through encrypt / decrypt, the product a * b through tensor product,
+    relinearisation under the fresh key and rescale)"""
+    digests = []
+    for k in range(2):
+        d = str(tmp_path / ("run%d" % k))
+        os.makedirs(d)
+        env = {k: v for k, v in os.environ.items() if k != "ACEHIP_SEED"}
+        r = subprocess.run([product_exe, "make", d] + CONFIGS["n4096_hw192"].split(), capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "made: keys.bin" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        import hashlib
+        import math
+        import re
+
+        vals = {m.group(1): [float(v) for v in m.group(2).split()] for m in re.finditer(r"msg_(\w+)\[0\.\.3\] =((?: -?\d+\.\d+)+)", r.stdout)}
+        xa = [math.sin(0.37 * i) * 0.5 for i in range(4)]
+        xb = [math.cos(0.23 * i + 1.0) * 0.4 for i in range(4)]
+        assert max(abs(g - w) for g, w in zip(vals["in_a"], xa)) < 1e-6, vals["in_a"]
+        assert max(abs(g - a * b) for g, a, b in zip(vals["relin_rescaled"], xa, xb)) < 1e-5, vals["relin_rescaled"]
+        digests.append(hashlib.sha256(open(os.path.join(d, "keys.bin"), "rb").read()).hexdigest())
+    assert digests[0] != digests[1]

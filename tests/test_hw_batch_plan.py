@@ -212,6 +212,58 @@ def test_convolution_taps_keep_the_accumulator_in_registers(rt):
             assert len(stores) <= 2, stores  # (the multiply-add that hands over to the last tap's plain add, and that add)
 
 
+def test_tails_of_several_rotations_run_in_three_stages(rt):
+    """What the rt_ant shim hands over since it keeps ops queued across the direct launches of a key-switch: the TAILS of several
+    generated Rotate() calls in one list -- per rotation k and limb:  d0_k += c0 (elementwise), rot_k = gather(d0_k), gather(d1_k),
+    then the tap  tmp = rot_k * pt_k, acc += tmp.  In program order every gather cuts the elementwise run, and the accumulator is
+    stored and reloaded per rotation.  The stage order (api_hw_batch.cpp hw_stage_order) runs all additions, then all gathers in ONE
+    launch, then all taps: the accumulator is stored once.  ACEHIP_HW_STAGES only changes the schedule, never the result (replayed
+    against sequential execution by _check)."""
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    rots, n_limbs = 4, 3
+    # rows: 0/1 acc c0/c1, 2/3 tmp c0/c1, 4 c0 of the source, 10+4k.. d0_k d1_k rot_k.c0 rot_k.c1, 40+k plaintext k
+    prog = []
+    for k in range(rots):
+        d0, d1, r0, r1 = 10 + 4 * k, 11 + 4 * k, 12 + 4 * k, 13 + 4 * k
+        for g in range(n_limbs):
+            prog.append((B.HW_ADD, g, at(d0, g), at(d0, g), at(4, g)))
+        for g in range(n_limbs):
+            prog += [(B.HW_ROTATE, g, at(r0, g), at(d0, g), 1 + k % 2), (B.HW_ROTATE, g, at(r1, g), at(d1, g), 1 + k % 2)]
+        for g in range(n_limbs):
+            prog += [(B.HW_MUL, g, at(2, g), at(r0, g), at(40 + k, g)), (B.HW_MUL, g, at(3, g), at(r1, g), at(40 + k, g)),
+                     (B.HW_ADD, g, at(0, g), at(0, g), at(2, g)), (B.HW_ADD, g, at(1, g), at(1, g), at(3, g))]
+    plan = _check(rt, prog, 45 * T, 17)
+    launches = []
+    for p in plan:
+        kind = "rot" if (p[0] & 0xFF) == B.HW_ROTATE else "ew"
+        if not launches or launches[-1][0] != p[5]:
+            launches.append((p[5], kind))
+    assert [k for _, k in launches] == ["ew", "rot", "ew"], launches     # (program order: ew rot ew rot ew rot ew rot ew)
+    for g in range(n_limbs):
+        for row in (0, 1):
+            stores = [p for p in plan if p[2] == at(row, g) and not (p[0] & B.HW_NOSTORE)]
+            assert len(stores) <= 2, stores                              # not once per rotation
+
+
+def test_stage_order_respects_every_hazard(rt):
+    """gathers and elementwise ops that DO depend on each other keep their order: a gather that reads what an earlier elementwise
+    op wrote, an elementwise op that overwrites the source of an earlier gather (write after read), a gather into a limb an earlier
+    elementwise op reads, two gathers through the same limb"""
+    T = rt.L + rt.K
+    at = lambda row, g: BASE + (row * T + g) * SPAN  # noqa: E731
+    g = 0
+    prog = [(B.HW_ADD, g, at(1, g), at(0, g), at(0, g)),        # x1 = 2 x0
+            (B.HW_ROTATE, g, at(2, g), at(1, g), 1),            # x2 = rot(x1)           read after write
+            (B.HW_MUL, g, at(1, g), at(0, g), at(0, g)),        # x1 = x0^2              write after read of the gather's source
+            (B.HW_ROTATE, g, at(3, g), at(1, g), 2),            # x3 = rot(x1 new)
+            (B.HW_ADD, g, at(4, g), at(3, g), at(2, g)),        # x4 = x3 + x2
+            (B.HW_ROTATE, g, at(2, g), at(4, g), 1),            # x2 = rot(x4)           gather into a limb an earlier op read
+            (B.HW_ROTATE, g, at(5, g), at(2, g), 2),            # x5 = rot(x2)           gather after gather through x2
+            (B.HW_SUB, g, at(0, g), at(5, g), at(4, g))]        # x0 = x5 - x4           overwrites the first operand of everything
+    _check(rt, prog, 6 * T, 23)
+
+
 def test_scalar_term_sums_keep_the_accumulator_in_registers(rt):
     """Sums of scalar multiples as the generated activation polynomials and the bootstrap spell them: per term  t = copy(x_k);
     t = t * c_k; acc = acc + t  through one temporary.  The kernel keeps its two most recent results in registers (the temporary

@@ -89,3 +89,45 @@ def test_gemm_relu_add_pools(lib):
     assert np.allclose(_take(lib.Average_pool_ref(_d(t), 1, 2, 8, 8, 2, 2, 2, 2, 0, 0, 0, 0), 32), want.ravel(), rtol=1e-12)
     assert np.allclose(_take(lib.Max_pool_ref(_d(t), 1, 2, 8, 8, 2, 2, 2, 2, 0, 0, 0, 0), 32), want.ravel(), rtol=1e-12)  # (validated as average)
     assert np.allclose(_take(lib.Global_average_pool_ref(_d(t), 1, 2, 8, 8), 2), t.mean(axis=(2, 3)).ravel(), rtol=1e-12)
+
+
+def _chacha_block_py(key, counter, nonce):
+    """RFC 8439 section 2.3 on Python integers (the checker of the runtime's block function)"""
+    M = 0xFFFFFFFF
+    rotl = lambda x, n: ((x << n) | (x >> (32 - n))) & M  # noqa: E731
+    s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key) + [counter] + list(nonce)
+    x = list(s)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & M for a, b in zip(x, s)]
+
+
+def test_chacha20_block_of_the_random_streams(lib):
+    """the block function behind key generation / encryption randomness (csrc/rt/rt_rng.hpp) against the known answer of RFC 8439 2.3.2
+    and against the restatement above on other inputs"""
+    lib.acehip_rt_debug_chacha20_block.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.acehip_rt_debug_chacha20_block.restype = None
+
+    def block(key, counter, nonce):
+        out = (C.c_uint32 * 16)()
+        lib.acehip_rt_debug_chacha20_block((C.c_uint32 * 8)(*key), counter, (C.c_uint32 * 3)(*nonce), out)
+        return list(out)
+
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    got = block(key, 1, [0x09000000, 0x4A000000, 0])
+    assert got == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+                   0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        k = [int(v) for v in rng.integers(0, 1 << 32, 8)]
+        n = [int(v) for v in rng.integers(0, 1 << 32, 3)]
+        c = int(rng.integers(0, 1 << 32))
+        assert block(k, c, n) == _chacha_block_py(k, c, n)

@@ -22,9 +22,9 @@ PROGRAM = {"resnet20": "resnet20_cifar10_pre", "resnet32": "resnet32_cifar10_pre
            "resnet44": "resnet44_cifar10_pre", "resnet56": "resnet56_cifar10_pre", "resnet110": "resnet110_cifar10_train"}
 # (the deeper the network, the smaller the largest sigma that stays in range: profiles/r04a_sigma_sweep.txt, r04ae_sigma_sweep_more_models.txt;
 #  ResNet-110 leaves the range at every sigma tried, profiles/r04f_sigma_sweep_resnet110.txt)
-SIGMA = {"resnet20": 0.2, "resnet32": 0.2, "resnet32c100": 0.2, "resnet44": 0.15, "resnet56": 0.12, "resnet110": 0.01}
+SIGMA = {"resnet20": 0.2, "resnet32": 0.15, "resnet32c100": 0.2, "resnet44": 0.13, "resnet56": 0.08, "resnet110": 0.01}
 SEED = 2
-GEN = {"resnet20": "numpy", "resnet32": "numpy", "resnet32c100": "numpy", "resnet44": "numpy", "resnet56": "numpy", "resnet110": "numpy"}
+GEN = {"resnet20": "ih12", "resnet32": "numpy", "resnet32c100": "numpy", "resnet44": "numpy", "resnet56": "numpy", "resnet110": "numpy"}
 
 
 def path_of(key, sigma=None, gen=None):
