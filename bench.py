@@ -338,6 +338,16 @@ def finish_cpu_baseline(res, stats_per_image):
                 "value": round(sum(1.0 / (full["image_s"] * t / pred) for t in per_core), 8), "unit": "images/s",
                 "note": "measured dev-container seconds per image (1 thread) x priced(this host) / priced(dev container), summed over the "
                         "loaded cores (one ratio for the whole image; `value` moves every function family by its own)"}
+    # the transfer model checked on the bench host itself (on demand: tools/cpu_model_check.py host, ~5 min of one core under gpurun):
+    # a real reference program the host can finish -- operator script + two bootstraps at this ring -- timed there by the reference's own
+    # clock, against profile_scaled_image() applied to that program's dev-container profile
+    chk = os.path.join(ROOT, "profiles", "cpu_model_check_bench_host.json")
+    if os.path.exists(chk):
+        c = json.load(open(chk))
+        res["model_check_on_bench_host"] = {k: c.get(k) for k in ("program", "host_cpu", "dev_cpu", "dev_measured_s", "predicted_s", "measured_s",
+                                                                     "predicted_over_measured", "method")}
+        res["model_check_on_bench_host"]["same_cpu_model_as_this_run"] = c.get("host_cpu") == res.get("cpu_model")
+        res["model_check_on_bench_host"]["source"] = "profiles/cpu_model_check_bench_host.json (tools/cpu_model_check.py)"
     _extrapolate_socket(res)
 
 
@@ -974,40 +984,42 @@ def main():
         from ace_compiler_amd.binding import ArenaCfg
 
         KS_BATCH = 12
+        # (a context of its own: an arena that holds the pipeline's workspace stays with its context for good)
+        rtb = A.AceHip(N, L, Q0, SF, DNUM, device=local_rank)
+        hb = rtb.h
         lib.acehip_workspace_words.restype = C.c_size_t
-        ws_words = lib.acehip_workspace_words(h)
+        ws_words = lib.acehip_workspace_words(hb)
         gran = lambda w: (w + 31) // 32 * 32  # noqa: E731
         off_ws, off_sc = 0, gran(ws_words)
         off_a = off_sc + 2 * N
         off_o0 = off_a + gran(L * N)
         off_o1 = off_o0 + gran(L * N)
         rep_words = off_o1 + gran(L * N)
-        arena = rt.buf(rep_words * KS_BATCH)
+        arena = rtb.buf(rep_words * KS_BATCH)
         cfg = ArenaCfg(arena.ptr, rep_words * 8, rep_words * 8, KS_BATCH, arena.at(off_ws), arena.at(off_sc), 2)
-        rt.check(lib.acehip_ctx_set_arena(h, C.byref(cfg)))
-        rt.check(lib.acehip_ctx_select(h, 0, KS_BATCH))
-        rt.check(lib.acehip_upload(h, arena.at(off_a), host.ctypes.data, L * N * 8, None))  # every selected replica gets the input
+        rtb.check(lib.acehip_ctx_set_arena(hb, C.byref(cfg)))
+        rtb.check(lib.acehip_ctx_select(hb, 0, KS_BATCH))
+        rtb.check(lib.acehip_upload(hb, arena.at(off_a), host.ctypes.data, L * N * 8, None))  # every selected replica gets the input
 
         def ks_b():
-            rt.check(lib.acehip_key_switch(h, arena.at(off_o0), arena.at(off_o1), arena.at(off_a), key.ptr, L, None))
+            rtb.check(lib.acehip_key_switch(hb, arena.at(off_o0), arena.at(off_o1), arena.at(off_a), key.ptr, L, None))
 
         for _ in range(3):
             ks_b()
-        ksb_ms = rt.time_ms(ks_b, 20)
+        ksb_ms = rtb.time_ms(ks_b, 20)
         # every replica must hold the bits of the single operation (same input, same key)
         ref0 = np.empty(L * N, dtype=np.uint64)
         got = np.empty(L * N, dtype=np.uint64)
         ks()
-        rt.check(lib.acehip_ctx_select(h, 0, 1))
-        rt.check(lib.acehip_download(h, ref0.ctypes.data, o0.ptr, L * N * 8, None))
+        rt.check(lib.acehip_memcpy_d2h(ref0.ctypes.data, o0.ptr, L * N * 8, None))
         same = True
         for r in (0, KS_BATCH // 2, KS_BATCH - 1):
-            rt.check(lib.acehip_ctx_select(h, r, 1))
-            rt.check(lib.acehip_download(h, got.ctypes.data, arena.at(off_o0), L * N * 8, None))
+            rtb.check(lib.acehip_ctx_select(hb, r, 1))
+            rtb.check(lib.acehip_download(hb, got.ctypes.data, arena.at(off_o0), L * N * 8, None))
             same = same and bool(np.array_equal(got, ref0))
-        rt.check(lib.acehip_ctx_select(h, 0, 1))
-        rt.check(lib.acehip_ctx_set_arena(h, None))
+        rtb.sync()
         arena.free()
+        rtb.close()
         ks_batched = {"ciphertexts_per_launch": KS_BATCH, "ms_per_launch_set": round(ksb_ms, 4), "ms_per_key_switch": round(ksb_ms / KS_BATCH, 4),
                       "per_s": round(KS_BATCH * 1e3 / ksb_ms, 1),
                       # the key is read once per launch set: algorithmic bytes = B x (single - key) + key

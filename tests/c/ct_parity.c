@@ -33,6 +33,9 @@
 #include "rt_ant/rt_ant.h"
 
 #ifdef REF_BUILD
+#include <time.h>
+void Ref_sampler_start(void); /* tests/c/ref_sampler.c (inert without REF_SAMPLER_OUT) */
+void Ref_sampler_stop(void);
 #include "rtlib/context.h"
 #include "util/ckks_key_generator.h"
 #include "util/ckks_parameters.h"
@@ -472,8 +475,19 @@ int main(int argc, char** argv) {
     Acehip_rt_load_ciph(&b, p);
   }
 #endif
+#ifdef REF_BUILD
+  /* the operator script as a timed span of the REFERENCE: CPU seconds of this process between here and the end of the script
+   * (tools/cpu_model_check.py: a real program of the reference timed on the bench host, against what bench.py's CPU model predicts
+   * for it); with REF_SAMPLER_OUT set the span is also sampled (tests/c/ref_sampler.c -> tools/ref_profile_report.py) */
+  struct timespec ts0_, ts1_;
+  clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts0_);
+  Ref_sampler_start();
+#endif
   script(a, b);
 #ifdef REF_BUILD
+  Ref_sampler_stop();
+  clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts1_);
+  printf("script_cpu_s %.3f\n", (ts1_.tv_sec - ts0_.tv_sec) + 1e-9 * (ts1_.tv_nsec - ts0_.tv_nsec));
   write_keys(kpath); /* after the script: Bootstrap creates the keys of a new slot count on first use */
 #endif
   Free_ciph_poly(&a, 1);

@@ -24,7 +24,7 @@ PROGRAM = {"resnet20": "resnet20_cifar10_pre", "resnet32": "resnet32_cifar10_pre
 #  ResNet-110 leaves the range at every sigma tried, profiles/r04f_sigma_sweep_resnet110.txt)
 SIGMA = {"resnet20": 0.2, "resnet32": 0.15, "resnet32c100": 0.2, "resnet44": 0.13, "resnet56": 0.08, "resnet110": 0.01}
 SEED = 2
-GEN = {"resnet20": "ih12", "resnet32": "numpy", "resnet32c100": "numpy", "resnet44": "numpy", "resnet56": "numpy", "resnet110": "numpy"}
+GEN = {k: "ih12" for k in ENTRIES}  # what the NEXT reference run of a model uses; a fixture entry records the generator it was made with
 
 
 def path_of(key, sigma=None, gen=None):
