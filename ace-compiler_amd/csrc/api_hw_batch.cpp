@@ -200,12 +200,12 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg, const DevCtx& d
     g_hw_what_if[w] += loads;
   }
   for (u32 sgm = 0; sgm < n_seg; ++sgm) {
-    const u64 *r0 = nullptr, *r1 = nullptr;  // the kernel's two register entries
+    const u64 *r0 = nullptr, *r1 = nullptr, *rb = nullptr;  // the kernel's two result entries and its operand entry
     const u32 beg = args.seg_start[sgm], end = args.seg_start[sgm + 1];
     for (u32 k = beg; k < end; ++k) {
       const HwBatchOp& o = args.op[k];
       const u32 kind = o.kind & HW_OP_KIND_MASK;
-      auto miss = [&](const u64* x) { return x != r0 && x != r1; };
+      auto miss = [&](const u64* x) { return x != r0 && x != r1 && x != rb; };
       u64 loads = 0, sh = 0;
       if (kind != HW_OP_ZERO) {
         loads += miss(o.a);
@@ -213,9 +213,11 @@ static void hw_traffic_count(const HwBatchArgs& args, u32 n_seg, const DevCtx& d
         if (kind == HW_OP_ADD || kind == HW_OP_SUB || kind == HW_OP_MUL || kind == HW_OP_MULADD) {
           loads += miss(o.b);
           sh += miss(o.b) && shared(o.b);
+          if (o.b != r0 && o.b != r1) rb = o.b;
         }
         if (kind == HW_OP_MULADD) loads += miss(o.res);
       }
+      if (o.res == rb) rb = nullptr;
       g_hw_traffic[kind][3] += sh;
       const bool keep = (o.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == o.res);
       g_hw_traffic[kind][0] += 1;
@@ -592,6 +594,76 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
       }
       live = w;
       h.ord.resize(live);
+    }
+  }
+  // Siblings (round 5): chains that read the SAME read-only limb as second operand at neighbouring places of the program -- the c0 and
+  // the c1 chain of a plaintext product (both multiply by the plaintext's limb), the two accumulators of a key inner product (both
+  // multiply by the raised digit's limb) -- are put into ONE segment, ops in program order, so that the kernel's operand entry
+  // (hw_batch_ew_kernel) loads the shared limb once.  Chains are independent (no written limb in common), so any merge that keeps program
+  // order inside the segment computes the same values; the accumulators of two siblings fit the kernel's two result entries.
+  static const bool siblings_on = [] { const char* e = getenv("ACEHIP_HW_SIBLINGS"); return !e || atoi(e) != 0; }();  // (measurement knob)
+  if (siblings_on && h.cnt.size() > 1) {
+    const u32 n_ch = (u32)h.cnt.size();
+    static thread_local std::vector<u32> ch_of, ch_parent, ch_size, last_reader, grp_start;
+    ch_of.assign(m, UINT32_MAX);
+    ch_parent.resize(n_ch);
+    ch_size.resize(n_ch);
+    {
+      u32 ch = 0;
+      for (size_t t = 0; t < live; ++t) {
+        while (t >= h.cnt[ch]) ++ch;
+        ch_of[h.ord[t]] = ch;
+      }
+      for (u32 j = 0; j < n_ch; ++j) {
+        ch_parent[j] = j;
+        ch_size[j] = h.cnt[j] - (j ? h.cnt[j - 1] : 0);
+      }
+    }
+    last_reader.assign(n_nodes, UINT32_MAX);  // per read-only limb: the live op that read it last as second operand
+    bool merged = false;
+    constexpr u32 kWindow = 6, kMaxSegment = HW_BATCH_MAX / 2;
+    u32 live_seen = 0;
+    static thread_local std::vector<u32> live_idx;
+    live_idx.assign(m, 0);
+    for (size_t k = 0; k < m; ++k) {
+      if (h.dead[k]) continue;
+      live_idx[k] = live_seen++;
+      if (!hw_has_b(h.kind[k])) continue;
+      const u32 nb = h.n_b[k];
+      if (h.written[nb]) continue;
+      const u32 p = last_reader[nb];
+      last_reader[nb] = (u32)k;
+      if (p == UINT32_MAX || live_idx[k] - live_idx[p] > kWindow || ops[p].prime_gi != ops[k].prime_gi) continue;
+      const u32 ca = uf_find(ch_parent, ch_of[k]), cb = uf_find(ch_parent, ch_of[p]);
+      if (ca == cb || ch_size[ca] + ch_size[cb] > kMaxSegment) continue;
+      ch_parent[cb] = ca;
+      ch_size[ca] += ch_size[cb];
+      merged = true;
+    }
+    if (merged) {  // new emission order: groups by first appearance, ops of a group in program order
+      static thread_local std::vector<u32> grp_of_root, new_cnt, new_ord;
+      grp_of_root.assign(n_ch, UINT32_MAX);
+      new_cnt.clear();
+      for (size_t k = 0; k < m; ++k) {
+        if (h.dead[k]) continue;
+        const u32 root = uf_find(ch_parent, ch_of[k]);
+        if (grp_of_root[root] == UINT32_MAX) {
+          grp_of_root[root] = (u32)new_cnt.size();
+          new_cnt.push_back(0);
+        }
+        new_cnt[grp_of_root[root]]++;
+      }
+      u32 run2 = 0;
+      for (auto& x : new_cnt) {
+        const u32 t = x;
+        x = run2;
+        run2 += t;
+      }
+      new_ord.resize(live);
+      for (size_t k = 0; k < m; ++k)
+        if (!h.dead[k]) new_ord[new_cnt[grp_of_root[uf_find(ch_parent, ch_of[k])]]++] = (u32)k;
+      h.ord.swap(new_ord);
+      h.cnt.assign(new_cnt.begin(), new_cnt.end());
     }
   }
   // Which results have to reach memory: walking the list backwards, need[x] = the version of limb x that is current here is

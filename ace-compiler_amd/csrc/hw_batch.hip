@@ -101,7 +101,25 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   // decide which results have to reach memory: api_hw_batch.cpp RegCache.)
   const u64 *r0 = nullptr, *r1 = nullptr;
   V4 v0{{0, 0}, {0, 0}}, v1{{0, 0}, {0, 0}};
-  auto fetch = [&](const u64* list_addr, const u64* real_addr) { return list_addr == r0 ? v0 : (list_addr == r1 ? v1 : ld4(real_addr + i)); };
+  // Round 5: one more entry, for an OPERAND -- the second operand most recently loaded from memory.  Generated code multiplies both
+  // polynomials of a ciphertext by the same plaintext limb, and both accumulators of a key inner product by the same raised digit
+  // limb (mul c0, mul c1 per limb); the host puts such sibling chains into one segment (api_hw_batch.cpp "siblings"), where the shared
+  // operand is then loaded once.  An op that writes the cached limb drops the entry.  (All address compares are on kernel arguments:
+  // wave-uniform.)
+  const u64* rb = nullptr;
+  V4 vbc{{0, 0}, {0, 0}};
+  auto fetch = [&](const u64* list_addr, const u64* real_addr) {
+    return list_addr == r0 ? v0 : (list_addr == r1 ? v1 : (list_addr == rb ? vbc : ld4(real_addr + i)));
+  };
+  auto fetch_b = [&](const u64* list_addr, const u64* real_addr) {
+    if (list_addr == r0) return v0;
+    if (list_addr == r1) return v1;
+    if (list_addr != rb) {
+      vbc = ld4(real_addr + i);
+      rb = list_addr;
+    }
+    return vbc;
+  };
   for (u32 k = beg; k < end; ++k) {
     HwBatchOp op = args.op[k];
     const u32 kind = op.kind & HW_OP_KIND_MASK;
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
           const u64 imm = (u64)(uintptr_t)op.b;
           vb = V4{{imm, imm}, {imm, imm}};
         } else {
-          vb = fetch(b0, op.b);
+          vb = fetch_b(b0, op.b);
         }
         switch (kind) {
           case HW_OP_ADD:
@@ -149,6 +167,7 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
       }
     }
     if (!keep_in_regs) st4(op.res + i, vr);
+    if (res0 == rb) rb = nullptr;  // the cached operand has a new value
     if (res0 != r0) {  // another limb than the last result's: that one becomes the older entry
       r1 = r0;
       v1 = v0;

@@ -181,17 +181,21 @@ def test_resnet20_batch_issued_in_replica_groups_matches_the_reference(tmp_path)
 
 
 def test_resnet20_logits_with_independent_keys_agree_to_ckks_precision(tmp_path):
-    """the tolerance-level check, now with digits: OUR random keys and encryption randomness (no seed), same weights and image --
-    the logits agree with the reference's to 5e-3 of the largest one.  (Independent keys mean independent CKKS noise: every one of the
-    19 bootstraps adds about 1.2e-3 at this parameter set on either runtime, profiles/r01m_bootstrap_precision.md; measured here
-    2.3e-3 of the largest logit.  The bit-level statement is the test above.)"""
+    """the tolerance-level check, with digits: OUR fresh keys and encryption randomness (no seed: a new ChaCha20 master key from the OS
+    every run), same weights and image -- the logits agree with the reference's to 2.5e-2 of the largest one.  Independent keys mean
+    independent CKKS noise: every one of the 19 bootstraps adds about 1.2e-3 at this parameter set on either runtime
+    (profiles/r01m_bootstrap_precision.md), i.e. 5e-3 absolute as a random walk and 2.3e-2 at worst on logits up to 0.44; measured on
+    single draws 2.3e-3 (round 4) and 7.2e-3 (round 5) of the largest logit.  The bound has to hold for EVERY draw of the keys, so it sits
+    at five times the random-walk figure -- and a single wrong rotation misses it by more than a factor of ten (asserted by the next test).  The bit-level statement
+    is the test above."""
     env = dict(os.environ, **_model_env())
     env.pop("MODEL_ENC_SEED")
+    env.pop("ACEHIP_SEED", None)
     r = subprocess.run([MODEL_EXE, "1"], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = [float(x) for x in _logits9(r.stdout)[0]]
     scale = max(abs(v) for v in MODEL["logits9"])
-    assert max(abs(a - b) for a, b in zip(got, MODEL["logits9"])) <= 5e-3 * scale, (got, MODEL["logits9"])
+    assert max(abs(a - b) for a, b in zip(got, MODEL["logits9"])) <= 2.5e-2 * scale, (got, MODEL["logits9"])
 
 
 def test_a_single_changed_rotation_is_caught(tmp_path, capsys):
@@ -204,8 +208,8 @@ def test_a_single_changed_rotation_is_caught(tmp_path, capsys):
     scale = max(abs(v) for v in MODEL["logits9"])
     err = max(abs(a - b) for a, b in zip(bad, MODEL["logits9"]))
     with capsys.disabled():
-        print("\n[negative control] one Rotate amount changed: max |logit - reference| = %.4f (tolerance of the parity test: %.6f)" % (err, 5e-3 * scale))
-    assert err > 10 * 5e-3 * scale
+        print("\n[negative control] one Rotate amount changed: max |logit - reference| = %.4f (tolerance of the parity test: %.6f)" % (err, 2.5e-2 * scale))
+    assert err > 10 * 2.5e-2 * scale
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

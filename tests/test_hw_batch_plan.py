@@ -174,7 +174,15 @@ def test_generated_key_inner_product_is_split_into_independent_chains(rt):
                      (B.HW_MUL, g, tmp, at(3 + 4 * digit, g), at(0, g)), (B.HW_ADD, g, at(5, g), at(5, g), tmp)]
     plan = _check(rt, prog, 10 * T, 5)
     kinds = [p[0] & 0xFF for p in plan]
-    assert len({(la, sg) for *_, la, sg in plan}) >= 2 * T - 1      # independent chains
+    segs = {}
+    for q in plan:
+        segs.setdefault((q[5], q[6]), []).append(q)
+    # independent chains: one per limb -- the two accumulators of a limb are SIBLINGS (both multiply by the same raised-digit limb) and share
+    # a segment, ops in program order, so that the kernel's operand entry loads that limb once (round 5)
+    assert len(segs) >= T - 1
+    shared_b = sum(1 for ops in segs.values() for x, y in zip(ops, ops[1:]) if x[4] == y[4] and (x[0] & 0xFF) in (B.HW_MUL, B.HW_MULADD)
+                   and (y[0] & 0xFF) in (B.HW_MUL, B.HW_MULADD))
+    assert shared_b >= 2 * (T - 1)                                  # (per limb: digit 0 and digit 1, the second product right behind the first)
     assert sum(1 for p in plan if p[2] >= SCRATCH) == 0             # no private version is ever written
     assert B.HW_ZERO not in kinds                                   # every fill met its first addend
     # digit 0: 2T products written into their accumulator directly; digit 1: 2T multiply-adds but the very last (product in the
@@ -210,6 +218,15 @@ def test_convolution_taps_keep_the_accumulator_in_registers(rt):
         for row in (0, 1):
             stores = [p for p in plan if p[2] == at(row, g) and not (p[0] & B.HW_NOSTORE)]
             assert len(stores) <= 2, stores  # (the multiply-add that hands over to the last tap's plain add, and that add)
+    # siblings (round 5): the c0 and the c1 chain of a limb multiply by the same plaintext limb; they share a segment, c0 and c1 of a tap
+    # next to each other, so that the kernel's operand entry loads the plaintext limb once per tap instead of twice
+    segs = {}
+    for q in plan:
+        segs.setdefault((q[5], q[6]), []).append(q)
+    assert len(segs) == n_limbs
+    for ops in segs.values():
+        pairs = sum(1 for x, y in zip(ops, ops[1:]) if x[4] == y[4] and x[4] >= at(20, 0))
+        assert pairs >= taps - 1, [hex(o[4]) for o in ops]
 
 
 def test_tails_of_several_rotations_run_in_three_stages(rt):
