@@ -619,6 +619,21 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
         ch_size[j] = h.cnt[j] - (j ? h.cnt[j - 1] : 0);
       }
     }
+    // only chains that (but for one op) write ONE limb (an accumulator, a plain result) are merged: two of them fill the kernel's two result entries;
+    // a chain that alternates between a temporary and an accumulator needs both entries for itself (merging such chains measured
+    // 3 % MORE stores: the temporaries evicted each other)
+    static thread_local std::vector<char> one_limb;
+    one_limb.assign(n_ch, 1);
+    {
+      static thread_local std::vector<u32> first_res, other_writes;
+      first_res.assign(n_ch, UINT32_MAX);
+      other_writes.assign(n_ch, 0);
+      for (size_t t = 0; t < live; ++t) {
+        const u32 k = h.ord[t], ch = ch_of[k], nr = h.n_res[k];
+        if (first_res[ch] == UINT32_MAX) first_res[ch] = nr;
+        else if (first_res[ch] != nr && ++other_writes[ch] > 1) one_limb[ch] = 0;  // (one stray write is fine: the last, visible product of a tap loop)
+      }
+    }
     last_reader.assign(n_nodes, UINT32_MAX);  // per read-only limb: the live op that read it last as second operand
     bool merged = false;
     constexpr u32 kWindow = 6, kMaxSegment = HW_BATCH_MAX / 2;
@@ -634,8 +649,10 @@ void hw_run_ew(acehip_ctx* c, const acehip_hw_op* ops, size_t m, hipStream_t st,
       const u32 p = last_reader[nb];
       last_reader[nb] = (u32)k;
       if (p == UINT32_MAX || live_idx[k] - live_idx[p] > kWindow || ops[p].prime_gi != ops[k].prime_gi) continue;
+      if (!one_limb[ch_of[k]] || !one_limb[ch_of[p]]) continue;
       const u32 ca = uf_find(ch_parent, ch_of[k]), cb = uf_find(ch_parent, ch_of[p]);
       if (ca == cb || ch_size[ca] + ch_size[cb] > kMaxSegment) continue;
+      if (ch_size[ca] != (h.cnt[ca] - (ca ? h.cnt[ca - 1] : 0)) || ch_size[cb] != (h.cnt[cb] - (cb ? h.cnt[cb - 1] : 0))) continue;  // pairs only
       ch_parent[cb] = ca;
       ch_size[ca] += ch_size[cb];
       merged = true;
