@@ -89,6 +89,9 @@ SYMBOLS = [
     ("acehip_modup_digits", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_modup_digits_to", C.c_int, [_vp, _vp, _vp, _u32, _vp]),
     ("acehip_key_inner_product", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("acehip_keymac_mod_down2", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    ("acehip_keymac_fusable", C.c_int, [_vp, _u32, _u32]),
+    ("acehip_debug_set_kmac_fuse", C.c_int, [C.c_int]),
     ("acehip_key_inner_product_add", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),

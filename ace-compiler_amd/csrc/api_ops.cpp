@@ -7,9 +7,29 @@
 // re-reads its alpha sources through L2 and the pass becomes VALU-bound.  Measured (MI355X, round 2): key-switch 0.256 ms
 // either way, ResNet-20 1.51 images/s fused vs 1.56 unfused -- so it is OFF unless ACEHIP_CONV_FUSION=1 (bit-exact both ways,
 // tests/test_gpu_parity.py::test_conv_fusion_matches).
+// The base conversion computed by the first pass of the forward NTT while it loads its input (ntt_fast.hip SRC_CONV*): every output limb's
+// workgroups read all n_in source tiles again (through L2), the converted limbs are never written in coefficient form.
+//   ACEHIP_CONV_FUSION=1: wherever it is possible (measured slower on the whole image: the re-reads and the multiply-adds of 12 sources per output)
+//   ACEHIP_CONV_FUSION_UP=n: ModUp conversions with at most n source limbs (the low levels of a network: few sources, K outputs)
+//   ACEHIP_CONV_FUSION_DOWN=n: ModDown conversions with at most n output limbs (K sources each)
+static u32 env_u32(const char* name, u32 dflt) {
+  const char* e = getenv(name);
+  return e ? (u32)strtoul(e, nullptr, 0) : dflt;
+}
 bool conv_fusable(const acehip_ctx* c, u32 n_in) {
   static const bool on = [] { const char* e = getenv("ACEHIP_CONV_FUSION"); return e && *e == '1'; }();
   return on && c->dc.logN == 16 && c->dc.split_bits <= 30 && n_in <= 12 && c->sh_world <= 1;
+}
+static bool conv_fusable_up(const acehip_ctx* c, u32 level) {  // every digit's conversion of a ModUp at `level`
+  static const u32 cap = env_u32("ACEHIP_CONV_FUSION_UP", 0);
+  const u32 n_in = std::min(c->hp.alpha, level);
+  if (conv_fusable(c, c->hp.alpha)) return true;
+  return n_in <= cap && c->dc.logN == 16 && c->dc.split_bits <= 30 && n_in <= 12 && c->sh_world <= 1;
+}
+static bool conv_fusable_down(const acehip_ctx* c, u32 level) {
+  static const u32 cap = env_u32("ACEHIP_CONV_FUSION_DOWN", 0);
+  if (conv_fusable(c, c->hp.K)) return true;
+  return level <= cap && c->dc.logN == 16 && c->dc.split_bits <= 30 && c->hp.K <= 12 && c->sh_world <= 1;
 }
 
 static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, const u64* in1, u32 level, hipStream_t s);
@@ -245,7 +265,7 @@ static int do_mod_down_n(acehip_ctx* c, u64* out0, u64* out1, const u64* in0, co
     }
   }
   // (descriptor nd + 1: the ModDown problem with its K sources at limb positions 0.. of `pc`)
-  const bool conv_in_ntt = conv_fusable(c, hp.K);
+  const bool conv_in_ntt = conv_fusable_down(c, level);
   for (const DevCtx& dc : dcs) {
     if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, QL, pc, PK, plan->d_descs + plan->nd + 1, 0, np, level, s, hp.K, PtrTab8{}, plan->mfma_down);
     if (dc.logN == 16) {
@@ -281,6 +301,105 @@ int acehip_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64
   if (!out0 || !out1 || !in0 || !in1 || out0 == in0 || out1 == in1 || out0 == in1 || out1 == in0 || out0 == out1)
     return fail(ACEHIP_EINVAL, "acehip_mod_down2: outputs must not alias inputs or each other");
   return for_replica_chunks(c, [&] { return do_mod_down_n(c, out0, out1, in0, in1, level, (hipStream_t)s); });
+}
+
+}  // extern "C"
+// Key inner product + Mod_down of both accumulators with the accumulators never stored (kernels.hpp Kmac): the inverse first pass of
+// the P-limbs and the Mod_down tail on the q-limbs form the sums where they would load them.  Per key-switch 4 (level + K) limb
+// transfers less than key inner product kernel + acehip_mod_down2 (2 (level + K) written, 2 (level + K) read back).
+//   ACEHIP_KMAC_FUSE=0: never (callers use the unfused pipelines), 2: also where the transforms would run as narrow passes
+static std::atomic<int>& kmac_fuse_slot() {
+  static std::atomic<int> m{[] { const char* e = getenv("ACEHIP_KMAC_FUSE"); return e ? atoi(e) : 1; }()};
+  return m;
+}
+static int kmac_fuse_mode() { return kmac_fuse_slot().load(std::memory_order_relaxed); }
+bool kmac_fusable(const acehip_ctx* c, u32 level, u32 nd) {
+  const int mode = kmac_fuse_mode();
+  if (mode == 0 || !c->on_device || c->dc.logN != 16 || sharded(c) || nd == 0 || nd > kKmacMaxDigits) return false;
+  if (mode >= 2) return true;
+  const u32 rows_q = 2 * level * c->seln, rows_p = 2 * c->hp.K * c->seln;
+  return rows_q > c->dc.ntt_narrow_max_rows && rows_p > c->dc.ntt_narrow_max_rows;
+}
+int do_keymac_mod_down2(acehip_ctx* c, u64* out0, u64* out1, const Kmac& km, u32 level, hipStream_t s, u64* scratch = nullptr) {
+  const HostParams& hp = c->hp;
+  const KsPlan* plan = get_ks_plan(c, level);
+  if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
+  const size_t N = hp.N, PK = (size_t)hp.K * N, QL = (size_t)level * N, E = QL + PK;
+  dbg_touch(out0, QL);
+  dbg_touch(out1, QL);
+  for (u32 d = 0; d < km.nd; ++d) {
+    dbg_touch(km.ext[d], E);
+    dbg_touch(km.key[d], 2 * (size_t)(hp.L + hp.K) * N);
+  }
+  if (km.own) dbg_touch(km.own, QL);
+  u64* pc = scratch ? scratch : c->ws;  // [2][K][N] p-limbs of both accumulators in the coefficient domain
+  u64* tmp = pc + 2 * PK;               // [2][level][N]
+  const bool conv_in_ntt = conv_fusable_down(c, level);
+  for (const DevCtx& dc : launch_dcs(c)) {
+    NttFuse fi;
+    fi.km = km;
+    fi.km_pos0 = level;             // launch position j = extended position level + j
+    fi.inv_scale = plan->inv_down;  // (P/p_j)^-1 folded into the last inverse stage
+    launch_ntt_fused(dc, pc, 0, 0, hp.K, true, s, 0, 2, PK, 0, fi);
+    if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, QL, pc, PK, plan->d_descs + plan->nd + 1, 0, 2, level, s, hp.K, PtrTab8{}, plan->mfma_down);
+    NttFuse fo;
+    if (conv_in_ntt) {
+      fo.conv = plan->d_descs + plan->nd + 1;
+      fo.conv_step = 0;
+      fo.conv_max_in = hp.K;
+      fo.conv_src = pc;
+      fo.conv_src_stride = PK;
+    }
+    fo.epi = 3;
+    fo.km = km;
+    fo.km_pos0 = 0;
+    fo.out0 = out0;
+    fo.out1 = out1;
+    fo.w = c->pinv;
+    fo.wp = c->pinv_prec;
+    launch_ntt_fused(dc, tmp, level, 0, level, false, s, 0, 2, QL, 0, fo);
+  }
+  stat(ST_KEYMAC, 1, 8ull * E * (3ull * km.nd + 2));
+  stat(ST_MODDOWN, 2, 8ull * 2 * N * (2 * level + hp.K));
+  return post_launch();
+}
+extern "C" {
+int acehip_debug_set_kmac_fuse(int mode) { return kmac_fuse_slot().exchange(mode); }  // tests: the ACEHIP_KMAC_FUSE setting; returns the old one
+int acehip_keymac_fusable(const acehip_ctx* c, uint32_t level, uint32_t n_digits) {
+  return c && level >= 1 && level <= c->hp.L && kmac_fusable(c, level, n_digits) ? 1 : 0;
+}
+int acehip_keymac_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const uint64_t* const* h_ext, const uint64_t* const* h_key,
+                            uint32_t n_digits, uint32_t level, acehip_stream s_) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: bad level");
+  if (!out0 || !out1 || out0 == out1 || !h_ext || !h_key || n_digits == 0 || n_digits > kKmacMaxDigits)
+    return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: bad arguments");
+  const HostParams& hp = c->hp;
+  const size_t N = hp.N, E = (size_t)(level + hp.K) * N, T = hp.L + hp.K;
+  for (u32 d = 0; d < n_digits; ++d)
+    if (!h_ext[d] || !h_key[d]) return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: null digit or key part");
+  hipStream_t s = (hipStream_t)s_;
+  if (kmac_fusable(c, level, n_digits)) {
+    Kmac km;
+    km.nd = n_digits;
+    km.level = level;
+    km.key_T = (u32)T;
+    for (u32 d = 0; d < n_digits; ++d) {
+      km.ext[d] = h_ext[d];
+      km.key[d] = h_key[d];
+    }
+    return for_replica_chunks(c, [&] { return do_keymac_mod_down2(c, out0, out1, km, level, s); });
+  }
+  // unfused: the accumulators in the workspace (behind Mod_down's own scratch), one key inner product launch per digit
+  u64* acc0 = c->ws + 2 * (size_t)hp.K * N + 2 * (size_t)level * N;
+  u64* acc1 = acc0 + E;
+  if ((size_t)(acc1 + E - c->ws) > c->ws_words) return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: workspace too small");
+  return for_replica_chunks(c, [&] {
+    for (const DevCtx& dc : launch_dcs(c))
+      for (u32 d = 0; d < n_digits; ++d) launch_key_mac(dc, acc0, acc1, h_key[d], h_key[d] + T * N, h_ext[d], level, d != 0, s);
+    stat(ST_KEYMAC, 1, 8ull * E * (3ull * n_digits + 2));
+    return do_mod_down_n(c, out0, out1, acc0, acc1, level, s);
+  });
 }
 
 // ModRaise of bootstrapping (Transform_values_from_level0 ckks_bootstrap_context.c:1527-1551): limb 0 of each
@@ -695,11 +814,11 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
     // 2. every digit's base conversion (scaling by (Q_d/q_i)^-1 folded into the inverse NTT) and
     // 3. the NTT of every digit's complement limbs (own digit limbs are skipped): at N = 2^16 one pipeline, the conversion
     //    is computed by the first NTT pass while it loads its input
-    if (conv_fusable(c, hp.alpha)) {
+    if (conv_fusable_up(c, level)) {
       NttFuse fc;
       fc.conv = plan->d_descs;
       fc.conv_step = 1;
-      fc.conv_max_in = hp.alpha;
+      fc.conv_max_in = std::min(hp.alpha, level);
       fc.conv_src = coef;
       fc.conv_src_stride = 0;
       launch_ntt_fused(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha, fc);
@@ -707,6 +826,24 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
       launch_base_conv_batch(dc, ext, E, coef, 0, plan->d_descs, 1, nd, plan->max_nc, s, hp.alpha, PtrTab8{}, plan->mfma_up);
       launch_ntt(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
     }
+  }
+  if (kmac_fusable(c, level, nd)) {
+    // 4 + 5. the key inner product is formed by Mod_down's own passes (the accumulators are never stored); a digit's own limbs are
+    // read from `in`.  Mod_down's scratch (2 K + 2 level limbs) takes the place of the accumulators behind the digits.
+    Kmac km;
+    km.nd = nd;
+    km.alpha = hp.alpha;
+    km.level = level;
+    km.key_T = hp.L + hp.K;
+    km.own = in;
+    for (u32 d = 0; d < nd; ++d) {
+      km.ext[d] = ext + d * E;
+      km.key[d] = key + (size_t)d * 2 * (hp.L + hp.K) * N;
+    }
+    stat(ST_KEYSWITCH, 1, acehip_key_switch_bytes(c, level));
+    return do_keymac_mod_down2(c, out0, out1, km, level, s, acc0);
+  }
+  for (const DevCtx& dc : dcs) {
     // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
     launch_key_mac_fused(dc, acc0, acc1, key, ext, E, in, level, nd, hp.alpha, s);
     // 5. ModDown of both accumulators together (polynomial.c:928-967)
@@ -724,7 +861,7 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
       for (u32 j = 0; j < hp.K; ++j) x.push_back(XItem{acc0 + z * E + (size_t)(level + j) * N, (hp.L + j) % c->sh_world});
     if (int e = shard_exchange(c, x.data(), x.size(), s)) return e;
   }
-  const bool conv_in_ntt = fused && conv_fusable(c, hp.K);
+  const bool conv_in_ntt = fused && conv_fusable_down(c, level);
   for (const DevCtx& dc : dcs) {
     if (!conv_in_ntt) launch_base_conv_batch(dc, tmp, (size_t)level * N, acc0, E, plan->d_descs + nd, 0, 2, level, s, hp.K, PtrTab8{}, plan->mfma_down);
     if (fused) {  // the ModDown tail rides in the last NTT pass, the conversion P -> Q in the first
@@ -1021,11 +1158,11 @@ static int modup_digits_to(acehip_ctx* c, uint64_t* const* h_ext, const uint64_t
   }
   const u32 n_ext_rows = level + hp.K - std::min(hp.alpha, level - hp.alpha * (nd - 1));
   for (const DevCtx& dc : dcs) {
-    if (conv_fusable(c, hp.alpha)) {  // the conversions ride in the first pass of the NTT
+    if (conv_fusable_up(c, level)) {  // the conversions ride in the first pass of the NTT
       NttFuse fc;
       fc.conv = plan->d_descs;
       fc.conv_step = 1;
-      fc.conv_max_in = hp.alpha;
+      fc.conv_max_in = std::min(hp.alpha, level);
       fc.conv_src = coef;
       fc.conv_src_stride = 0;
       for (u32 d = 0; d < nd; ++d) fc.polyz[d] = outz.p[d];

@@ -156,6 +156,22 @@ constexpr u32 kConvMfmaDigits = 9;  // 7-bit digits of a constant below 2^63
 
 enum class EwOp : int { Add = 0, Sub = 1, Mul = 2, MulAdd = 3 };
 
+// Key inner product computed where an NTT pass would load a stored accumulator (Fast_switch_key_ext ckks_evaluator.c:418-460; generated
+// code resnet20_cifar10_pre.onnx.inc:7011-7036): the value of polynomial z at extended limb position pos (prime gi) is
+//   sum_{d < nd} E_d[pos] (*) key[d][z][gi],   E_d[pos] = own + pos*N when own != nullptr and pos < level and pos / alpha == d
+//                                                        (the digit's own limbs read from the key-switch input), else ext[d] + pos*N.
+// The accumulators of a key-switch then never exist in memory: the inverse first pass of Mod_down's P-limbs and the Mod_down tail on the
+// q-limbs form the sums themselves (exact 128-bit sums, one reduction: the canonical residue of the same integer).
+struct Kmac {
+  u32 nd = 0;         // digits; 0: off
+  u32 alpha = 0, level = 0;
+  u32 key_T = 0;      // L + K: polynomial z of key part d starts at key[d] + z*key_T*N, prime gi at + gi*N
+  const u64* own = nullptr;
+  const u64* ext[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const u64* key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+constexpr u32 kKmacMaxDigits = 8;
+
 // Work fused into the first / last pass of an N = 2^16 NTT (ntt_fast.hip), so that the neighbours of a transform
 // in Rescale / ModDown / ModUp / encode need no launch and no pass over memory of their own.
 struct NttFuse {
@@ -197,6 +213,10 @@ struct NttFuse {
   const u64* x1 = nullptr;
   const u64* w = nullptr;
   const u64* wp = nullptr;
+  // inverse, first pass (with km.nd != 0): the input of polynomial z at limb position pos is the key inner product at extended
+  // position km_pos0 + pos;  forward, last pass, epi == 3: the ModDown tail of epi == 2 with x_z replaced by the key inner product
+  Kmac km;
+  u32 km_pos0 = 0;
 };
 // statistics hook (api_core.cpp): `limbs` limb-transforms were just launched (direct calls and the ones inside the pipelines alike)
 void ntt_count(u64 limbs);

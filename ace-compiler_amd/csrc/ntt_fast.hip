@@ -393,9 +393,9 @@ struct StridedArgs {
 // scalar branch at the top): sharing the loads lets the compiler hoist both paths' twiddles above the branch, which
 // costs half of the occupancy.
 // SRC: where x[] comes from: SRC_MEM the limb itself (in place), SRC_MSG the signed message f.msg reduced mod the limb's prime
-// (encode), SRC_CONV8/12 the fast base conversion of up to 8/12 coefficient-domain source limbs (ModUp / ModDown: the
+// (encode), SRC_CONV4/8/12 the fast base conversion of up to 4/8/12 coefficient-domain source limbs (ModUp / ModDown: the
 // converted limbs are never written in coefficient form; 16 sources would spill registers: those take the separate kernel)
-enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV8 = 8, SRC_CONV12 = 12 };
+enum : int { SRC_MEM = 0, SRC_MSG = 1, SRC_CONV4 = 4, SRC_CONV8 = 8, SRC_CONV12 = 12 };
 // canonical input of the forward strided pass, rows 16k+hg of the workgroup's tile (SRC: see above)
 template <int SRC>
 __device__ __forceinline__ void strided_fwd_source(const DevCtx& c, const StridedArgs& a, const DevPrime& P, const NttFuse& f, u32 pos,
@@ -415,12 +415,12 @@ __device__ __forceinline__ void strided_fwd_source(const DevCtx& c, const Stride
       if (v < 0 && r != 0) r = q - r;
       x[k] = f.msg_scale ? mul_mod(r, sc, P) : r;
     }
-  } else if (SRC >= SRC_CONV8) {
+  } else if (SRC >= SRC_CONV4) {
     // x[n] = ( sum_i y_i[n] * hat[i][row] ) mod q: exact 128-bit sum, one reduction (Reduce_rns_base polynomial.c:928-967,
     // Decompose_modup :1302-1320); the pre-factors (Q_d/q_i)^-1 were folded into the inverse NTT that produced y.  Same
     // arithmetic as base_conv_batch16_kernel (keyswitch.hip): halves of split_bits <= 30 bits, four carry-free
     // multiply-add chains per term; the row's constants are wave-uniform (scalar registers).
-    constexpr int NI = SRC >= SRC_CONV8 ? SRC : 1;  // (the branch is dead for the other sources)
+    constexpr int NI = SRC >= SRC_CONV4 ? SRC : 1;  // (the branch is dead for the other sources)
     const ConvDesc& d = f.conv[z * f.conv_step];
     const u32 n_in = d.n_in, jcol = d.col ? d.col[row] : row;
     if (d.out_pos[row] != pos) __builtin_trap();  // the launch must enumerate the limbs like the descriptor does
@@ -684,6 +684,29 @@ __global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_strided_kernel(De
 // CANON_OUT (inverse only): write canonical values instead of lazy [0,lim) (needed when a generic
 // pass follows instead of the strided fast pass).
 // ------------------------------------------------------------------------------------------------
+// ---- key inner product as the source of a contiguous pass (kernels.hpp Kmac).  One workgroup = tile `tile` of polynomial z at extended
+// limb position xpos (prime gi): the value at coefficient tile*4096 + e is sum_d E_d[e] * key_d[z][gi][e] -- exact 128-bit sums of at most 8
+// products below 2^122, reduced once (the canonical residue, whatever order generated code's Hw_modmul / Hw_modadd chains use).  The
+// digit and key base pointers are kernel arguments indexed by the wave-uniform d: scalar loads.
+struct KmacSrc {
+  u32 xpos, gi, z, rep, tile;
+  u64 q, ml, mh;
+};
+__device__ __forceinline__ ulong2 kmac_at(const DevCtx& c, const Kmac& km, const KmacSrc& k, u32 e) {
+  U128 s0{0, 0}, s1{0, 0};
+  const size_t eoff = (size_t)k.xpos * c.N + (size_t)k.tile * 4096 + e;
+  const size_t koff = ((size_t)k.z * km.key_T + k.gi) * c.N + (size_t)k.tile * 4096 + e;
+  const u32 own_d = (km.own != nullptr && k.xpos < km.level) ? k.xpos / km.alpha : 0xffffffffu;
+  for (u32 d = 0; d < km.nd; ++d) {
+    const u64* eb = d == own_d ? km.own : km.ext[d];
+    const ulong2 ev = *reinterpret_cast<const ulong2*>(reb(c, eb, k.rep) + eoff);
+    const ulong2 kv = *reinterpret_cast<const ulong2*>(reb(c, km.key[d], k.rep) + koff);
+    mac128(s0, ev.x, kv.x);
+    mac128(s1, ev.y, kv.y);
+  }
+  return ulong2{reduce128(s0, k.q, k.ml, k.mh), reduce128(s1, k.q, k.ml, k.mh)};
+}
+
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
 // rho = 16*lo4+k on return
 template <bool SMALL, bool TW8>
@@ -717,9 +740,10 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
 
 // inverse rounds: the tile is read from S (coalesced 16-byte loads through LDS), round B first (stages s8+7..s8+4 on the 16
 // contiguous rho = 16h + g'), then round A (stages s8+3..s8 on rho = 16k + g); lazy [0,lim) output unless CANON_OUT
-template <bool SMALL, bool CANON_OUT, bool TW8>
+template <bool SMALL, bool CANON_OUT, bool TW8, bool KM = false>
 __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW,
-                                                const u64* __restrict__ TP, u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
+                                                const u64* __restrict__ TP, u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q,
+                                                const DevCtx* kc = nullptr, const Kmac* km = nullptr, const KmacSrc* ks = nullptr) {
   const BfK bk = bf_consts<SMALL>(q);
   const u32 tid = threadIdx.x;
   u64 x[16];
@@ -728,10 +752,14 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
     const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-    const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
     ulong2 v;
-    v.x = vv.x;
-    v.y = vv.y;
+    if (KM) {  // the tile is the key inner product (canonical residues)
+      v = kmac_at(*kc, *km, *ks, e);
+    } else {
+      const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+      v.x = vv.x;
+      v.y = vv.y;
+    }
     lds[bb * kBlkPitch + cpad(rho)] = v.x;
     lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
   }
@@ -792,8 +820,10 @@ __device__ __forceinline__ void contig_fwd_body_fp(const u64* __restrict__ X, co
 }
 
 // inverse: canonical u64 input from S (coalesced through LDS, as contig_inv_body), output doubles |v| <= 0.51q for the strided FP pass
+template <bool KM = false>
 __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u64* __restrict__ S, const double* __restrict__ TWD, u64* lds,
-                                                   u32 s8, u32 o, u32 b, u32 lo4, u64 q) {
+                                                   u32 s8, u32 o, u32 b, u32 lo4, u64 q, const DevCtx* kc = nullptr, const Kmac* km = nullptr,
+                                                   const KmacSrc* ks = nullptr) {
   const FpK k = fp_consts(q);
   const u32 tid = threadIdx.x;
   double x[16], t0, t1[2], t2[4], t3[8];
@@ -801,7 +831,14 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
 #pragma unroll
   for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
     const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-    const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+    u64x2_t vv;
+    if (KM) {
+      const ulong2 v = kmac_at(*kc, *km, *ks, e);
+      vv.x = v.x;
+      vv.y = v.y;
+    } else {
+      vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+    }
     lds[bb * kBlkPitch + cpad(rho)] = vv.x;
     lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
   }
@@ -855,7 +892,8 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
     __syncthreads();
     const size_t tail_off = (size_t)pos * c.N + (size_t)w.tile * 4096;  // q-limb `pos` of x_z / out_z
-    const u64* __restrict__ xin = FUSE ? reb(c, w.z ? f.x1 : f.x0, w.rep) + tail_off : nullptr;
+    const KmacSrc ks{f.km_pos0 + pos, w.gi, w.z, w.rep, w.tile, q, P.prec128_lo, P.prec128_hi};
+    const u64* __restrict__ xin = (FUSE == 1 || FUSE == 2) ? reb(c, w.z ? f.x1 : f.x0, w.rep) + tail_off : nullptr;
     u64* __restrict__ dst = FUSE ? reb(c, w.z ? f.out1 : f.out0, w.rep) + tail_off : X;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
 #pragma unroll
@@ -872,6 +910,10 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
         const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + e);
         v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
         v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
+      } else if (FUSE == 3) {  // the ModDown tail on the key inner product itself
+        const ulong2 xv = kmac_at(c, f.km, ks, e);
+        v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
+        v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
       }
 #if NTT_EXP & 2
       if (v.x != 0x123456789ull) continue;
@@ -882,6 +924,13 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
       ntst(reinterpret_cast<u64x2_t*>(dst + e), vv);
     }
   } else {
+    if (FUSE == 2) {  // input = the key inner product
+      const KmacSrc ks{f.km_pos0 + pos, w.gi, w.z, w.rep, w.tile, q, P.prec128_lo, P.prec128_hi};
+      if (fp)                       contig_inv_body_fp<true>(X, nullptr, TWD, lds, s8, o, b, lo4, q, &c, &f.km, &ks);
+      else if (q <= kSmallPrimeMax) contig_inv_body<true, CANON_OUT, TW8, true>(X, nullptr, TW, TP, lds, s8, o, b, lo4, q, &c, &f.km, &ks);
+      else                          contig_inv_body<false, CANON_OUT, TW8, true>(X, nullptr, TW, TP, lds, s8, o, b, lo4, q, &c, &f.km, &ks);
+      return;
+    }
     const u64* __restrict__ S =
         FUSE ? reb(c, w.z ? f.src1 : f.src0, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
     if (fp)                       contig_inv_body_fp(X, S, TWD, lds, s8, o, b, lo4, q);
@@ -1218,7 +1267,7 @@ __global__ __launch_bounds__(256) void ntt4_contig_kernel(DevCtx c, u64* __restr
 // small launches take the narrow passes: at most c.ntt_narrow_max_rows limb rows (limbs x polynomials)
 static bool launch_ntt_narrow(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                               u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f) {
-  if (n_limbs * n_polys * c.nrep > c.ntt_narrow_max_rows || f.conv != nullptr) return false;
+  if (n_limbs * n_polys * c.nrep > c.ntt_narrow_max_rows || f.conv != nullptr || f.km.nd != 0) return false;  // (the key inner product rides in the wide passes only)
   dim3 block(256), grid(64 * n_limbs * n_polys * c.nrep);
 #define ACEHIP_N4_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
@@ -1258,6 +1307,7 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
 #define ACEHIP_NTT_ARGS grid, block, lds_pad, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
   if (!inverse) {
     if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
+    else if (f.conv && f.conv_max_in <= 4)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV4>), ACEHIP_NTT_ARGS);
     else if (f.conv && f.conv_max_in <= 8)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV8>), ACEHIP_NTT_ARGS);
     else if (f.conv)               hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV12>), ACEHIP_NTT_ARGS);
     else                           hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MEM>), ACEHIP_NTT_ARGS);
@@ -1265,19 +1315,23 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
     if (tw8) {
       if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, true, true>), ACEHIP_NTT_ARGS);
       else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, true, true>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 3) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 3, true, true>), ACEHIP_NTT_ARGS);
       else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, true, true>), ACEHIP_NTT_ARGS);
     } else {
       if (f.epi == 1)      hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 1, false, true>), ACEHIP_NTT_ARGS);
       else if (f.epi == 2) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 2, false, true>), ACEHIP_NTT_ARGS);
+      else if (f.epi == 3) hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 3, false, true>), ACEHIP_NTT_ARGS);
       else                 hipLaunchKernelGGL((ntt8_contig_kernel<false, true, 0, false, true>), ACEHIP_NTT_ARGS);
     }
   } else {
     if (tw8) {
-      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, true, true>), ACEHIP_NTT_ARGS);
-      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, true, true>), ACEHIP_NTT_ARGS);
+      if (f.km.nd)     hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 2, true, true>), ACEHIP_NTT_ARGS);
+      else if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, true, true>), ACEHIP_NTT_ARGS);
+      else             hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, true, true>), ACEHIP_NTT_ARGS);
     } else {
-      if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, false, true>), ACEHIP_NTT_ARGS);
-      else        hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, false, true>), ACEHIP_NTT_ARGS);
+      if (f.km.nd)     hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 2, false, true>), ACEHIP_NTT_ARGS);
+      else if (f.src0) hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 1, false, true>), ACEHIP_NTT_ARGS);
+      else             hipLaunchKernelGGL((ntt8_contig_kernel<true, false, 0, false, true>), ACEHIP_NTT_ARGS);
     }
     hipLaunchKernelGGL((ntt8_strided_kernel<true, SRC_MEM>), ACEHIP_NTT_ARGS);
   }

@@ -43,6 +43,7 @@ void hw_flush_site(const char* file, int line);
 struct Touch {
   const void* p;
   size_t words;
+  bool ro = false;  // the launch only READS the range: queued ops that read it too need not run first, raised digits in it stay valid
 };
 void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n);
 // ACEHIP_POISON=1 (debug): aborts when the launch issued since hw_flush_touching touched pool memory outside `touch`

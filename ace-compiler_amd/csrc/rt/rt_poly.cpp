@@ -425,8 +425,29 @@ struct ModupCache {
 };
 thread_local ModupCache g_muc;
 }  // namespace
+// ACEHIP_PROFILE: calls per level of the three pipelines generated code drives (which levels carry the transforms)
+namespace {
+struct LevelHist {
+  size_t modup[72] = {}, modup_reuse[72] = {}, mod_down2[72] = {}, mod_down1[72] = {}, rescale2[72] = {}, rescale1[72] = {};
+};
+thread_local LevelHist g_lvl;
+}
+// Mod_down pairs whose key inner product was still queued (keymac_pair_from_queue below)
+struct KmacStats {
+  size_t tried = 0, fused = 0, no_zero = 0, shape = 0, other = 0;
+};
+thread_local KmacStats g_kmac_stats;
 static void muc_stats_print() {
+  {
+    const KmacStats& k = g_kmac_stats;
+    printf("[ACEHIP] Mod_down pairs behind a queued key inner product: %zu examined, %zu ran without storing the accumulators; not taken: %zu zero fill "
+           "already executed, %zu irregular shape, %zu other\n", k.tried, k.fused, k.no_zero, k.shape, k.other);
+  }
   printf("[ACEHIP] all-digit ModUp: %zu launched, %zu more rotations served from digits raised before\n", g_muc.n_raise, g_muc.n_reuse);
+  for (u32 l = 0; l < 72; ++l)
+    if (g_lvl.modup[l] + g_lvl.modup_reuse[l] + g_lvl.mod_down2[l] + g_lvl.mod_down1[l] + g_lvl.rescale2[l] + g_lvl.rescale1[l])
+      printf("[ACEHIP] level %2u: ModUp %zu (+%zu reused) Mod_down pairs %zu singles %zu Rescale pairs %zu singles %zu\n", l, g_lvl.modup[l],
+             g_lvl.modup_reuse[l], g_lvl.mod_down2[l], g_lvl.mod_down1[l], g_lvl.rescale2[l], g_lvl.rescale1[l]);
 }
 namespace {
 void queue_submit(const Touch* touch = nullptr, size_t n_touch = 0, bool defer = false);
@@ -437,6 +458,7 @@ void pending_flush() {
   if (!g_pend.kind) return;
   const PendingPair p = g_pend;
   g_pend.kind = 0;
+  (p.kind == 1 ? g_lvl.mod_down1 : g_lvl.rescale1)[p.level < 72 ? p.level : 71]++;
   cancel_fills(p.out, p.kind == 1 ? p.level : p.level - 1);
   const size_t N = ctx().N;
   g_muc.written(p.out, (size_t)(p.kind == 1 ? p.level : p.level - 1) * N);
@@ -666,13 +688,19 @@ void split_for_launch(const Touch* touch, size_t n_touch, std::vector<acehip_hw_
       t_hi = std::max(t_hi, (const u64*)touch[i].p + touch[i].words);
     }
   auto hits_launch = [&](const u64* p) { return p + N > t_lo && p < t_hi && touches(touch, n_touch, p, N); };
+  auto hits_launch_w = [&](const u64* p) {  // ... a range the launch may WRITE (a queued READ of a range the launch only reads is no conflict)
+    if (!(p + N > t_lo && p < t_hi)) return false;
+    for (size_t i = 0; i < n_touch; ++i)
+      if (touch[i].p && !touch[i].ro && p + N > (const u64*)touch[i].p && p < (const u64*)touch[i].p + touch[i].words) return true;
+    return false;
+  };
   auto near_s = [&](const u64* p) { return p >= s_lo && p < s_hi; };
   for (size_t k = n; k-- > 0;) {
     const acehip_hw_op& o = g_hwq[k];
     const u64* a = o.op != ACEHIP_HW_ZERO ? o.a : nullptr;
     const u64* b = op_has_b(o.op) ? (const u64*)o.b : nullptr;
-    // against the launch: every declared range counts as read AND written
-    bool hit = hits_launch(o.res) || (a && hits_launch(a)) || (b && hits_launch(b));
+    // against the launch: every declared range counts as read AND written, unless it is marked read-only
+    bool hit = hits_launch(o.res) || (a && hits_launch_w(a)) || (b && hits_launch_w(b));
     // against the ops behind it that are submitted
     if (!hit && n_sub)
       hit = (near_s(o.res) && (s_read.has(o.res) || s_write.has(o.res))) || (a && near_s(a) && s_write.has(a)) || (b && near_s(b) && s_write.has(b));
@@ -936,7 +964,8 @@ void hw_flush_touching(const char* file, int line, const Touch* touch, size_t n)
   note_site(file, line);
   if (poison_on()) (void)acehip_debug_touches(1, nullptr, nullptr, 0);  // start a fresh log for the launch that follows
   pending_flush();
-  for (size_t i = 0; i < n; ++i) g_muc.written((const u64*)touch[i].p, touch[i].words);  // (any operand may be an output)
+  for (size_t i = 0; i < n; ++i)
+    if (!touch[i].ro) g_muc.written((const u64*)touch[i].p, touch[i].words);  // (any operand not marked read-only may be an output)
   queue_submit(touch, n, true);
 }
 void hw_cancel_fills(const u64* out, size_t n_limbs) { cancel_fills(out, n_limbs); }
@@ -1441,9 +1470,11 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
     m.lent = nullptr;
     for (u32 d = 0; d < 8; ++d) m.holds[d] = d < nd ? (int)d : -1;
     m.n_raise++;
+    g_lvl.modup[level < 72 ? level : 71]++;
     slot = 0;
   } else if (q_part_idx == 0) {
     m.n_reuse++;
+    g_lvl.modup_reuse[level < 72 ? level : 71]++;
   }
   // hand the digit over by exchanging blocks: res keeps its size (asserted above: level + K limbs), the cache gets res's
   // old block, which queued ops may still read -- it is rewritten only by the next all-digit ModUp, a direct launch that
@@ -1465,6 +1496,132 @@ POLY Decomp_modup(POLY res, POLY poly, uint32_t q_part_idx) {
   res->_is_ntt = true;
   return res;
 }
+// ---- key inner product + Mod_down pair without the accumulators (round 5) ----
+// Generated code forms the two accumulators of a key-switch limb by limb (resnet20_cifar10_pre.onnx.inc:7011-7034: per digit and
+// limb  tmp = key0 * ext; swk_c0 += tmp; tmp = key1 * ext; swk_c1 += tmp), then calls Mod_down on both (:7035-7036) and frees them.
+// When the queue still holds exactly that for the pair's inputs -- every limb of both accumulators: a zero fill, then one
+// `acc += tmp` per digit whose tmp is the product of limb `pos` of ONE raised digit block and limb gi(pos) of ONE key part, nothing
+// else written to those limbs, no operand rewritten afterwards -- the pair runs as acehip_keymac_mod_down2 on the digits and key
+// parts themselves: the Mod_down passes form the sums where they would load them and the accumulators are never stored (4 (level + K)
+// limb transfers per key-switch less).  The queued products and additions are NOT taken out: the launch does not touch what they
+// touch (the digits are declared read-only), so they simply stay queued (split_for_launch) and die with the accumulators when
+// generated code frees them a few calls later (the library drops ops whose results lie in freed blocks); a program that reads
+// the accumulators afterwards instead finds the ops still queued and gets them executed: nothing changes for it but the order.
+static inline u32 limb_gi_of(u32 pos, u32 level, u32 L) { return pos < level ? pos : L + (pos - level); }
+namespace {
+bool keymac_pair_from_queue(u64* out0, u64* out1, const u64* acc0, const u64* acc1, u32 level) {
+  static const bool on = getenv("ACEHIP_KMAC_SHIM") == nullptr || atoi(getenv("ACEHIP_KMAC_SHIM")) != 0;
+  static const bool keep_on = getenv("ACEHIP_HW_KEEP") == nullptr || atoi(getenv("ACEHIP_HW_KEEP")) != 0;
+  Context& c = ctx();
+  if (!on || !keep_on || c.shard_world > 1 || g_hwq.empty()) return false;
+  const u32 nd = acehip_num_decomp(c.hip, level);
+  if (!acehip_keymac_fusable(c.hip, level, nd)) return false;
+  g_kmac_stats.tried++;
+  const size_t N = c.N;
+  const u32 E = level + c.K, T = c.L + c.K;
+  const u64* base[2] = {acc0, acc1};
+  struct Term {
+    const u64 *a, *b;
+    u32 gi;
+  };
+  static thread_local std::vector<Term> terms;          // [z][pos][8]
+  static thread_local std::vector<unsigned char> cnt;   // [z][pos]: 0xff = not zero-filled yet, else the number of terms
+  terms.assign((size_t)2 * E * 8, Term{nullptr, nullptr, 0});
+  cnt.assign((size_t)2 * E, 0xff);
+  // scratch limb -> the product it holds now (generated code funnels every product through ONE limb; a handful of entries, oldest dropped)
+  struct Pending {
+    const u64* tmp;
+    Term t;
+  };
+  Pending pending[8];
+  u32 n_pending = 0;
+  auto pending_drop = [&](u32 i) {
+    for (u32 j = i + 1; j < n_pending; ++j) pending[j - 1] = pending[j];
+    --n_pending;
+  };
+  static thread_local PtrSet used;  // limbs that recorded products read
+  used.reset(4 * (size_t)E * 8 + 64);
+  auto slot_of = [&](const u64* p, u32& z, u32& pos) {
+    for (u32 zz = 0; zz < 2; ++zz)
+      if (p >= base[zz] && p < base[zz] + (size_t)E * N) {
+        const size_t off = (size_t)(p - base[zz]);
+        if (off % N) return -1;
+        z = zz;
+        pos = (u32)(off / N);
+        return 1;
+      }
+    return 0;
+  };
+  for (const acehip_hw_op& o : g_hwq) {
+    u32 z = 0, pos = 0;
+    const int hit = slot_of(o.res, z, pos);
+    if (hit < 0) return ++g_kmac_stats.other, false;
+    if (hit == 0) {
+      if (used.has(o.res)) return ++g_kmac_stats.other, false;  // an operand of a recorded product is rewritten later
+      for (u32 i = n_pending; i-- > 0;)  // the limb gets a new value: products that read it or lie in it are history
+        if (pending[i].tmp == o.res || pending[i].t.a == o.res || pending[i].t.b == o.res) pending_drop(i);
+      if (o.op == ACEHIP_HW_MUL) {
+        if (n_pending == 8) pending_drop(0);
+        pending[n_pending++] = Pending{o.res, Term{o.a, (const u64*)o.b, o.prime_gi}};
+      }
+      continue;
+    }
+    unsigned char& n = cnt[(size_t)z * E + pos];
+    if (o.op == ACEHIP_HW_ZERO) {
+      if (n != 0xff && n != 0) return ++g_kmac_stats.other, false;
+      n = 0;
+      continue;
+    }
+    if (o.op != ACEHIP_HW_ADD || o.a != o.res) return ++g_kmac_stats.other, false;
+    if (n == 0xff) return ++g_kmac_stats.no_zero, false;  // the fill ran earlier: what the limb holds is not in the queue
+    u32 pi = n_pending;
+    for (u32 i = 0; i < n_pending; ++i)
+      if (pending[i].tmp == (const u64*)o.b) pi = i;
+    const u32 gi = limb_gi_of(pos, level, c.L);
+    if (pi == n_pending || n >= 8 || o.prime_gi != gi || pending[pi].t.gi != gi) return ++g_kmac_stats.other, false;
+    terms[((size_t)z * E + pos) * 8 + n++] = pending[pi].t;
+    used.insert(pending[pi].t.a);
+    used.insert(pending[pi].t.b);
+  }
+  for (size_t i = 0; i < (size_t)2 * E; ++i)
+    if (cnt[i] != nd) return ++(cnt[i] == 0xff ? g_kmac_stats.no_zero : g_kmac_stats.shape), false;
+  // the regular shape: term d of limb pos = (digit block d) + pos*N times (key part d)[z] + gi(pos)*N, in either operand order
+  const u64 *ext[8], *key[8];
+  for (u32 d = 0; d < nd; ++d) {
+    bool ok = false;
+    for (int swap = 0; swap < 2 && !ok; ++swap) {
+      const Term t0 = terms[d];
+      const u64* e0 = swap ? t0.a : t0.b;
+      const u64* k0 = swap ? t0.b : t0.a;
+      ok = true;
+      for (u32 z = 0; z < 2 && ok; ++z)
+        for (u32 pos = 0; pos < E && ok; ++pos) {
+          const Term t = terms[((size_t)z * E + pos) * 8 + d];
+          const u64* e = swap ? t.a : t.b;
+          const u64* k = swap ? t.b : t.a;
+          ok = e == e0 + (size_t)pos * N && k == k0 + ((size_t)z * T + limb_gi_of(pos, level, c.L)) * N;
+        }
+      if (ok) {
+        ext[d] = e0;
+        key[d] = k0 - (size_t)limb_gi_of(0, level, c.L) * N;
+      }
+    }
+    if (!ok) return ++g_kmac_stats.shape, false;
+  }
+  // the outputs must be strangers to everything the sums read
+  for (u32 d = 0; d < nd; ++d)
+    for (u64* o : {out0, out1})
+      if (o + (size_t)level * N > ext[d] && o < ext[d] + (size_t)E * N) return ++g_kmac_stats.other, false;
+  cancel_fills(out0, level);
+  cancel_fills(out1, level);
+  const size_t EW = (size_t)E * N;
+  auto dig = [&](u32 d) { return Touch{d < nd ? ext[d] : nullptr, d < nd ? EW : 0, true}; };
+  HIPCHK_T(acehip_keymac_mod_down2(c.hip, out0, out1, ext, key, nd, level, nullptr), {out0, (size_t)level * N}, {out1, (size_t)level * N}, dig(0),
+           dig(1), dig(2), dig(3), dig(4), dig(5), dig(6), dig(7));
+  g_kmac_stats.fused++;
+  return true;
+}
+}  // namespace
 POLY Mod_down(POLY res, POLY poly) {
   RtmScope rtm(RTM_MOD_DOWN);
   Context& c = ctx();
@@ -1476,6 +1633,11 @@ POLY Mod_down(POLY res, POLY poly) {
   if (g_pend.kind == 1 && g_pend.level == level && g_pend.out != out && g_pend.in != in && g_pend.out != in && g_pend.in != out) {
     const PendingPair p = g_pend;
     g_pend.kind = 0;
+    g_lvl.mod_down2[level < 72 ? level : 71]++;
+    if (keymac_pair_from_queue(p.out, out, p.in, in, level)) {
+      res->_is_ntt = poly->_is_ntt;
+      return res;
+    }
     cancel_fills(p.out, level);
     cancel_fills(out, level);
     // (ACEHIP_POISON_SELFTEST=1 leaves one input out of the list on purpose: the check of ACEHIP_POISON must abort here -- tests only)
@@ -1512,6 +1674,7 @@ POLY Rescale(POLY res, POLY poly) {
       g_pend.kind = 0;
       cancel_fills(p.out, level - 1);
       cancel_fills(out, level - 1);
+      g_lvl.rescale2[level < 72 ? level : 71]++;
       HIPCHK_T(acehip_rescale2(c.hip, p.out, out, p.in, in, level, nullptr), {p.out, (size_t)(level - 1) * c.N},
                {out, (size_t)(level - 1) * c.N}, {p.in, (size_t)level * c.N}, {in, (size_t)level * c.N});
     } else {

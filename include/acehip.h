@@ -288,6 +288,18 @@ int acehip_modup_digits(acehip_ctx* ctx, uint64_t* d_ext, const uint64_t* d_in, 
  * (level + K) limbs.  (The rt_ant shim swaps these blocks into the caller's polynomials instead of copying.) */
 int acehip_modup_digits_to(acehip_ctx* ctx, uint64_t* const* h_ext, const uint64_t* d_in, uint32_t level, acehip_stream stream);
 int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext, uint32_t level, acehip_stream stream);
+/* Fast_switch_key_ext followed by Mod_down of both accumulators (Fast_switch_key ckks_evaluator.c:391-460 from its inner product
+ * on; generated code resnet20_cifar10_pre.onnx.inc:7011-7036 + the Mod_down pair behind it): d_out{0,1} = Mod_down( sum_d key{0,1}[d]
+ * (*) ext[d] ), `level` limbs each.  h_ext, h_key: HOST arrays of n_digits (<= 8) device pointers -- raised digit d (level + K limbs,
+ * NTT domain) and key part d ([2][L+K][N], as acehip_key_inner_product's d_key + d*2*(L+K)*N).  Results are those of
+ * acehip_key_inner_product + acehip_mod_down2; at N = 2^16 the accumulators are never stored (the Mod_down passes form the sums where
+ * they would load them).  acehip_keymac_fusable: 1 when that form will be used for (level, n_digits) under the current replica selection. */
+int acehip_keymac_mod_down2(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* const* h_ext, const uint64_t* const* h_key,
+                            uint32_t n_digits, uint32_t level, acehip_stream stream);
+int acehip_keymac_fusable(const acehip_ctx* ctx, uint32_t level, uint32_t n_digits);
+/* test hook: the ACEHIP_KMAC_FUSE setting of this process (0 never, 1 where the transforms run as wide passes anyway, 2 always);
+ * returns the previous one */
+int acehip_debug_set_kmac_fuse(int mode);
 /* Fast_rotate_ext (ckks_evaluator.c:539-575) adds P * c0 to the first accumulator before the automorphism: the same inner
  * product with d_acc0[i] += d_add0[i] * h_scalars[i] mod q_i on the q-limbs i < level (h_scalars: host array of `level`
  * residues, P mod q_i there), in the same pass. */

@@ -277,3 +277,45 @@ def test_ckks_level_provider_programs(name):
         pytest.fail("workloads/_gen/examples/egseal_* not built (needs /root/reference: make -C workloads provider) -- build outputs of the dev container that must travel with the snapshot")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SUCCESS!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mod_down_pair_on_a_queued_key_inner_product(tmp_path):
+    """tests/c/kmac_pair.c: generated-style rotations at N = 2^16 whose Mod_down pair runs on the raised digits and key parts themselves while the
+    products and additions that would have filled the accumulators stay queued (rt_poly.cpp keymac_pair_from_queue; the accumulators are never
+    stored): plain rotations, accumulators read afterwards, a digit rewritten behind the sums, fills already executed, a preloaded accumulator,
+    an operand rewritten between a product and its addition.  Correct against the clear computation; bit-identical slot by slot with the
+    shortcut off (ACEHIP_KMAC_SHIM=0), with the stored-accumulator kernels (ACEHIP_KMAC_FUSE=0), without kept ops, under ACEHIP_POISON=1 and
+    with three images per launch; the shortcut is taken exactly where the queue proves it right."""
+    import ace_compiler_amd  # noqa: F401
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    bmod.build_rt()
+    exe = str(tmp_path / "kmac_pair")
+    inc = os.path.join(ROOT, "include")
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c", "kmac_pair.c"), "-I", inc, "-I", os.path.join(inc, "rt_ant"),
+           "-L", bmod.LIBDIR, "-lFHErt_ant", "-lFHErt_common", "-lm", "-Wl,-rpath," + bmod.LIBDIR, "-o", exe]
+    subprocess.check_call(cmd)
+    outs, stats = {}, {}
+    for tag, extra in (("shim", {"ACEHIP_KMAC_FUSE": "2"}), ("off", {"ACEHIP_KMAC_FUSE": "2", "ACEHIP_KMAC_SHIM": "0"}),
+                       ("stored", {"ACEHIP_KMAC_FUSE": "0"}), ("keep_off", {"ACEHIP_KMAC_FUSE": "2", "ACEHIP_HW_KEEP": "0"}),
+                       ("poison", {"ACEHIP_KMAC_FUSE": "2", "ACEHIP_POISON": "1"}), ("batch3", {"ACEHIP_BATCH": "3"})):
+        # (ACEHIP_HW_KEEP_RUN: no periodic full hand-over, which would execute some accumulator fills early and make the counts below
+        #  depend on where in the program it falls)
+        env = dict(os.environ, ACEHIP_SEED="77", ACEHIP_PROFILE="1", ACEHIP_HW_KEEP_RUN="1000", **extra)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "SUCESS!" in r.stdout, tag + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith("slot ")]
+        assert len(outs[tag]) == 60
+        line = [ln for ln in r.stdout.splitlines() if "Mod_down pairs behind a queued key inner product" in ln]
+        assert line, r.stdout[-1500:]
+        stats[tag] = [int(t) for t in line[0].replace(",", " ").replace(";", " ").replace(":", " ").split() if t.isdigit()]
+    assert outs["shim"] == outs["off"] == outs["stored"] == outs["keep_off"] == outs["poison"] == outs["batch3"]
+    # 8 pairs.  The three plain rotations and the one whose accumulators are read afterwards can take the shortcut; one finds its fills executed
+    # (Acehip_rt_sync), three find a queue that does not prove the sums (digit rewritten, accumulator preloaded, operand rewritten before
+    # the addition).  A full hand-over forced by the pool's bound on pinned blocks may execute further fills early: such a pair counts as
+    # "fill already executed" whatever else is wrong with it, so only the totals are fixed.
+    for tag in ("shim", "poison", "batch3"):
+        tried, fused, no_zero, shape, other = stats[tag]
+        assert tried == 8 and fused + no_zero + shape + other == 8 and 3 <= fused <= 4 and no_zero >= 1 and shape == 0 and other >= 2, stats
+    assert stats["off"][1] == 0 and stats["stored"][1] == 0 and stats["keep_off"][1] == 0, stats

@@ -348,3 +348,65 @@ def test_reference_polynomial_kats_on_the_gpu():
     finally:
         rt.close()
         o.close()
+
+
+def test_keymac_mod_down2_matches_inner_product_then_mod_down(env):
+    """acehip_keymac_mod_down2 = Fast_switch_key_ext (ckks_evaluator.c:418-460) + Reduce_rns_base of both accumulators (polynomial.c:928-967),
+    with and without the form that never stores the accumulators (ACEHIP_KMAC_FUSE 2 / 0; at N = 2^16 the sums are formed inside the first
+    inverse pass of the P-limbs and inside the Mod_down tail).  The digits are separate blocks, as the rt_ant shim hands them over.  Oracle:
+    the generated loops' Hw_modmul / Hw_modadd chains, then Mod_down."""
+    o, rt, level = env
+    N, K, T = o.N, o.K, o.L + o.K
+    nd = o.num_decomp(level)
+    E = level + K
+    key = o.make_key(900)
+    ext = [o.uniform(E, level, 910 + d) for d in range(nd)]
+    gis = _gis(o, level, E)
+    e0 = np.zeros((E, N), dtype=np.uint64)
+    e1 = np.zeros((E, N), dtype=np.uint64)
+    for d in range(nd):
+        k0 = np.stack([key[d, 0, gi] for gi in gis])
+        k1 = np.stack([key[d, 1, gi] for gi in gis])
+        e0 = o.hw_modadd(e0, o.hw_modmul(k0, ext[d], gis), gis)
+        e1 = o.hw_modadd(e1, o.hw_modmul(k1, ext[d], gis), gis)
+    want0, want1 = o.mod_down(e0, level), o.mod_down(e1, level)
+    dk = rt.to_device(key)
+    pad = rt.buf(3 * N)  # (keeps the digit blocks apart: no common stride)
+    de = [rt.to_device(x) for x in ext]
+    r0, r1 = rt.buf(level * N), rt.buf(level * N)
+    h_ext = (C.c_void_p * nd)(*[d.ptr for d in de])
+    h_key = (C.c_void_p * nd)(*[dk.at(d * 2 * T * N) for d in range(nd)])
+    old = rt.lib.acehip_debug_set_kmac_fuse(1)
+    try:
+        for mode in (0, 2, 1):
+            rt.lib.acehip_debug_set_kmac_fuse(mode)
+            assert rt.lib.acehip_keymac_fusable(rt.h, level, nd) == (1 if (mode == 2 and N == 65536) else 0)  # (one image: narrow passes)
+            r0.upload(np.zeros(level * N, dtype=np.uint64))
+            r1.upload(np.zeros(level * N, dtype=np.uint64))
+            rt.check(rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, nd, level, None))
+            assert np.array_equal(r0.download((level, N)), want0), mode
+            assert np.array_equal(r1.download((level, N)), want1), mode
+    finally:
+        rt.lib.acehip_debug_set_kmac_fuse(old)
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r0.ptr, h_ext, h_key, nd, level, None) < 0
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, 0, level, None) < 0
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, nd, o.L + 1, None) < 0
+    for d in [dk, pad, r0, r1] + de:
+        d.free()
+
+
+def test_key_switch_with_the_inner_product_inside_mod_down(env):
+    """acehip_key_switch (Fast_switch_key ckks_evaluator.c:391-460) gives the oracle's result whether or not the accumulators are stored
+    (ACEHIP_KMAC_FUSE 0 / 2): own-digit limbs come from the input polynomial, the others from the raised digits."""
+    o, rt, level = env
+    a = o.uniform(level, level, 930)
+    key = o.make_key(940)
+    w0, w1 = o.key_switch(a, key, level)
+    old = rt.lib.acehip_debug_set_kmac_fuse(1)
+    try:
+        for mode in (0, 2):
+            rt.lib.acehip_debug_set_kmac_fuse(mode)
+            g0, g1 = rt.key_switch(a, key, level)
+            assert np.array_equal(g0, w0) and np.array_equal(g1, w1), mode
+    finally:
+        rt.lib.acehip_debug_set_kmac_fuse(old)
