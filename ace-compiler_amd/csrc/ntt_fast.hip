@@ -41,7 +41,9 @@ struct Tw {
 #ifndef NTT_EXP
 #define NTT_EXP 0  // timing experiments only (results are wrong): 1 no butterflies, 2 no data loads/stores, 4 no twiddle loads,
                    // 8 no strided pass at all (what a one-pass transform would save), 16 the forward contiguous pass does not load its
-                   // input (what reading the first pass' output out of the XCD's L2 could save at most)
+                   // input (what reading the first pass' output out of the XCD's L2 could save at most), 32 every per-lane twiddle
+                   // load hits the same few KiB (what the twiddle stream costs beyond its instructions), 64 the same for the key parts of the
+                   // key inner product formed inside a pass (kmac_tile)
 #endif
 // SMALL: the companion is used as floor(w*2^63/q) = floor(w*2^64/q) >> 1 (see shoup5_add)
 template <bool SMALL>
@@ -49,7 +51,11 @@ __device__ __forceinline__ Tw ldtw(const ulong2* __restrict__ t, u32 idx) {
 #if NTT_EXP & 4
   return Tw{(u64)idx * 0x9E3779B97F4A7C15ull, ((u64)idx * 0xC2B2AE3D27D4EB4Full + threadIdx.x) >> 1};
 #else
+#if NTT_EXP & 32
+  const ulong2 v = t[idx & 255u];  // timing experiment (results are wrong): the twiddle stream always hits the same 4 KiB
+#else
   const ulong2 v = t[idx];
+#endif
   return Tw{v.x, SMALL ? v.y >> 1 : v.y};
 #endif
 }
@@ -237,13 +243,18 @@ struct Tp15 {
   u64 p0, p1[2], p2[4], p3[8];
 };
 __device__ __forceinline__ void load_tp(const u64* __restrict__ TP, u32 sbase, u32 prefix, Tp15& t) {
-  t.p0 = TP[(1u << sbase) + prefix];
+#if NTT_EXP & 32
+#define ACEHIP_TPIDX(i) ((i) & 255u)
+#else
+#define ACEHIP_TPIDX(i) (i)
+#endif
+  t.p0 = TP[ACEHIP_TPIDX((1u << sbase) + prefix)];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) t.p1[i] = TP[(2u << sbase) + (prefix << 1) + i];
+  for (int i = 0; i < 2; ++i) t.p1[i] = TP[ACEHIP_TPIDX((2u << sbase) + (prefix << 1) + i)];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t.p2[i] = TP[(4u << sbase) + (prefix << 2) + i];
+  for (int i = 0; i < 4; ++i) t.p2[i] = TP[ACEHIP_TPIDX((4u << sbase) + (prefix << 2) + i)];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t.p3[i] = TP[(8u << sbase) + (prefix << 3) + i];
+  for (int i = 0; i < 8; ++i) t.p3[i] = TP[ACEHIP_TPIDX((8u << sbase) + (prefix << 3) + i)];
 }
 template <bool SMALL>
 __device__ __forceinline__ Tw tw_of(u64 p, u64 q) {
@@ -692,6 +703,7 @@ struct KmacSrc {
   u32 xpos, gi, z, rep, tile;
   u64 q, ml, mh;
 };
+// generic form (any number of digits): one coefficient pair, digits one after the other
 __device__ __forceinline__ ulong2 kmac_at(const DevCtx& c, const Kmac& km, const KmacSrc& k, u32 e) {
   U128 s0{0, 0}, s1{0, 0};
   const size_t eoff = (size_t)k.xpos * c.N + (size_t)k.tile * 4096 + e;
@@ -705,6 +717,69 @@ __device__ __forceinline__ ulong2 kmac_at(const DevCtx& c, const Kmac& km, const
     mac128(s1, ev.y, kv.y);
   }
   return ulong2{reduce128(s0, k.q, k.ml, k.mh), reduce128(s1, k.q, k.ml, k.mh)};
+}
+// The workgroup's 8 coefficient pairs per lane (e = 2*tid + 512*i) for ND digits known at compile time: the 2*ND*CH loads of CH pairs
+// are issued together before any of them is used (the generic loop above waits for every pair of loads in turn: eight or more memory
+// latencies one after the other, which is what the pass then costs next to the kernels of other image streams).  sink(i, value).
+template <int ND>
+struct KmacPtrs {
+  const u64* e[ND];
+  const u64* k[ND];
+};
+template <int ND>
+__device__ __forceinline__ KmacPtrs<ND> kmac_ptrs(const DevCtx& c, const Kmac& km, const KmacSrc& k) {
+  KmacPtrs<ND> p;
+  const size_t eoff = (size_t)k.xpos * c.N + (size_t)k.tile * 4096;
+  const size_t koff = ((size_t)k.z * km.key_T + k.gi) * c.N + (size_t)k.tile * 4096;
+  const u32 own_d = (km.own != nullptr && k.xpos < km.level) ? k.xpos / km.alpha : 0xffffffffu;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    p.e[d] = reb(c, (u32)d == own_d ? km.own : km.ext[d], k.rep) + eoff;
+    p.k[d] = reb(c, km.key[d], k.rep) + koff;
+  }
+  return p;
+}
+template <int ND, class Sink>
+__device__ __forceinline__ void kmac_tile(const DevCtx& c, const Kmac& km, const KmacSrc& k, u32 tid, Sink sink) {
+  constexpr int CH = ND == 1 ? 8 : (ND == 2 ? 4 : 2);  // 64 (48 for three digits) registers of loads in flight
+  const KmacPtrs<ND> p = kmac_ptrs<ND>(c, km, k);
+#pragma unroll
+  for (int i0 = 0; i0 < 8; i0 += CH) {
+    ulong2 ev[CH][ND], kv[CH][ND];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        const u32 e = 2 * tid + 512 * (u32)(i0 + i);
+        ev[i][d] = *reinterpret_cast<const ulong2*>(p.e[d] + e);
+#if NTT_EXP & 64  // timing experiment (results are wrong): every key load of the limb hits the same 4 KiB -- what the key stream costs a pass
+        kv[i][d] = *reinterpret_cast<const ulong2*>(p.k[d] - (size_t)k.tile * 4096 + (e & 510u));
+#else
+        kv[i][d] = *reinterpret_cast<const ulong2*>(p.k[d] + e);
+#endif
+      }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      U128 s0{0, 0}, s1{0, 0};
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        mac128(s0, ev[i][d].x, kv[i][d].x);
+        mac128(s1, ev[i][d].y, kv[i][d].y);
+      }
+      sink(i0 + i, ulong2{reduce128(s0, k.q, k.ml, k.mh), reduce128(s1, k.q, k.ml, k.mh)});
+    }
+  }
+}
+template <class Sink>
+__device__ __forceinline__ void kmac_tile_any(const DevCtx& c, const Kmac& km, const KmacSrc& k, u32 tid, Sink sink) {
+  switch (km.nd) {  // (wave-uniform: a kernel argument)
+    case 1: kmac_tile<1>(c, km, k, tid, sink); break;
+    case 2: kmac_tile<2>(c, km, k, tid, sink); break;
+    case 3: kmac_tile<3>(c, km, k, tid, sink); break;
+    case 4: kmac_tile<4>(c, km, k, tid, sink); break;
+    default:
+      for (u32 i = 0; i < 8; ++i) sink((int)i, kmac_at(c, km, k, 2 * tid + 512 * i));
+  }
 }
 
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
@@ -749,19 +824,20 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
   u64 x[16];
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+  if (KM) {  // the tile is the key inner product (canonical residues)
+    kmac_tile_any(*kc, *km, *ks, tid, [&](int i, ulong2 v) {
+      const u32 e = 2 * tid + 512 * (u32)i, bb = e >> 8, rho = e & 255;
+      lds[bb * kBlkPitch + cpad(rho)] = v.x;
+      lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
+    });
+  } else {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
-    const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-    ulong2 v;
-    if (KM) {  // the tile is the key inner product (canonical residues)
-      v = kmac_at(*kc, *km, *ks, e);
-    } else {
+    for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
+      const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
       const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
-      v.x = vv.x;
-      v.y = vv.y;
+      lds[bb * kBlkPitch + cpad(rho)] = vv.x;
+      lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
     }
-    lds[bb * kBlkPitch + cpad(rho)] = v.x;
-    lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
   }
   Tp15 tp;
   if (TW8) load_tp(TP, s8 + 4, 16 * o + lo4, tp);
@@ -828,19 +904,20 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
   const u32 tid = threadIdx.x;
   double x[16], t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");
+  if (KM) {
+    kmac_tile_any(*kc, *km, *ks, tid, [&](int i, ulong2 v) {
+      const u32 e = 2 * tid + 512 * (u32)i, bb = e >> 8, rho = e & 255;
+      lds[bb * kBlkPitch + cpad(rho)] = v.x;
+      lds[bb * kBlkPitch + cpad(rho) + 1] = v.y;
+    });
+  } else {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
-    const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-    u64x2_t vv;
-    if (KM) {
-      const ulong2 v = kmac_at(*kc, *km, *ks, e);
-      vv.x = v.x;
-      vv.y = v.y;
-    } else {
-      vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+    for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
+      const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
+      const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+      lds[bb * kBlkPitch + cpad(rho)] = vv.x;
+      lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
     }
-    lds[bb * kBlkPitch + cpad(rho)] = vv.x;
-    lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
   }
   fp_load_tw(TWD, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
   __syncthreads();
@@ -896,6 +973,16 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
     const u64* __restrict__ xin = (FUSE == 1 || FUSE == 2) ? reb(c, w.z ? f.x1 : f.x0, w.rep) + tail_off : nullptr;
     u64* __restrict__ dst = FUSE ? reb(c, w.z ? f.out1 : f.out0, w.rep) + tail_off : X;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
+    if (FUSE == 3) {  // the ModDown tail on the key inner product itself
+      kmac_tile_any(c, f.km, ks, tid, [&](int i, ulong2 xv) {
+        const u32 e = 2 * tid + 512 * (u32)i, bb = e >> 8, rho = e & 255;
+        u64x2_t vv;
+        vv.x = mul_shoup(sub_mod(xv.x, lds[bb * kBlkPitch + cpad(rho)], q), tw_w, tw_p, q);
+        vv.y = mul_shoup(sub_mod(xv.y, lds[bb * kBlkPitch + cpad(rho) + 1], q), tw_w, tw_p, q);
+        ntst(reinterpret_cast<u64x2_t*>(dst + e), vv);
+      });
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte stores
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
@@ -908,10 +995,6 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
         v.y = add_mod(mul_shoup(xv.y, tw_w, tw_p, q), v.y, q);
       } else if (FUSE == 2) {
         const ulong2 xv = *reinterpret_cast<const ulong2*>(xin + e);
-        v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
-        v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
-      } else if (FUSE == 3) {  // the ModDown tail on the key inner product itself
-        const ulong2 xv = kmac_at(c, f.km, ks, e);
         v.x = mul_shoup(sub_mod(xv.x, v.x, q), tw_w, tw_p, q);
         v.y = mul_shoup(sub_mod(xv.y, v.y, q), tw_w, tw_p, q);
       }

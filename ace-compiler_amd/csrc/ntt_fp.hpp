@@ -113,13 +113,18 @@ __device__ __forceinline__ void fp_radix16_inv_0(double (&x)[16], double t0, con
 // twiddles as doubles, [L+K][N] like the integer tables (same indices): per lane ...
 __device__ __forceinline__ void fp_load_tw(const double* __restrict__ TW, u32 sbase, u32 prefix, double& t0, double (&t1)[2], double (&t2)[4],
                                            double (&t3)[8]) {
-  t0 = TW[(1u << sbase) + prefix];
+#if defined(NTT_EXP) && (NTT_EXP & 32)  // timing experiment (results are wrong): every per-lane twiddle load hits the same 2 KiB (what the twiddle stream costs)
+#define ACEHIP_TWIDX(i) ((i) & 255u)
+#else
+#define ACEHIP_TWIDX(i) (i)
+#endif
+  t0 = TW[ACEHIP_TWIDX((1u << sbase) + prefix)];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) t1[i] = TW[(2u << sbase) + (prefix << 1) + i];
+  for (int i = 0; i < 2; ++i) t1[i] = TW[ACEHIP_TWIDX((2u << sbase) + (prefix << 1) + i)];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t2[i] = TW[(4u << sbase) + (prefix << 2) + i];
+  for (int i = 0; i < 4; ++i) t2[i] = TW[ACEHIP_TWIDX((4u << sbase) + (prefix << 2) + i)];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t3[i] = TW[(8u << sbase) + (prefix << 3) + i];
+  for (int i = 0; i < 8; ++i) t3[i] = TW[ACEHIP_TWIDX((8u << sbase) + (prefix << 3) + i)];
 }
 // ... and the 15 twiddles of stages 0..3, the same for every lane: scalar loads through the constant address space
 typedef const __attribute__((address_space(4))) double* fp_ctw_ptr;
