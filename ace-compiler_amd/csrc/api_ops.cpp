@@ -317,8 +317,10 @@ bool kmac_fusable(const acehip_ctx* c, u32 level, u32 nd) {
   const int mode = kmac_fuse_mode();
   if (mode == 0 || !c->on_device || c->dc.logN != 16 || sharded(c) || nd == 0 || nd > kKmacMaxDigits) return false;
   if (mode >= 2) return true;
-  const u32 rows_q = 2 * level * c->seln, rows_p = 2 * c->hp.K * c->seln;
-  return rows_q > c->dc.ntt_narrow_max_rows && rows_p > c->dc.ntt_narrow_max_rows;
+  // (measured on the single C3 key-switch, 14 P-limb rows and 50 q-limb rows: 0.230 -> 0.221 ms although the P-limbs' inverse passes turn
+  //  wide -- one launch less; where the q-limb passes are narrow too the narrow pipeline stays)
+  const u32 rows_q = 2 * level * c->seln;
+  return rows_q > c->dc.ntt_narrow_max_rows;
 }
 int do_keymac_mod_down2(acehip_ctx* c, u64* out0, u64* out1, const Kmac& km, u32 level, hipStream_t s, u64* scratch = nullptr) {
   const HostParams& hp = c->hp;

@@ -12,7 +12,8 @@ import _oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SETS = [(16, 10, 60, 59, 3, 10), (64, 7, 60, 51, 3, 5), (4096, 6, 60, 50, 3, 6), (65536, 5, 51, 50, 2, 4)]
+# (the last set: six one-limb digits -- the any-number-of-digits form of the key inner product inside Mod_down's passes, 60-bit q0 and P)
+SETS = [(16, 10, 60, 59, 3, 10), (64, 7, 60, 51, 3, 5), (4096, 6, 60, 50, 3, 6), (65536, 5, 51, 50, 2, 4), (65536, 6, 60, 50, 6, 6)]
 
 
 @pytest.fixture(scope="module", params=SETS, ids=lambda s: "n%d_l%d_lv%d" % (s[0], s[1], s[5]))
@@ -380,7 +381,8 @@ def test_keymac_mod_down2_matches_inner_product_then_mod_down(env):
     try:
         for mode in (0, 2, 1):
             rt.lib.acehip_debug_set_kmac_fuse(mode)
-            assert rt.lib.acehip_keymac_fusable(rt.h, level, nd) == (1 if (mode == 2 and N == 65536) else 0)  # (one image: narrow passes)
+            # (one image: the fused form where the q-limb passes are wide anyway -- more than 16 limb rows for the two polynomials)
+            assert rt.lib.acehip_keymac_fusable(rt.h, level, nd) == (1 if (N == 65536 and (mode == 2 or (mode == 1 and 2 * level > 16))) else 0)
             r0.upload(np.zeros(level * N, dtype=np.uint64))
             r1.upload(np.zeros(level * N, dtype=np.uint64))
             rt.check(rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, nd, level, None))
