@@ -93,6 +93,7 @@ SYMBOLS = [
     ("acehip_keymac_fusable", C.c_int, [_vp, _u32, _u32]),
     ("acehip_debug_set_kmac_fuse", C.c_int, [C.c_int]),
     ("acehip_key_inner_product_add", C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    ("acehip_key_inner_products", C.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp]),
     ("acehip_decomp", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_mod_up", C.c_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("acehip_bsgs_inner", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),

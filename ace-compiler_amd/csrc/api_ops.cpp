@@ -1239,6 +1239,41 @@ int acehip_key_inner_product_add(acehip_ctx* c, uint64_t* acc0, uint64_t* acc1, 
   return post_launch();
 }
 
+// The hoisted rotations of Rotate_iteration (ckks_bootstrap_context.c:1276-1290): n key inner products over the same raised digits, each as
+// acehip_key_inner_product[_add] would form it, in one pass over the digits
+int acehip_key_inner_products(acehip_ctx* c, uint64_t* const* h_acc0, uint64_t* const* h_acc1, const uint64_t* const* h_keys, uint32_t n_keys,
+                              const uint64_t* ext, uint32_t level, const uint64_t* add0, const uint64_t* h_scalars, acehip_stream s) {
+  if (int e = check_dev(c)) return e;
+  if (level == 0 || level > c->hp.L) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: bad level");
+  if (!h_acc0 || !h_acc1 || !h_keys || !ext || n_keys == 0) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: null argument");
+  if ((add0 != nullptr) != (h_scalars != nullptr)) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: addend and scalars go together");
+  if (add0 && level > 64) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: at most 64 q-limbs with an addend");
+  for (u32 j = 0; j < n_keys; ++j)
+    if (!h_acc0[j] || !h_acc1[j] || !h_keys[j] || h_acc0[j] == h_acc1[j]) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: bad output / key of a rotation");
+  LimbConsts w{};
+  if (add0)
+    for (u32 i = 0; i < level; ++i) {
+      if (h_scalars[i] >= c->hp.primes[i].q) return fail(ACEHIP_EINVAL, "acehip_key_inner_products: scalar is not a residue of its prime");
+      w.w[i] = h_scalars[i];
+    }
+  const u32 nd = c->hp.num_decomp(level);
+  const size_t E = (size_t)(level + c->hp.K) * c->hp.N;
+  static const bool multi_on = [] { const char* e = getenv("ACEHIP_KEYMAC_MULTI"); return !e || atoi(e) != 0; }();
+  for (u32 j0 = 0; j0 < n_keys; j0 += KEY_MULTI_MAX) {
+    const u32 n = std::min(KEY_MULTI_MAX, n_keys - j0);
+    for (const DevCtx& dc : launch_dcs(c)) {
+      if (multi_on && nd <= 4 && n > 1) {
+        launch_key_mac_multi(dc, h_acc0 + j0, h_acc1 + j0, h_keys + j0, n, ext, E, level, nd, (hipStream_t)s, add0, add0 ? &w : nullptr);
+      } else {  // one rotation (or more digits than the registers hold): the single-key kernels
+        for (u32 j = j0; j < j0 + n; ++j)
+          launch_key_mac_fused(dc, h_acc0[j], h_acc1[j], h_keys[j], ext, E, nullptr, level, nd, c->hp.alpha, (hipStream_t)s, add0, add0 ? &w : nullptr);
+      }
+    }
+  }
+  for (u32 j = 0; j < n_keys; ++j) stat(ST_KEYMAC, 1, 8ull * E * (3ull * nd + 2) + (add0 ? 8ull * level * c->hp.N : 0));
+  return post_launch();
+}
+
 // Rotate_iteration's inner loop (ckks_bootstrap_context.c:1326-1341): out_i = sum_j rot_j (*) pt_{i,j} in the PQ basis
 int acehip_bsgs_inner(acehip_ctx* c, uint64_t* const* out0, uint64_t* const* out1, const uint64_t* const* in0, const uint64_t* const* in1,
                       const uint64_t* const* pt, uint32_t g, uint32_t b, uint32_t pt_q_limbs, uint32_t level, acehip_stream s) {

@@ -263,6 +263,11 @@ struct LimbConsts;
 void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key, const u64* ext, size_t ext_stride,
                           const u64* in, u32 level, u32 nd, u32 alpha, hipStream_t s, const u64* add0 = nullptr,
                           const LimbConsts* w = nullptr);
+// several key inner products over the same raised digits in one pass over them (keyswitch.hip key_mac_multi_kernel): rotation j < n_keys
+// writes acc{0,1}[j] from key set keys[j]; nd <= 4 digits, n_keys <= KEY_MULTI_MAX
+constexpr u32 KEY_MULTI_MAX = 16;
+void launch_key_mac_multi(const DevCtx& c, u64* const* acc0, u64* const* acc1, const u64* const* keys, u32 n_keys, const u64* ext,
+                          size_t ext_stride, u32 level, u32 nd, hipStream_t s, const u64* add0 = nullptr, const LimbConsts* w = nullptr);
 // BSGS inner products (keyswitch.hip bsgs_inner_kernel): kernel-argument block, g <= 16, b <= 16, g*b <= 128
 constexpr u32 BSGS_MAX_G = 16, BSGS_MAX_B = 16, BSGS_MAX_PT = 128;
 struct BsgsArgs {

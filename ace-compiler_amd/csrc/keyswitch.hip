@@ -2,6 +2,8 @@
 // launch, the key inner product fused over digits, and the two-polynomial ModDown tail.
 // Reference algorithm: Decompose_modup polynomial.c:1241-1335, Multiply_add :148-183,
 // Reduce_rns_base :928-967 (generated Rotate()/Relinearize(), resnet20_cifar10_pre.onnx.inc:6972-7146).
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace acehip {
@@ -397,18 +399,21 @@ __global__ __launch_bounds__(256) void key_mac_fused_reps_kernel(DevCtx c, u64* 
     const u32 rep = c.rep0 + r;
     const u64* ext_r = reb(c, ext, rep);
     const u64* in_r = reb(c, in, rep);
-    ulong2 r0{0, 0}, r1{0, 0};
+    // exact 128-bit sums (at most four products below 2^122), one reduction per output
+    U128 s0x{0, 0}, s0y{0, 0}, s1x{0, 0}, s1y{0, 0};
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
       if ((u32)d < nd) {
         const u64* e_src = ((u32)d == own) ? in_r + pb : ext_r + (size_t)d * ext_stride + pb;
         const ulong2 e = *reinterpret_cast<const ulong2*>(e_src + i);
-        r0.x = add_mod(r0.x, mul_mod(k0[d].x, e.x, P), P.q);
-        r0.y = add_mod(r0.y, mul_mod(k0[d].y, e.y, P), P.q);
-        r1.x = add_mod(r1.x, mul_mod(k1[d].x, e.x, P), P.q);
-        r1.y = add_mod(r1.y, mul_mod(k1[d].y, e.y, P), P.q);
+        mac128(s0x, k0[d].x, e.x);
+        mac128(s0y, k0[d].y, e.y);
+        mac128(s1x, k1[d].x, e.x);
+        mac128(s1y, k1[d].y, e.y);
       }
     }
+    ulong2 r0{reduce128(s0x, P.q, P.prec128_lo, P.prec128_hi), reduce128(s0y, P.q, P.prec128_lo, P.prec128_hi)};
+    ulong2 r1{reduce128(s1x, P.q, P.prec128_lo, P.prec128_hi), reduce128(s1y, P.q, P.prec128_lo, P.prec128_hi)};
     if (add0 != nullptr && pos < level) {
       const ulong2 a = *reinterpret_cast<const ulong2*>(reb(c, add0, rep) + pb + i);
       r0.x = add_mod(r0.x, mul_mod(a.x, wl, P), P.q);
@@ -436,6 +441,99 @@ void launch_key_mac_fused(const DevCtx& c, u64* acc0, u64* acc1, const u64* key,
   dim3 grid(X * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   hipLaunchKernelGGL(key_mac_fused_kernel, grid, block, 0, s, c, acc0, acc1, key, ext, ext_stride, in, level, nd, alpha, add0,
                      w ? *w : LimbConsts{});
+}
+
+// Several key inner products over the SAME raised digits (the hoisted rotations of Rotate_iteration ckks_bootstrap_context.c:1276-1290:
+// one Switch_key_precompute, then Fast_rotate_ext with one key per rotation): rotation j gets acc{0,1}_j = sum_d key_j{0,1}[d] (*) ext[d]
+// (+ add0 * w on the q-limbs of acc0_j).  One key inner product per launch reads the digits -- beta (l+K) limbs per image, hundreds of MB per
+// batch, far beyond any cache -- once per ROTATION; here a lane keeps its coefficient of every digit of up to 12 images in registers
+// and walks the rotations: the digits are read once per launch, every key part once per launch (for all images), only the sums are
+// per rotation and image.  One coefficient per lane (8-byte accesses, 512 contiguous bytes per wave instruction) so that 12 images x ND
+// digits fit the register file.  Same arithmetic as key_mac_fused_kernel: canonical residues of the same sums.
+constexpr u32 kKmMultiReps = 12;
+struct KeyMultiArgs {
+  u64* acc0[KEY_MULTI_MAX];
+  u64* acc1[KEY_MULTI_MAX];
+  const u64* key[KEY_MULTI_MAX];  // key set of rotation j: [nd][2][L+K][N]
+  u32 n;
+};
+template <int ND>
+__global__ __launch_bounds__(256) void key_mac_multi_kernel(DevCtx c, KeyMultiArgs a, const u64* ext, size_t ext_stride, u32 level, u32 nd,
+                                                            const u64* add0, LimbConsts w, u32 rep_first, u32 rep_count) {
+  const u32 X = (c.N + 255) / 256;
+  const u32 pos = __builtin_amdgcn_readfirstlane(blockIdx.x / X), x = blockIdx.x % X;
+  const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;
+  const DevPrime P = c.primes[gi];
+  const size_t T = c.L + c.K;
+  const size_t pb = (size_t)pos * c.N, kb = (size_t)gi * c.N;
+  const u32 i = x * 256 + threadIdx.x;
+  if (i >= c.N) return;
+  const bool with_add = add0 != nullptr && pos < level;  // uniform for the workgroup
+  const u64 wl = with_add ? w.w[pos] : 0;
+  u64 e[kKmMultiReps][ND], pc[kKmMultiReps];
+#pragma unroll
+  for (u32 r = 0; r < kKmMultiReps; ++r) {
+    const u32 rr = r < rep_count ? r : 0;  // (images past the group: reload the first, never stored)
+    const u64* ext_r = reb(c, ext, c.rep0 + rep_first + rr);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) e[r][d] = (u32)d < nd ? ext_r[(size_t)d * ext_stride + pb + i] : 0;
+    pc[r] = with_add ? reb(c, add0, c.rep0 + rep_first + rr)[pb + i] : 0;
+  }
+  if (with_add) {
+#pragma unroll
+    for (u32 r = 0; r < kKmMultiReps; ++r) pc[r] = mul_mod(pc[r], wl, P);
+  }
+  for (u32 j = 0; j < a.n; ++j) {
+    u64 k0[ND], k1[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const u32 dd = (u32)d < nd ? (u32)d : 0;
+      const u64* kp = a.key[j] + ((size_t)dd * 2) * T * c.N + kb;  // (keys lie outside the arena: the same for every image)
+      k0[d] = kp[i];
+      k1[d] = kp[T * c.N + i];
+    }
+    u64* o0 = a.acc0[j];
+    u64* o1 = a.acc1[j];
+#pragma unroll
+    for (u32 r = 0; r < kKmMultiReps; ++r) {
+      if (r < rep_count) {  // uniform
+        // exact 128-bit sums of the ND products (below 2^124), ONE reduction per output: the kernel is bound by instruction issue, and a
+        // reduction per product costs three times the multiply-adds of the product (digits past nd are zeros)
+        U128 s0{0, 0}, s1{0, 0};
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          mac128(s0, k0[d], e[r][d]);
+          mac128(s1, k1[d], e[r][d]);
+        }
+        const u64 r0 = add_mod(reduce128(s0, P.q, P.prec128_lo, P.prec128_hi), pc[r], P.q);
+        const u64 r1 = reduce128(s1, P.q, P.prec128_lo, P.prec128_hi);
+        reb(c, o0, c.rep0 + rep_first + r)[pb + i] = r0;
+        reb(c, o1, c.rep0 + rep_first + r)[pb + i] = r1;
+      }
+    }
+  }
+}
+
+void launch_key_mac_multi(const DevCtx& c, u64* const* acc0, u64* const* acc1, const u64* const* keys, u32 n_keys, const u64* ext,
+                          size_t ext_stride, u32 level, u32 nd, hipStream_t s, const u64* add0, const LimbConsts* w) {
+  ACEHIP_ABLATE(ABL_KEYMAC);
+  KeyMultiArgs a;
+  a.n = n_keys;
+  for (u32 j = 0; j < KEY_MULTI_MAX; ++j) {
+    a.acc0[j] = j < n_keys ? acc0[j] : nullptr;
+    a.acc1[j] = j < n_keys ? acc1[j] : nullptr;
+    a.key[j] = j < n_keys ? keys[j] : nullptr;
+  }
+  const LimbConsts lw = w ? *w : LimbConsts{};
+  dim3 grid(((c.N + 255) / 256) * (level + c.K)), block(256);
+  for (u32 r0 = 0; r0 < c.nrep; r0 += kKmMultiReps) {  // the images of the launch in groups the registers hold
+    const u32 cnt = std::min(kKmMultiReps, c.nrep - r0);
+    if (nd <= 1)      hipLaunchKernelGGL(key_mac_multi_kernel<1>, grid, block, 0, s, c, a, ext, ext_stride, level, nd, add0, lw, r0, cnt);
+    else if (nd == 2) hipLaunchKernelGGL(key_mac_multi_kernel<2>, grid, block, 0, s, c, a, ext, ext_stride, level, nd, add0, lw, r0, cnt);
+    else if (nd == 3) hipLaunchKernelGGL(key_mac_multi_kernel<3>, grid, block, 0, s, c, a, ext, ext_stride, level, nd, add0, lw, r0, cnt);
+    else              hipLaunchKernelGGL(key_mac_multi_kernel<4>, grid, block, 0, s, c, a, ext, ext_stride, level, nd, add0, lw, r0, cnt);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,7 +585,11 @@ __global__ __launch_bounds__(256, ACEHIP_BSGS_MIN_WG) void bsgs_inner_kernel(Dev
     for (int j = 0; j < G; ++j) {
       const u64* pt = j < (int)a.g ? reb(c, a.pt[bi * a.g + j], rep) : nullptr;
       if (pt != nullptr) {  // a missing diagonal (giant + j == num_rot) contributes nothing
+#ifdef BSGS_EXP  // timing experiment (results are wrong): every diagonal load hits the first 4 KiB of its limb -- what the diagonal stream costs
+        const ulong2 p = *reinterpret_cast<const ulong2*>(pt + pt_off + (i & 510u));
+#else
         const ulong2 p = *reinterpret_cast<const ulong2*>(pt + pt_off + i);
+#endif
         mac128(s0x, r0[j].x, p.x);
         mac128(s0y, r0[j].y, p.y);
         mac128(s1x, r1[j].x, p.x);

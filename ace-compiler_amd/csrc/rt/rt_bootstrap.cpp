@@ -526,10 +526,35 @@ void rotate_iteration(Ct& result, Precom* pre, std::vector<std::vector<PLAINTEXT
   // with the fused kernel the automorphisms of the hoisted rotations are applied where that kernel reads its inputs
   std::vector<Ct> fast_rot(giant_step);
   std::vector<u32> rot_k(giant_step, 0);
-  for (int j = 0; j < giant_step; j++) {
-    const int32_t val = rot_in[step][j];
-    if (val != 0) fast_rotate_ext(fast_rot[j], result, val, digits, true, fused ? &rot_k[j] : nullptr);
-    else switch_key_ext(fast_rot[j], result);
+  if (fused) {
+    // every hoisted rotation's <key, digits> + P*c0 (Fast_rotate_ext without its automorphism) in ONE pass over the digits
+    // (acehip_key_inner_products): they are beta (l+K) limbs per image and were read once per rotation
+    std::vector<u64*> a0, a1;
+    std::vector<const u64*> keys;
+    for (int j = 0; j < giant_step; j++) {
+      const int32_t val = rot_in[step][j];
+      if (val == 0) {
+        switch_key_ext(fast_rot[j], result);
+        continue;
+      }
+      rot_k[j] = ensure_rot_key(val);
+      SwitchKeyStore* key = ensure_auto_key(rot_k[j]);
+      ev::init(fast_rot[j], l, c.K, result.c._scaling_factor, result.c._sf_degree, result.c._slots, false);  // the inner product writes every limb
+      a0.push_back(q_limbs(&fast_rot[j].c._c0_poly));
+      a1.push_back(q_limbs(&fast_rot[j].c._c1_poly));
+      keys.push_back(key->data);
+    }
+    if (!keys.empty()) {
+      std::vector<u64> pm = p_mod_q(l);
+      HIPCHK(acehip_key_inner_products(c.hip, a0.data(), a1.data(), keys.data(), (u32)keys.size(), digits, l, q_limbs(&result.c._c0_poly),
+                                       pm.data(), nullptr));
+    }
+  } else {
+    for (int j = 0; j < giant_step; j++) {
+      const int32_t val = rot_in[step][j];
+      if (val != 0) fast_rotate_ext(fast_rot[j], result, val, digits, true, nullptr);
+      else switch_key_ext(fast_rot[j], result);
+    }
   }
   dfree(digits);
   POLYNOMIAL first{};

@@ -305,6 +305,12 @@ int acehip_debug_set_kmac_fuse(int mode);
  * residues, P mod q_i there), in the same pass. */
 int acehip_key_inner_product_add(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1, const uint64_t* d_key, const uint64_t* d_ext,
                                  uint32_t level, const uint64_t* d_add0, const uint64_t* h_scalars, acehip_stream stream);
+/* The hoisted rotations of Rotate_iteration (ckks_bootstrap_context.c:1276-1290: one Switch_key_precompute, then Fast_rotate_ext with one
+ * rotation key each): n_keys key inner products over the SAME raised digits d_ext in one pass over them.  h_acc0 / h_acc1 / h_keys: HOST
+ * arrays of n_keys device pointers (outputs of level + K limbs; key sets [num_decomp][2][L+K][N]); d_add0 / h_scalars as in
+ * acehip_key_inner_product_add (both NULL: no addend), applied to every rotation.  Results are those of n_keys single calls. */
+int acehip_key_inner_products(acehip_ctx* ctx, uint64_t* const* h_acc0, uint64_t* const* h_acc1, const uint64_t* const* h_keys, uint32_t n_keys,
+                              const uint64_t* d_ext, uint32_t level, const uint64_t* d_add0, const uint64_t* h_scalars, acehip_stream stream);
 /* Baby-step giant-step inner products of Rotate_iteration (ckks_bootstrap_context.c:1326-1341: Mul_plaintext +
  * Add_ciphertext over one giant step, for every baby step): d_out{0,1}[i] = sum_{j<g} d_in{0,1}[j] (*) pt[i*g + j],
  * i < b, over the level+K limbs of PQ-extended ciphertexts, in ONE pass over the plaintext diagonals.  pt entries are

@@ -412,3 +412,53 @@ def test_key_switch_with_the_inner_product_inside_mod_down(env):
             assert np.array_equal(g0, w0) and np.array_equal(g1, w1), mode
     finally:
         rt.lib.acehip_debug_set_kmac_fuse(old)
+
+
+def test_key_inner_products_over_the_same_digits(env):
+    """acehip_key_inner_products: the hoisted rotations of Rotate_iteration (ckks_bootstrap_context.c:1276-1290) -- several rotation keys over ONE
+    set of raised digits, with and without the P * c0 addend of Fast_rotate_ext -- give what one acehip_key_inner_product[_add] call per key
+    gives (those are checked against the oracle above); 1, 3 and 17 keys (more than one launch holds)."""
+    o, rt, level = env
+    N, K = o.N, o.K
+    nd = o.num_decomp(level)
+    E = level + K
+    ext = np.stack([o.uniform(E, level, 760 + d) for d in range(nd)])
+    c0 = o.uniform(level, level, 770)
+    pm = []
+    for i in range(level):
+        r = 1
+        for j in range(K):
+            r = (r * (o.primes[o.L + j] % o.primes[i])) % o.primes[i]
+        pm.append(r)
+    hs = (C.c_uint64 * level)(*pm)
+    de, dc = rt.to_device(ext), rt.to_device(c0)
+    for n_keys in (1, 3, 17):
+        dks = [rt.to_device(o.make_key(800 + 10 * j)) for j in range(n_keys)]
+        for with_add in (False, True):
+            want = []
+            a0, a1 = rt.buf(E * N), rt.buf(E * N)
+            for dk in dks:
+                if with_add:
+                    rt.check(rt.lib.acehip_key_inner_product_add(rt.h, a0.ptr, a1.ptr, dk.ptr, de.ptr, level, dc.ptr, hs, None))
+                else:
+                    rt.check(rt.lib.acehip_key_inner_product(rt.h, a0.ptr, a1.ptr, dk.ptr, de.ptr, level, None))
+                want.append((a0.download((E, N)), a1.download((E, N))))
+            outs = [(rt.buf(E * N), rt.buf(E * N)) for _ in range(n_keys)]
+            h0 = (C.c_void_p * n_keys)(*[x[0].ptr for x in outs])
+            h1 = (C.c_void_p * n_keys)(*[x[1].ptr for x in outs])
+            hk = (C.c_void_p * n_keys)(*[dk.ptr for dk in dks])
+            rt.check(rt.lib.acehip_key_inner_products(rt.h, h0, h1, hk, n_keys, de.ptr, level, dc.ptr if with_add else None,
+                                                      hs if with_add else None, None))
+            for j in range(n_keys):
+                assert np.array_equal(outs[j][0].download((E, N)), want[j][0]), (n_keys, with_add, j)
+                assert np.array_equal(outs[j][1].download((E, N)), want[j][1]), (n_keys, with_add, j)
+            assert rt.lib.acehip_key_inner_products(rt.h, h0, h1, hk, n_keys, de.ptr, level, dc.ptr, None, None) < 0
+            for x in outs:
+                x[0].free()
+                x[1].free()
+            a0.free()
+            a1.free()
+        for dk in dks:
+            dk.free()
+    de.free()
+    dc.free()
