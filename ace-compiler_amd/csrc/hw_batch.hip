@@ -5,6 +5,8 @@
 // ops into dependency chains (ops that touch a common written limb, kept in program order) and hands up to
 // HW_BATCH_MAX ops to one launch: blockIdx.y walks one chain segment in order, so a coefficient's whole
 // history stays in one lane and the sequential semantics of the original call sequence are preserved.
+#include <algorithm>
+
 #include "device_arith.hpp"
 #include "kernels.hpp"
 
@@ -73,8 +75,13 @@ __device__ __forceinline__ V4 map2(const V4& a, const V4& b, F f) {
   return r;
 }
 
+// Thread layout (round 5): a workgroup is R images x C coefficient chunks of 64 lanes (R * C waves, wave w = image w % R, chunk w / R).
+// Operands that all images share -- weight plaintexts above all -- used to be shared through L2 only (one workgroup per image), which
+// holds for one stream and not next to the kernels of other image streams (those loads redirected to 4 KiB: headline +3.2 %,
+// profiles/r05aq_*); with the images of a batch as the waves of ONE workgroup their requests for a shared line meet in the CU's own
+// cache.  One image per launch: R = 1, C = 4, the old layout.
 template <int CAP>
-__global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
+__global__ __launch_bounds__(1024) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT<CAP> args, u32 R, u32 C, u32 lockstep) {
   __shared__ u64 s_q[kMaxPrimes], s_mu[kMaxPrimes];
   __shared__ u32 s_nb[kMaxPrimes];
   if (ACEHIP_HW_STAGE) {
@@ -90,10 +97,14 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   // (replica = blockIdx.z, the slowest index.  Dealing the replicas of a tile side by side -- kernels.hpp rep_block(), which pays
   // for the key inner product and the BSGS kernel -- measured 3 % slower here: the operands the replicas share, weight plaintexts, are a
   // small part of this kernel's traffic)
-  const u32 i = (blockIdx.x * 256 + threadIdx.x) * kHwLanes;
-  if (i >= c.N) return;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const u32 wr = wave % R, wc = wave / R;
+  const u32 i = ((blockIdx.x * C + wc) * 64 + lane) * kHwLanes;
+  const u32 rl = blockIdx.z * R + wr;  // image of this wave within the launch
+  const bool active = i < c.N && rl < c.nrep;
+  if (!active && !lockstep) return;
   const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
-  const u32 rep = c.rep0 + blockIdx.z;  // replica of this workgroup: operands inside the replicated arena move with it
+  const u32 rep = c.rep0 + rl;  // replica of this wave: operands inside the replicated arena move with it
   // The two most recent results of the segment stay in registers, keyed by their limb (the list's own addresses): slot 0 the
   // last result, slot 1 the last result of ANOTHER limb before it.  A chain that alternates between a temporary and an
   // accumulator (t = x * c; acc = acc + t; ... -- polynomial evaluation, convolution taps) then reads neither from memory.
@@ -108,19 +119,28 @@ __global__ __launch_bounds__(256) void hw_batch_ew_kernel(DevCtx c, HwBatchArgsT
   // wave-uniform.)
   const u64* rb = nullptr;
   V4 vbc{{0, 0}, {0, 0}};
+#ifdef HW_EXP  // timing experiment (results are wrong): operands all images share (outside the arena) are read from the first 4 KiB of their limb
+  auto at = [&](const u64* real_addr) { return ((u64)real_addr - c.rep_lo < c.rep_span) ? real_addr + i : real_addr + (i & 510u); };
+#else
+  auto at = [&](const u64* real_addr) { return real_addr + i; };
+#endif
   auto fetch = [&](const u64* list_addr, const u64* real_addr) {
-    return list_addr == r0 ? v0 : (list_addr == r1 ? v1 : (list_addr == rb ? vbc : ld4(real_addr + i)));
+    return list_addr == r0 ? v0 : (list_addr == r1 ? v1 : (list_addr == rb ? vbc : ld4(at(real_addr))));
   };
   auto fetch_b = [&](const u64* list_addr, const u64* real_addr) {
     if (list_addr == r0) return v0;
     if (list_addr == r1) return v1;
     if (list_addr != rb) {
-      vbc = ld4(real_addr + i);
+      vbc = ld4(at(real_addr));
       rb = list_addr;
     }
     return vbc;
   };
   for (u32 k = beg; k < end; ++k) {
+    if (lockstep) {  // experiment: the images of the workgroup start every op together, so that their loads of a shared operand meet in the CU's cache
+      __syncthreads();
+      if (!active) continue;
+    }
     HwBatchOp op = args.op[k];
     const u32 kind = op.kind & HW_OP_KIND_MASK;
     const u64 *const res0 = op.res, *const a0 = op.a, *const b0 = op.b;  // (registers are matched by the list's own addresses)
@@ -215,11 +235,17 @@ static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
 void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hipStream_t s) {
   ACEHIP_ABLATE(ABL_EW);
   if (n_seg == 0) return;
-  dim3 grid((c.N / kHwLanes + 255) / 256, n_seg, c.nrep), block(256);
+  // images per workgroup: all of a batch up to 12 (ACEHIP_HW_REPS_WG=1: one, the layout that shares through L2); chunks so that a
+  // workgroup has at least four waves
+  static const u32 reps_cap = [] { const char* e = getenv("ACEHIP_HW_REPS_WG"); return e && atoi(e) > 0 ? (u32)atoi(e) : 1u; }();
+  static const u32 lockstep = [] { const char* e = getenv("ACEHIP_HW_REPS_SYNC"); return e && atoi(e) > 0 ? 1u : 0u; }();
+  const u32 R = std::min(std::min(c.nrep, reps_cap), 16u), C = R >= 4 ? 1u : (R == 3 ? 1u : (R == 2 ? 2u : 4u));
+  const u32 per_wg = 64 * kHwLanes * C;  // coefficients of a limb per workgroup
+  dim3 grid((c.N + per_wg - 1) / per_wg, n_seg, (c.nrep + R - 1) / R), block(64 * R * C);
   const u32 n_ops = args.seg_start[n_seg];
-  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));
-  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));
-  else hipLaunchKernelGGL(hw_batch_ew_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args);
+  if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_ew_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg), R, C, lockstep);
+  else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_ew_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg), R, C, lockstep);
+  else hipLaunchKernelGGL(hw_batch_ew_kernel<HW_BATCH_MAX>, grid, block, 0, s, c, args, R, C, lockstep);
 }
 
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {

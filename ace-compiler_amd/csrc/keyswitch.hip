@@ -658,8 +658,82 @@ __global__ __launch_bounds__(256, ACEHIP_BSGS1_MIN_WG) void bsgs_inner1_kernel(D
   }
 }
 
+// The images of a batch as the WAVES of one workgroup (round 5).  The diagonals are the same for every image; the forms above leave their
+// sharing to L2 (workgroups of the same tile side by side), which holds for one stream and not next to the kernels of other image streams
+// (every diagonal load redirected to 4 KiB: headline +1.2 %, profiles/r05al_*).  Here wave w of a workgroup is image rep_first + w, a lane
+// one coefficient: the g diagonals of an output are staged ONCE per workgroup in LDS (64 coefficients each, double-buffered: the next
+// output's are requested before this one's are multiplied) and read by all waves.  Same sums, same single reduction: same bits.
+template <int G>
+__global__ __launch_bounds__(1024) void bsgs_inner_reps_kernel(DevCtx c, BsgsArgs a, u32 level, u32 rep_first) {
+  __shared__ u64 sd[2][G][64];
+  const u32 X = c.N / 64;
+  const u32 pos = __builtin_amdgcn_readfirstlane(blockIdx.x / X), x = blockIdx.x % X;
+  const u32 gi = limb_prime(pos, level, c.L);
+  if (!owns(c, gi)) return;  // (uniform for the workgroup)
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const u32 rep = c.rep0 + rep_first + wave;
+  const DevPrime& P = c.primes[gi];
+  const u64 q = P.q, ml = P.prec128_lo, mh = P.prec128_hi;
+  const size_t ct_off = (size_t)pos * c.N;
+  const size_t pt_off = pos < level ? ct_off : (size_t)(a.pt_q_alloc + (pos - level)) * c.N;
+  const u32 i = x * 64 + lane;
+  u64 r0[G], r1[G];
+  const u32 sh = __builtin_clz(c.N) + 1;  // 32 - log2(N)
+  const u32 b0 = __brev(i) >> sh;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (j < (int)a.g) {
+      const u32 k = a.in_auto[j];
+      const u64 *in0 = reb(c, a.in0[j], rep), *in1 = reb(c, a.in1[j], rep);
+      const u32 px = k == 0 ? i : __brev((((2 * b0 + 1) * k) & (2 * c.N - 1)) >> 1) >> sh;
+      r0[j] = in0[ct_off + px];
+      r1[j] = in1[ct_off + px];
+    } else {
+      r0[j] = r1[j] = 0;
+    }
+  }
+  auto stage = [&](u32 bi, u32 buf) {  // the g diagonals of output bi, this workgroup's 64 coefficients (a missing one: zeros)
+    for (u32 t = threadIdx.x; t < (u32)G * 64u; t += blockDim.x) {
+      const u32 j = t >> 6, l = t & 63u;
+      const u64* pt = j < a.g ? a.pt[bi * a.g + j] : nullptr;
+      sd[buf][j][l] = pt != nullptr ? pt[pt_off + x * 64 + l] : 0;
+    }
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (u32 bi = 0; bi < a.b; ++bi) {
+    if (bi + 1 < a.b) stage(bi + 1, (bi + 1) & 1u);
+    const u32 buf = bi & 1u;
+    U128 s0{0, 0}, s1{0, 0};
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const u64 p = sd[buf][j][lane];
+      mac128(s0, r0[j], p);
+      mac128(s1, r1[j], p);
+    }
+    reb(c, a.out0[bi], rep)[ct_off + i] = reduce128(s0, q, ml, mh);
+    reb(c, a.out1[bi], rep)[ct_off + i] = reduce128(s1, q, ml, mh);
+    __syncthreads();  // everybody has read this output's diagonals (the buffer is rewritten two outputs on) and the next one's are in place
+  }
+}
+
 void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_t s) {
   ACEHIP_ABLATE(ABL_BSGS);
+  // several images per launch and every diagonal outside the replicated arena (the usual case: precomputed plaintexts are shared by all
+  // images): the images-as-waves form.  ACEHIP_BSGS_REPS=0: the forms that share through L2.
+  static const bool reps_on = [] { const char* e = getenv("ACEHIP_BSGS_REPS"); return !e || atoi(e) != 0; }();
+  if (reps_on && c.nrep >= 4 && c.N % 64 == 0 && a.g > 8) {
+    bool shared = true;
+    for (u32 t = 0; t < a.g * a.b && shared; ++t) shared = !((u64)a.pt[t] - c.rep_lo < c.rep_span);
+    if (shared) {
+      dim3 grid((c.N / 64) * (level + c.K));
+      for (u32 r0 = 0; r0 < c.nrep; r0 += 16) {
+        const u32 cnt = std::min(16u, c.nrep - r0);
+        hipLaunchKernelGGL((bsgs_inner_reps_kernel<16>), grid, dim3(64 * cnt), 0, s, c, a, level, r0);
+      }
+      return;
+    }
+  }
   dim3 grid(((c.N / 2 + 255) / 256) * (level + c.K) * c.nrep), block(256);  // 1-D: rep_block() maps it
   if (a.g <= 4)      hipLaunchKernelGGL((bsgs_inner_kernel<4>), grid, block, 0, s, c, a, level);
   else if (a.g <= 8) hipLaunchKernelGGL((bsgs_inner_kernel<8>), grid, block, 0, s, c, a, level);
