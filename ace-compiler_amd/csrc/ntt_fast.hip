@@ -620,6 +620,198 @@ __device__ __forceinline__ void strided_inv_body_fp(u64* __restrict__ X, const d
   asm volatile("" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------
+// PIPELINED forms of the strided pass (ACEHIP_NTT_PIPE = T in {2, 4}; round 6).  A workgroup walks T adjacent tiles of ONE limb.
+// Every twiddle of the strided pass depends on the lane only (stages 0..3 are uniform, stages 4..7 go by the row group hg), never on
+// the tile, so both sets are fetched once per workgroup and stay in registers (SGPRs / VGPRs) over the walk; the 16 loads of tile
+// t+1 are issued BEFORE the butterflies of tile t (a second set of 16 registers), so that a wave's memory phase lies under its own
+// arithmetic instead of under the other workgroups' of the CU.  Same butterflies in the same order on the same values as the
+// one-tile bodies above: bit-identical results (tests force both forms).  Costs 3 instead of 4 workgroups per CU in registers.
+// ------------------------------------------------------------------------------------------------
+template <bool SMALL, int T>
+__device__ __forceinline__ void strided_fwd_pipe_body(const StridedArgs& a) {
+  const BfK bk = bf_consts<SMALL>(a.q);
+  u64 x[16], xn[16];
+  Tw u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+  const u32 vld = (a.hg << 11) + a.col * 8, vst = (a.hg << 15) + a.col * 8;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, vld, (u32)k << 15);
+  load_tw_uniform<SMALL>(a.TW, u0, u1, u2, u3);
+  load_tw<SMALL>(a.TW, 4, a.hg, t0, t1, t2, t3);
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) xn[k] = bld(a.buf, vld + 128u * (u32)(t + 1), (u32)k << 15);
+    }
+    radix16_fwd<SMALL>(x, u0, u1, u2, u3, bk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.lds[(16 * k + a.hg) * kRowPitch + a.cc] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = a.lds[(16 * a.hg + k) * kRowPitch + a.cc];
+    if (t + 1 < T) __syncthreads();  // the next tile's round A writes the LDS tile again
+    radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bst(a.buf, vst + 128u * (u32)t, (u32)k << 11, x[k]);
+    if (t + 1 < T) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = xn[k];
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+template <int T>
+__device__ __forceinline__ void strided_fwd_pipe_body_fp(const StridedArgs& a) {
+  const FpK k = fp_consts(a.q);
+  u64 xn[16];
+  double x[16], u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+  const u32 vld = (a.hg << 11) + a.col * 8, vst = (a.hg << 15) + a.col * 8;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xn[i] = bld(a.buf, vld, (u32)i << 15);
+  fp_load_tw_uniform(a.TWD, u0, u1, u2, u3);
+  fp_load_tw(a.TWD, 4, a.hg, t0, t1, t2, t3);
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fp_from_u64(xn[i]);  // canonical residues
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = bld(a.buf, vld + 128u * (u32)(t + 1), (u32)i << 15);
+    }
+    fp_radix16_fwd(x, u0, u1, u2, u3, k);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a.lds[(16 * i + a.hg) * kRowPitch + a.cc] = fp_bits(x[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(a.lds[(16 * a.hg + i) * kRowPitch + a.cc]);
+    if (t + 1 < T) __syncthreads();
+    fp_radix16_fwd(x, t0, t1, t2, t3, k);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bst(a.buf, vst + 128u * (u32)t, (u32)i << 11, fp_bits(x[i]));
+  }
+  asm volatile("" ::: "memory");
+}
+
+// inverse, pipelined: tiles walked like the forward form; X = the limb, col = the first tile's column of this lane
+template <bool SMALL, int T>
+__device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
+                                                      const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
+  constexpr u32 log_s = 8;
+  const u64 q = P.q;
+  const BfK bk = bf_consts<SMALL>(q);
+  u64 x[16], xn[16];
+  Tw u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = ntld(&X[((size_t)(16 * hg + k) << log_s) + col]);
+  load_tw<SMALL>(TW, 4, hg, t0, t1, t2, t3);
+  load_tw_uniform<SMALL>(TW, u0, u1, u2, u3);
+  Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
+  if (f.inv_scale) {
+    const u64* sc = f.inv_scale + 4 * (size_t)pos;
+    tn = Tw{sc[0], sc[1]};
+    tw = Tw{sc[2], sc[3]};
+  }
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) xn[k] = ntld(&X[((size_t)(16 * hg + k) << log_s) + col + 16u * (u32)(t + 1)]);
+    }
+    radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
+    radix16_inv_0<SMALL>(x, t0, bk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[(16 * k + hg) * kRowPitch + cc];
+    if (t + 1 < T) __syncthreads();
+    radix16_inv_321<SMALL>(x, u1, u2, u3, bk);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 s = x[k] + x[k + 8];
+      const u64 d = x[k] + bk.lim - x[k + 8];
+      u64 a = shoup_lazy(s, tn, q), b = shoup_lazy(d, tw, q);
+      x[k] = a >= q ? a - q : a;
+      x[k + 8] = b >= q ? b - q : b;
+    }
+    if (f.center_out) {
+      const u64 half = q >> 1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = x[k] > half ? x[k] - q : x[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ntst(&X[((size_t)(16 * k + hg) << log_s) + col + 16u * (u32)t], x[k]);
+    if (t + 1 < T) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = xn[k];
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+template <int T>
+__device__ __forceinline__ void strided_inv_pipe_body_fp(u64* __restrict__ X, const double* __restrict__ TWD, u64* lds, const DevPrime& P,
+                                                         const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
+  constexpr u32 log_s = 8;
+  const u64 q = P.q;
+  const FpK k = fp_consts(q);
+  u64 xn[16];
+  double x[16], u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xn[i] = ntld(&X[((size_t)(16 * hg + i) << log_s) + col]);
+  fp_load_tw(TWD, 4, hg, t0, t1, t2, t3);
+  fp_load_tw_uniform(TWD, u0, u1, u2, u3);
+  u64 un = P.n_inv, uw = P.inv_w1_ninv;
+  if (f.inv_scale) {
+    const u64* sc = f.inv_scale + 4 * (size_t)pos;
+    un = sc[0];
+    uw = sc[2];
+  }
+  const double tn = fp_from_u64(un), tw = fp_from_u64(uw);
+  const double half = fp_from_u64(q >> 1);
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(xn[i]);
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = ntld(&X[((size_t)(16 * hg + i) << log_s) + col + 16u * (u32)(t + 1)]);
+    }
+    fp_radix16_inv_321(x, t1, t2, t3, k);
+    fp_radix16_inv_0(x, t0, k);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[(16 * hg + i) * kRowPitch + cc] = fp_bits(x[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(lds[(16 * i + hg) * kRowPitch + cc]);
+    if (t + 1 < T) __syncthreads();
+    fp_radix16_inv_321(x, u1, u2, u3, k);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double s = x[i] + x[i + 8], d = x[i] - x[i + 8];
+      double a = fp_canon_f(fp_mulmod(s, tn, k), k), b = fp_canon_f(fp_mulmod(d, tw, k), k);
+      if (f.center_out) {
+        a = a > half ? a - k.q : a;
+        b = b > half ? b - k.q : b;
+      }
+      x[i] = a;
+      x[i + 8] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      u64 v;
+      if (f.center_out) v = (u64)(int64_t)x[i];
+      else              v = fp_to_u64(x[i]);
+      ntst(&X[((size_t)(16 * i + hg) << log_s) + col + 16u * (u32)t], v);
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
 // (uniform64: a load issued after stores of the same kernel is a vector load even when its address is uniform)
 // One resolved workgroup of a pass: tile of limb row y of polynomial z, the limb's position / prime
 struct NttWg {
@@ -684,6 +876,48 @@ __global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_strided_kernel(De
   ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   strided_pass<INVERSE, SRC>(c, poly, poly_stride, pos_off, f, lds, w);
+}
+
+// pipelined strided pass (in place, SRC_MEM): workgroup = tiles [T*tile, T*tile + T) of limb row y of polynomial z
+#ifndef NTT_PIPE_T4
+#define NTT_PIPE_T4 0  // 1: also compile the four-tile walk (experiments; measured slower than two tiles on every batch, profiles/r06a_*)
+#endif
+#ifndef NTT_PIPE_WG
+#define NTT_PIPE_WG 3  // workgroups per CU the pipelined kernels are compiled for
+#endif
+#ifdef NTT_PIPE_FP_ONLY  // experiment: the pipelined kernels carry the FP class only (register allocation of that class alone)
+#define NTT_PIPE_INT(x) (void)0  // (results of the integer classes are wrong: timing experiment)
+#else
+#define NTT_PIPE_INT(x) x
+#endif
+template <bool INVERSE, int T>
+__global__ __launch_bounds__(256, NTT_PIPE_WG) void ntt8_strided_pipe_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
+                                                                u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
+  __shared__ u64 lds[256 * kRowPitch];
+  constexpr u32 logT = T == 2 ? 1 : (T == 4 ? 2 : 3);
+  static_assert(T == 2 || T == 4 || T == 8, "tiles per workgroup");
+  const NttBlk blk = ntt_block(c.logN - 12 - logT, n_limbs, n_polys * c.nrep);
+  NttWg w{blk.tile * (u32)T, blk.y, blk.z, 0, 0, 0};
+  ntt_split_z(w, c, n_polys);
+  if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
+  const DevPrime& P = c.primes[w.gi];
+  const u64 q = uniform64(P.q);
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(w.pos - pos_off) * c.N;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
+  const u32 col = w.tile * 16 + cc;
+  const double* __restrict__ TWD = c.twd_fwd ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
+  const bool fp = TWD != nullptr && q < kFpPrimeMax;
+  if (!INVERSE) {
+    const StridedArgs a{limb_buf(X, c.N * 8), TW, TWD, lds, cc, hg, col, q};
+    if (fp)                       strided_fwd_pipe_body_fp<T>(a);
+    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_fwd_pipe_body<true, T>(a)));
+    else                          NTT_PIPE_INT((strided_fwd_pipe_body<false, T>(a)));
+  } else {
+    if (fp)                       strided_inv_pipe_body_fp<T>(X, TWD, lds, P, f, w.pos, cc, hg, col);
+    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_inv_pipe_body<true, T>(X, TW, lds, P, f, w.pos, cc, hg, col)));
+    else                          NTT_PIPE_INT((strided_inv_pipe_body<false, T>(X, TW, lds, P, f, w.pos, cc, hg, col)));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -784,19 +1018,28 @@ __device__ __forceinline__ void kmac_tile_any(const DevCtx& c, const Kmac& km, c
 
 // forward rounds: x[] holds rho = 16k+lo4 of block b on entry and the canonical values of the 16 contiguous
 // rho = 16*lo4+k on return
-template <bool SMALL, bool TW8>
+// PRE (pipelined form): x[] already holds the tile's values as they lie in memory (loaded during the previous tile's butterflies);
+// pf() issues the NEXT tile's loads.  It is called right after the tile's first twiddle loads: vmcnt counts in order, so a wait for
+// twiddles issued behind the prefetch would wait for the prefetch as well.
+struct NoPf {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <bool SMALL, bool TW8, bool PRE = false, class PF = NoPf>
 __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const ulong2* __restrict__ TW, const u64* __restrict__ TP,
-                                                u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16]) {
+                                                u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q, u64 mu, u64 (&x)[16], PF pf = PF{}) {
   const BfK bk = bf_consts<SMALL>(q);
   Tw t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");  // keeps this path's loads below the class branch
+  if (!PRE) {
 #pragma unroll
 #if NTT_EXP & (2 | 16)
-  for (int k = 0; k < 16; ++k) x[k] = (u64)(b * 256 + 16 * k + lo4) * 0x9E3779B97F4A7C15ull + o;
+    for (int k = 0; k < 16; ++k) x[k] = (u64)(b * 256 + 16 * k + lo4) * 0x9E3779B97F4A7C15ull + o;
 #else
-  for (int k = 0; k < 16; ++k) x[k] = ntld(&X[b * 256 + 16 * k + lo4]);
+    for (int k = 0; k < 16; ++k) x[k] = ntld(&X[b * 256 + 16 * k + lo4]);
 #endif
+  }
   load_tw<SMALL>(TW, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
+  pf();
   radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * k + lo4] = x[k];
@@ -815,10 +1058,13 @@ __device__ __forceinline__ void contig_fwd_body(const u64* __restrict__ X, const
 
 // inverse rounds: the tile is read from S (coalesced 16-byte loads through LDS), round B first (stages s8+7..s8+4 on the 16
 // contiguous rho = 16h + g'), then round A (stages s8+3..s8 on rho = 16k + g); lazy [0,lim) output unless CANON_OUT
-template <bool SMALL, bool CANON_OUT, bool TW8, bool KM = false>
+// PRE (pipelined form): the tile's 8 coalesced 16-byte loads are already in pre[]; a barrier follows the last LDS read (the next
+// tile of the walk writes the LDS tile again)
+template <bool SMALL, bool CANON_OUT, bool TW8, bool KM = false, bool PRE = false, class PF = NoPf>
 __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* __restrict__ S, const ulong2* __restrict__ TW,
                                                 const u64* __restrict__ TP, u64* lds, u32 s8, u32 o, u32 b, u32 lo4, u64 q,
-                                                const DevCtx* kc = nullptr, const Kmac* km = nullptr, const KmacSrc* ks = nullptr) {
+                                                const DevCtx* kc = nullptr, const Kmac* km = nullptr, const KmacSrc* ks = nullptr,
+                                                const u64x2_t* pre = nullptr, PF pf = PF{}) {
   const BfK bk = bf_consts<SMALL>(q);
   const u32 tid = threadIdx.x;
   u64 x[16];
@@ -834,7 +1080,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-      const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+      const u64x2_t vv = PRE ? pre[i] : ntld(reinterpret_cast<const u64x2_t*>(S + e));
       lds[bb * kBlkPitch + cpad(rho)] = vv.x;
       lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
     }
@@ -842,6 +1088,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
   Tp15 tp;
   if (TW8) load_tp(TP, s8 + 4, 16 * o + lo4, tp);
   else     load_tw<SMALL>(TW, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  pf();
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * lo4 + k];
@@ -858,6 +1105,7 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = lds[b * kBlkPitch + 17 * k + lo4];
+  if (PRE) __syncthreads();
   radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
   radix16_inv_0<SMALL>(x, t0, bk);
 #pragma unroll
@@ -875,14 +1123,16 @@ __device__ __forceinline__ void contig_inv_body(u64* __restrict__ X, const u64* 
 
 // ---- FP class, contiguous pass.  forward: input = the strided FP pass' doubles; x[] returns the canonical u64 residues of the 16
 // contiguous rho = 16*lo4+k, like contig_fwd_body
+template <bool PRE = false, class PF = NoPf>
 __device__ __forceinline__ void contig_fwd_body_fp(const u64* __restrict__ X, const double* __restrict__ TWD, u64* lds, u32 s8, u32 o, u32 b,
-                                                   u32 lo4, u64 q, u64 (&xo)[16]) {
+                                                   u32 lo4, u64 q, u64 (&xo)[16], PF pf = PF{}) {
   const FpK k = fp_consts(q);
   double x[16], t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(ntld(&X[b * 256 + 16 * i + lo4]));
+  for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(PRE ? xo[i] : ntld(&X[b * 256 + 16 * i + lo4]));
   fp_load_tw(TWD, s8, o, t0, t1, t2, t3);  // round A: stages s8..s8+3 on rho = 16k + g
+  pf();
   fp_radix16_fwd(x, t0, t1, t2, t3, k);
 #pragma unroll
   for (int i = 0; i < 16; ++i) lds[b * kBlkPitch + 17 * i + lo4] = fp_bits(x[i]);
@@ -896,10 +1146,10 @@ __device__ __forceinline__ void contig_fwd_body_fp(const u64* __restrict__ X, co
 }
 
 // inverse: canonical u64 input from S (coalesced through LDS, as contig_inv_body), output doubles |v| <= 0.51q for the strided FP pass
-template <bool KM = false>
+template <bool KM = false, bool PRE = false, class PF = NoPf>
 __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u64* __restrict__ S, const double* __restrict__ TWD, u64* lds,
                                                    u32 s8, u32 o, u32 b, u32 lo4, u64 q, const DevCtx* kc = nullptr, const Kmac* km = nullptr,
-                                                   const KmacSrc* ks = nullptr) {
+                                                   const KmacSrc* ks = nullptr, const u64x2_t* pre = nullptr, PF pf = PF{}) {
   const FpK k = fp_consts(q);
   const u32 tid = threadIdx.x;
   double x[16], t0, t1[2], t2[4], t3[8];
@@ -914,12 +1164,13 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // coalesced 16-byte loads
       const u32 e = 2 * tid + 512 * i, bb = e >> 8, rho = e & 255;
-      const u64x2_t vv = ntld(reinterpret_cast<const u64x2_t*>(S + e));
+      const u64x2_t vv = PRE ? pre[i] : ntld(reinterpret_cast<const u64x2_t*>(S + e));
       lds[bb * kBlkPitch + cpad(rho)] = vv.x;
       lds[bb * kBlkPitch + cpad(rho) + 1] = vv.y;
     }
   }
   fp_load_tw(TWD, s8 + 4, 16 * o + lo4, t0, t1, t2, t3);
+  pf();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = fp_red(fp_from_u64(lds[b * kBlkPitch + 17 * lo4 + i]), k);  // canonical -> |v| <= 0.51q (ntt_fp.hpp)
@@ -932,6 +1183,7 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(lds[b * kBlkPitch + 17 * i + lo4]);
+  if (PRE) __syncthreads();
   fp_radix16_inv_321(x, t1, t2, t3, k);
   fp_radix16_inv_0(x, t0, k);
 #pragma unroll
@@ -939,37 +1191,19 @@ __device__ __forceinline__ void contig_inv_body_fp(u64* __restrict__ X, const u6
   asm volatile("" ::: "memory");
 }
 
-// CONTIG pass of one workgroup.
-// FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
-// f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
-template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8, bool FP_OK>
-__device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
-                                            u64* lds, const NttWg& w) {
-  const DevPrime& P = c.primes[w.gi];
-  const u64 q = uniform64(P.q);
-  const u32 pos = w.pos;
-  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
-  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
-  const u64* __restrict__ TP = TW8 ? (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N : nullptr;
-  const u32 s8 = c.logN - 8;
-  const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
-  const u32 o = w.tile * 16 + b;
-
-  // FP class (ntt_fp.hpp): only where the OTHER pass of the transform is the wide strided pass (launch_ntt_fused sets FP_OK), never
-  // with CANON_OUT (the hybrid sizes, whose other stages are the generic integer kernel)
-  const double* __restrict__ TWD = (FP_OK && c.twd_fwd) ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
-  const bool fp = TWD != nullptr && q < kFpPrimeMax;
-  if (!INVERSE) {
-    u64 x[16];
-    if (fp)                       contig_fwd_body_fp(X, TWD, lds, s8, o, b, lo4, q, x);
-    else if (q <= kSmallPrimeMax) contig_fwd_body<true, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
-    else                          contig_fwd_body<false, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+// the end of a forward contiguous tile: x[] (canonical, the lane's 16 contiguous coefficients) goes through LDS into coalesced 16-byte
+// stores, combined with the fused neighbour (FUSE 1 / 2: Rescale / ModDown tail, 3: the ModDown tail on the key inner product).
+// X = the tile in the transformed polynomial, `tile` its index within the limb.
+template <int FUSE>
+__device__ __forceinline__ void contig_fwd_finish(const DevCtx& c, const NttFuse& f, u64* lds, const NttWg& w, u32 tile, const DevPrime& P, u64 q,
+                                                  u64* __restrict__ X, const u64 (&x)[16]) {
+  const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4, pos = w.pos;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[b * kBlkPitch + 17 * lo4 + k] = x[k];
     __syncthreads();
-    const size_t tail_off = (size_t)pos * c.N + (size_t)w.tile * 4096;  // q-limb `pos` of x_z / out_z
-    const KmacSrc ks{f.km_pos0 + pos, w.gi, w.z, w.rep, w.tile, q, P.prec128_lo, P.prec128_hi};
+    const size_t tail_off = (size_t)pos * c.N + (size_t)tile * 4096;  // q-limb `pos` of x_z / out_z
+    const KmacSrc ks{f.km_pos0 + pos, w.gi, w.z, w.rep, tile, q, P.prec128_lo, P.prec128_hi};
     const u64* __restrict__ xin = (FUSE == 1 || FUSE == 2) ? reb(c, w.z ? f.x1 : f.x0, w.rep) + tail_off : nullptr;
     u64* __restrict__ dst = FUSE ? reb(c, w.z ? f.out1 : f.out0, w.rep) + tail_off : X;
     const u64 tw_w = FUSE ? f.w[pos] : 0, tw_p = FUSE ? f.wp[pos] : 0;
@@ -1006,6 +1240,34 @@ __device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ p
       vv.y = v.y;
       ntst(reinterpret_cast<u64x2_t*>(dst + e), vv);
     }
+}
+
+// CONTIG pass of one workgroup.
+// FUSE: inverse -> 1: read the input from f.src_z (out of place);  forward -> 1 / 2: combine the result with
+// f.x_z and write it to f.out_z (Rescale / ModDown tail) instead of storing it in place
+template <bool INVERSE, bool CANON_OUT, int FUSE, bool TW8, bool FP_OK>
+__device__ __forceinline__ void contig_pass(const DevCtx& c, u64* __restrict__ poly, size_t poly_stride, u32 pos_off, const NttFuse& f,
+                                            u64* lds, const NttWg& w) {
+  const DevPrime& P = c.primes[w.gi];
+  const u64 q = uniform64(P.q);
+  const u32 pos = w.pos;
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const u64* __restrict__ TP = TW8 ? (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N : nullptr;
+  const u32 s8 = c.logN - 8;
+  const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
+  const u32 o = w.tile * 16 + b;
+
+  // FP class (ntt_fp.hpp): only where the OTHER pass of the transform is the wide strided pass (launch_ntt_fused sets FP_OK), never
+  // with CANON_OUT (the hybrid sizes, whose other stages are the generic integer kernel)
+  const double* __restrict__ TWD = (FP_OK && c.twd_fwd) ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
+  const bool fp = TWD != nullptr && q < kFpPrimeMax;
+  if (!INVERSE) {
+    u64 x[16];
+    if (fp)                       contig_fwd_body_fp(X, TWD, lds, s8, o, b, lo4, q, x);
+    else if (q <= kSmallPrimeMax) contig_fwd_body<true, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    else                          contig_fwd_body<false, TW8>(X, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x);
+    contig_fwd_finish<FUSE>(c, f, lds, w, w.tile, P, q, X, x);
   } else {
     if (FUSE == 2) {  // input = the key inner product
       const KmacSrc ks{f.km_pos0 + pos, w.gi, w.z, w.rep, w.tile, q, P.prec128_lo, P.prec128_hi};
@@ -1032,6 +1294,83 @@ __global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_contig_kernel(Dev
   ntt_split_z(w, c, n_polys);
   if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
   contig_pass<INVERSE, CANON_OUT, FUSE, TW8, FP_OK>(c, poly, poly_stride, pos_off, f, lds, w);
+}
+
+// PIPELINED contiguous pass (ACEHIP_NTT_PIPE = T; round 6): the workgroup walks tiles [T*tile, T*tile + T) of one limb; the global loads of
+// tile t+1 are issued before the butterflies of tile t.  The twiddles of this pass differ per tile and are fetched at the head of each
+// tile like in the one-tile form (they come from the XCD's L2: the polynomials of a launch share them).  FUSE as in contig_pass
+// (forward: 0..3; inverse: 0 / 1; the key inner product as the inverse's source keeps the one-tile form).
+template <bool INVERSE, int FUSE, bool TW8, int T>
+__global__ __launch_bounds__(256, NTT_PIPE_WG) void ntt8_contig_pipe_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
+                                                               u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
+  __shared__ u64 lds[16 * kBlkPitch];
+  constexpr u32 logT = T == 2 ? 1 : (T == 4 ? 2 : 3);
+  static_assert(T == 2 || T == 4 || T == 8, "tiles per workgroup");
+  static_assert(!INVERSE || FUSE <= 1, "the key inner product as the source of the inverse pass keeps the one-tile kernel");
+  const NttBlk blk = ntt_block(c.logN - 12 - logT, n_limbs, n_polys * c.nrep);
+  NttWg w{blk.tile * (u32)T, blk.y, blk.z, 0, 0, 0};
+  ntt_split_z(w, c, n_polys);
+  if (!ntt_resolve(w, c, f, level, pos0, skip_alpha)) return;
+  const DevPrime& P = c.primes[w.gi];
+  const u64 q = uniform64(P.q);
+  const u32 pos = w.pos;
+  u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096;
+  const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const u64* __restrict__ TP = TW8 ? (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N : nullptr;
+  const u32 s8 = c.logN - 8;
+  const u32 tid = threadIdx.x, lo4 = tid & 15, b = tid >> 4;
+  const double* __restrict__ TWD = c.twd_fwd ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
+  const bool fp = TWD != nullptr && q < kFpPrimeMax;
+  const bool small = q <= kSmallPrimeMax;
+  if (!INVERSE) {
+    u64 x[16], xn[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ntld(&X[b * 256 + 16 * k + lo4]);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      u64* __restrict__ Xt = X + (size_t)t * 4096;
+      const u32 tile = w.tile + (u32)t, o = tile * 16 + b;
+      auto pf = [&]() {
+        if (t + 1 < T) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) xn[k] = ntld(&Xt[4096 + b * 256 + 16 * k + lo4]);
+        }
+      };
+      if (fp)         contig_fwd_body_fp<true>(Xt, TWD, lds, s8, o, b, lo4, q, x, pf);
+      else if (small) NTT_PIPE_INT((contig_fwd_body<true, TW8, true>(Xt, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x, pf)));
+      else            NTT_PIPE_INT((contig_fwd_body<false, TW8, true>(Xt, TW, TP, lds, s8, o, b, lo4, q, P.prec128_hi, x, pf)));
+      contig_fwd_finish<FUSE>(c, f, lds, w, tile, P, q, Xt, x);
+      if (t + 1 < T) {
+        __syncthreads();  // the next tile's round A writes the LDS tile again
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = xn[k];
+      }
+    }
+  } else {
+    const u64* __restrict__ S =
+        FUSE ? reb(c, w.z ? f.src1 : f.src0, w.rep) + (size_t)(pos - pos_off) * c.N + (size_t)w.tile * 4096 : X;
+    u64x2_t v[8], vn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ntld(reinterpret_cast<const u64x2_t*>(S + 2 * tid + 512 * i));
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      u64* __restrict__ Xt = X + (size_t)t * 4096;
+      const u32 o = (w.tile + (u32)t) * 16 + b;
+      auto pf = [&]() {
+        if (t + 1 < T) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) vn[i] = ntld(reinterpret_cast<const u64x2_t*>(S + (size_t)(t + 1) * 4096 + 2 * tid + 512 * i));
+        }
+      };
+      if (fp)         contig_inv_body_fp<false, true>(Xt, nullptr, TWD, lds, s8, o, b, lo4, q, nullptr, nullptr, nullptr, v, pf);
+      else if (small) NTT_PIPE_INT((contig_inv_body<true, false, TW8, false, true>(Xt, nullptr, TW, TP, lds, s8, o, b, lo4, q, nullptr, nullptr, nullptr, v, pf)));
+      else            NTT_PIPE_INT((contig_inv_body<false, false, TW8, false, true>(Xt, nullptr, TW, TP, lds, s8, o, b, lo4, q, nullptr, nullptr, nullptr, v, pf)));
+      if (t + 1 < T) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = vn[i];
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1368,6 +1707,43 @@ static bool launch_ntt_narrow(const DevCtx& c, u64* poly, u32 level, u32 pos0, u
   return true;
 }
 
+// the pipelined forms of both passes (T tiles per workgroup); false: this launch has a fused neighbour only the one-tile kernels know
+template <int T>
+static bool launch_ntt_pipe_t(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                              u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f, bool tw8) {
+  dim3 block(256), grid(((c.N >> 12) / T) * n_limbs * n_polys * c.nrep);
+#define ACEHIP_NP_ARGS grid, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
+#define ACEHIP_NP_CONTIG(INV, FUSE)                                                                               \
+  do {                                                                                                            \
+    if (tw8) hipLaunchKernelGGL((ntt8_contig_pipe_kernel<INV, FUSE, true, T>), ACEHIP_NP_ARGS);                   \
+    else     hipLaunchKernelGGL((ntt8_contig_pipe_kernel<INV, FUSE, false, T>), ACEHIP_NP_ARGS);                  \
+  } while (0)
+  if (!inverse) {
+    if (f.msg || f.conv) return false;
+    hipLaunchKernelGGL((ntt8_strided_pipe_kernel<false, T>), ACEHIP_NP_ARGS);
+    if (f.epi == 1)      ACEHIP_NP_CONTIG(false, 1);
+    else if (f.epi == 2) ACEHIP_NP_CONTIG(false, 2);
+    else if (f.epi == 3) ACEHIP_NP_CONTIG(false, 3);
+    else                 ACEHIP_NP_CONTIG(false, 0);
+  } else {
+    if (f.km.nd) return false;
+    if (f.src0) ACEHIP_NP_CONTIG(true, 1);
+    else        ACEHIP_NP_CONTIG(true, 0);
+    hipLaunchKernelGGL((ntt8_strided_pipe_kernel<true, T>), ACEHIP_NP_ARGS);
+  }
+#undef ACEHIP_NP_CONTIG
+#undef ACEHIP_NP_ARGS
+  return true;
+}
+static bool launch_ntt_pipe(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
+                            u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f, bool tw8, u32 T) {
+  if (c.logN != 16) return false;
+#if NTT_PIPE_T4
+  if (T == 4) return launch_ntt_pipe_t<4>(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f, tw8);
+#endif
+  return launch_ntt_pipe_t<2>(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f, tw8);
+}
+
 // logN >= 16 uses both fast passes when logN == 16; the contig pass alone serves the last 8 stages of
 // any logN >= 13 (the generic LDS kernel does the leading logN-8 stages).
 void launch_ntt_fast(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s,
@@ -1388,6 +1764,10 @@ void launch_ntt_fused(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_lim
   // run beside them on the same CU (0 = off)
   static const size_t lds_pad = [] { const char* e = getenv("ACEHIP_NTT_LDS_PAD"); return e ? (size_t)strtoul(e, nullptr, 0) : (size_t)0; }();
 #define ACEHIP_NTT_ARGS grid, block, lds_pad, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
+  // ACEHIP_NTT_PIPE = 2 / 4: the pipelined forms (a workgroup walks that many tiles of a limb, the next tile's loads in flight during
+  // the butterflies); 0: one tile per workgroup.  Bit-identical either way.
+  static const u32 pipe = [] { const char* e = getenv("ACEHIP_NTT_PIPE"); const u32 v = e ? (u32)strtoul(e, nullptr, 0) : 0u; return (v == 2 || (v == 4 && NTT_PIPE_T4)) ? v : 0u; }();
+  if (pipe && launch_ntt_pipe(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f, tw8, pipe)) return;
   if (!inverse) {
     if (f.msg)                     hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_MSG>), ACEHIP_NTT_ARGS);
     else if (f.conv && f.conv_max_in <= 4)  hipLaunchKernelGGL((ntt8_strided_kernel<false, SRC_CONV4>), ACEHIP_NTT_ARGS);
