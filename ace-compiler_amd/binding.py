@@ -130,6 +130,7 @@ SYMBOLS = [
     ("acehip_shard_rank", _u32, [_vp]),
     ("acehip_shard_owned_limbs", _u32, [_vp, _u32]),
     ("acehip_shard_traffic", _u64, [_vp, _vp, C.c_int]),
+    ("acehip_shard_collectives", _u64, [_vp]),
     ("acehip_shard_schedule", C.c_int, [_vp, _u32, C.c_int, _u32, _vp, _vp, _vp, C.c_size_t]),
 ]
 

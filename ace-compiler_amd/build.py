@@ -52,16 +52,28 @@ def _newer(target, deps):
 # tree: a library older or newer than the sources beside it must never be loaded silently).
 #  * every object has a sidecar <obj>.dep = sha256 of its source, the headers it may include and its command line; it is rebuilt
 #    when that differs;
-#  * both shared libraries embed the fingerprint of ALL sources (tools/csrc_fingerprint.py: csrc/**, include/**) as the string
+#  * both shared libraries embed the fingerprint of ALL sources (tools/csrc_fingerprint.py: csrc/**, include/**) AND of the effective
+#    compile flags (the experiment scripts under tools/ build kernels that give wrong results into the in-tree library through
+#    ACEHIP_EXTRA_HIPCC_FLAGS: such a library must never pass for a clean build of the same sources) as the string
 #    "ACEHIP_SRC_FPR=<16 hex>" and export it (acehip_source_fingerprint / acehip_rt_source_fingerprint); needs_build() reads it out
 #    of the file, binding.load_library() compares it with the sources after dlopen, and the shim's Prepare_context aborts when the
 #    two libraries disagree.
 FPR_TAG = b"ACEHIP_SRC_FPR="
 
 
+def hip_flags():
+    """the flags every HIP object is compiled with.  -fgpu-default-stream=per-thread: the NULL stream of every entry point is the
+    calling thread's own stream, so host threads that each own a context (one image stream each) run concurrently on the GPU.
+    ACEHIP_EXTRA_HIPCC_FLAGS: experiments only; part of the fingerprint, so a process that does not carry the same value refuses
+    (rebuilds) a library built with it."""
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-fgpu-default-stream=per-thread", "-Wall",
+            "-Wno-unused-function"] + os.environ.get("ACEHIP_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def source_fingerprint():
     root = os.path.dirname(HERE)
     h = hashlib.sha256()
+    h.update(("flags: %s | %s\n" % (" ".join(hip_flags()), sorted(PER_FILE_FLAGS.items()))).encode())
     files = []
     for top in (os.path.join(root, "include"), CSRC):
         for d, _, names in os.walk(top):
@@ -126,10 +138,7 @@ def _hip_objects(force, verbose):
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs, objs = [], []
-    # -fgpu-default-stream=per-thread: the NULL stream of every entry point is the calling thread's own stream, so
-    # host threads that each own a context (one image stream each) run concurrently on the GPU
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-fgpu-default-stream=per-thread", "-Wall",
-             "-Wno-unused-function"] + os.environ.get("ACEHIP_EXTRA_HIPCC_FLAGS", "").split()  # extra flags: experiments only
+    flags = hip_flags()
     for src in SOURCES:
         s, o = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".", "_") + ".o")
         objs.append(o)

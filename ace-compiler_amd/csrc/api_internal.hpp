@@ -103,6 +103,7 @@ struct acehip_ctx {
   std::vector<u32> sh_hosted;
   void* rccl = nullptr;            // RcclComm* (api_shard.cpp) when the ranks are processes
   u64 xchg_bytes = 0, xchg_calls = 0;  // bytes this process received through exchanges / exchange steps
+  u64 xchg_collectives = 0;            // RCCL collectives issued for them (one per packed exchange, one per limb otherwise)
 
   template <typename T>
   T* up(const std::vector<T>& v) {

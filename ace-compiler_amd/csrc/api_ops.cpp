@@ -322,7 +322,11 @@ bool kmac_fusable(const acehip_ctx* c, u32 level, u32 nd) {
   const u32 rows_q = 2 * level * c->seln;
   return rows_q > c->dc.ntt_narrow_max_rows;
 }
-int do_keymac_mod_down2(acehip_ctx* c, u64* out0, u64* out1, const Kmac& km, u32 level, hipStream_t s, u64* scratch = nullptr) {
+// word ranges [a, a + na) and [b, b + nb) share a word
+static bool overlaps(const u64* a, size_t na, const u64* b, size_t nb) { return a < b + nb && b < a + na; }
+// own_stats: record ST_KEYMAC / ST_MODDOWN here (false: the caller accounts for the whole operation, e.g. ST_KEYSWITCH)
+int do_keymac_mod_down2(acehip_ctx* c, u64* out0, u64* out1, const Kmac& km, u32 level, hipStream_t s, u64* scratch = nullptr,
+                        bool own_stats = true) {
   const HostParams& hp = c->hp;
   const KsPlan* plan = get_ks_plan(c, level);
   if (!plan) return fail(ACEHIP_EHIP, "key-switch plan upload failed");
@@ -361,8 +365,10 @@ int do_keymac_mod_down2(acehip_ctx* c, u64* out0, u64* out1, const Kmac& km, u32
     fo.wp = c->pinv_prec;
     launch_ntt_fused(dc, tmp, level, 0, level, false, s, 0, 2, QL, 0, fo);
   }
-  stat(ST_KEYMAC, 1, 8ull * E * (3ull * km.nd + 2));
-  stat(ST_MODDOWN, 2, 8ull * 2 * N * (2 * level + hp.K));
+  if (own_stats) {
+    stat(ST_KEYMAC, 1, 8ull * E * (3ull * km.nd + 2));
+    stat(ST_MODDOWN, 2, 8ull * 2 * N * (2 * level + hp.K));
+  }
   return post_launch();
 }
 extern "C" {
@@ -378,8 +384,14 @@ int acehip_keymac_mod_down2(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const
     return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: bad arguments");
   const HostParams& hp = c->hp;
   const size_t N = hp.N, E = (size_t)(level + hp.K) * N, T = hp.L + hp.K;
-  for (u32 d = 0; d < n_digits; ++d)
+  const size_t QLw = (size_t)level * N;
+  if (overlaps(out0, QLw, out1, QLw)) return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: the outputs overlap");
+  for (u32 d = 0; d < n_digits; ++d) {
     if (!h_ext[d] || !h_key[d]) return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: null digit or key part");
+    // the last pass reads the digits while it writes the outputs (the two polynomials' workgroups of a tile read the same digit words)
+    if (overlaps(out0, QLw, h_ext[d], E) || overlaps(out1, QLw, h_ext[d], E))
+      return fail(ACEHIP_EINVAL, "acehip_keymac_mod_down2: an output overlaps a raised digit");
+  }
   hipStream_t s = (hipStream_t)s_;
   if (kmac_fusable(c, level, n_digits)) {
     Kmac km;
@@ -829,7 +841,11 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
       launch_ntt(dc, ext, level, 0, n_ext_rows, false, s, 0, nd, E, hp.alpha);
     }
   }
-  if (kmac_fusable(c, level, nd)) {
+  // (the fused last pass reads `in` -- the digits' own limbs -- while it writes out0 / out1, and both polynomials' workgroups of a tile read
+  //  the same words of `in`: an output that overlaps the input takes the pipeline with stored accumulators, which has read `in` completely
+  //  before it writes)
+  const bool out_aliases_in = overlaps(out0, (size_t)level * N, in, (size_t)level * N) || overlaps(out1, (size_t)level * N, in, (size_t)level * N);
+  if (kmac_fusable(c, level, nd) && !out_aliases_in) {
     // 4 + 5. the key inner product is formed by Mod_down's own passes (the accumulators are never stored); a digit's own limbs are
     // read from `in`.  Mod_down's scratch (2 K + 2 level limbs) takes the place of the accumulators behind the digits.
     Kmac km;
@@ -843,7 +859,7 @@ static int key_switch_impl(acehip_ctx* c, uint64_t* out0, uint64_t* out1, const 
       km.key[d] = key + (size_t)d * 2 * (hp.L + hp.K) * N;
     }
     stat(ST_KEYSWITCH, 1, acehip_key_switch_bytes(c, level));
-    return do_keymac_mod_down2(c, out0, out1, km, level, s, acc0);
+    return do_keymac_mod_down2(c, out0, out1, km, level, s, acc0, false);
   }
   for (const DevCtx& dc : dcs) {
     // 4. key inner product fused over digits; a digit's own limbs are read from `in` directly
@@ -1262,7 +1278,13 @@ int acehip_key_inner_products(acehip_ctx* c, uint64_t* const* h_acc0, uint64_t* 
   for (u32 j0 = 0; j0 < n_keys; j0 += KEY_MULTI_MAX) {
     const u32 n = std::min(KEY_MULTI_MAX, n_keys - j0);
     for (const DevCtx& dc : launch_dcs(c)) {
-      if (multi_on && nd <= 4 && n > 1) {
+      // the multi-key kernel reads a key part ONCE for all images of the launch (keys are shared: every caller allocates them outside the
+      // replicated arena).  A key set INSIDE the arena differs per replica: those launches take the single-key kernels, which decide
+      // per key (launch_key_mac_fused: key_shared)
+      bool keys_shared = true;
+      if (dc.nrep > 1)
+        for (u32 j = j0; j < j0 + n; ++j) keys_shared = keys_shared && !((u64)h_keys[j] - dc.rep_lo < dc.rep_span);
+      if (multi_on && nd <= 4 && n > 1 && keys_shared) {
         launch_key_mac_multi(dc, h_acc0 + j0, h_acc1 + j0, h_keys + j0, n, ext, E, level, nd, (hipStream_t)s, add0, add0 ? &w : nullptr);
       } else {  // one rotation (or more digits than the registers hold): the single-key kernels
         for (u32 j = j0; j < j0 + n; ++j)

@@ -463,6 +463,7 @@ struct RcclApi {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // optional: without it every exchange is grouped broadcasts
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi* rccl_api() {
@@ -488,6 +489,7 @@ RcclApi* rccl_api() {
     api.GroupStart = (int (*)())sym("ncclGroupStart");
     api.GroupEnd = (int (*)())sym("ncclGroupEnd");
     api.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
     api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     if (!api.GetUniqueId || !api.CommInitRank || !api.GroupStart || !api.GroupEnd || !api.Broadcast) api.lib = nullptr;
   });
@@ -502,9 +504,116 @@ struct RcclComm {
   hipStream_t xs = nullptr;
   hipEvent_t before = nullptr, after = nullptr;
   bool pending = false;  // an exchange was begun and not yet joined (shard_exchange_begin / _end)
+  // ---- packed exchanges (round 6): ONE collective per exchange.  The limbs an exchange names are scattered over the polynomials'
+  // reference layout (owner = gi % world), so every rank copies the limbs it owns into its slice of a staging block, one ncclAllGather
+  // (one ncclBroadcast when a single rank owns them all) moves the block, and the limbs of the other ranks are copied from it to
+  // where the pipelines read them.  The local copies run at HBM speed (0.1 us per limb); what crosses xGMI is one message per peer
+  // instead of one per limb.  stage: [stage_words]; begin() takes regions from stage_used on, end() enqueues the pending copies out
+  // of them on the launch stream and starts over.
+  u64* stage = nullptr;
+  size_t stage_words = 0, stage_used = 0;
+  std::vector<std::pair<u64*, const u64*>> unpack;  // (destination limb, limb in the staging block) of the exchanges begun since the last end()
 };
 constexpr int kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
 }  // namespace
+
+// limb copies between absolute addresses (no replica rebasing, no ownership filter), 112 per launch of the per-limb batch kernel
+static void copy_limbs_abs(acehip_ctx* c, const std::vector<std::pair<u64*, const u64*>>& cps, hipStream_t s) {
+  DevCtx dc = c->dc;
+  dc.rep_span = 0;
+  dc.rep0 = 0;
+  dc.nrep = 1;
+  dc.sh_world = 1;
+  HwBatchArgs cp;
+  u32 m = 0;
+  for (size_t k = 0; k < cps.size(); ++k) {
+    cp.seg_start[m] = (uint16_t)m;
+    cp.op[m++] = HwBatchOp{cps[k].first, cps[k].second, nullptr, HW_OP_COPY, 0};
+    if (m == HW_BATCH_MAX || k + 1 == cps.size()) {
+      cp.seg_start[m] = (uint16_t)m;
+      launch_hw_batch_ew(dc, cp, m, s);
+      m = 0;
+    }
+  }
+}
+static bool packed_exchanges_on() {
+  static const bool on = [] { const char* e = getenv("ACEHIP_SHARD_PACKED"); return !e || atoi(e) != 0; }();
+  return on;
+}
+// One collective for the whole exchange (RcclComm: packed exchanges).  *done = false: not applicable here, use the grouped broadcasts.
+static int shard_exchange_begin_packed(acehip_ctx* c, const XItem* items, size_t n, hipStream_t s, bool* done) {
+  *done = false;
+  RcclComm* rc = (RcclComm*)c->rccl;
+  RcclApi* api = rccl_api();
+  if (!packed_exchanges_on()) return ACEHIP_OK;
+  const size_t N = c->hp.N;
+  const u32 world = rc->world;
+  const u64 lo = c->dc.rep_lo, span = c->dc.rep_span, stride = c->dc.rep_stride;
+  // every (limb, replica) of the exchange with its owner, in the order all ranks enumerate alike
+  std::vector<std::pair<u64*, u32>> limbs;
+  std::vector<u32> cnt(world, 0);
+  for (size_t k = 0; k < n; ++k) {
+    const u64 a = (u64)items[k].ptr;
+    const bool in_arena = a - lo < span && stride != 0;
+    if (items[k].root >= world) return fail(ACEHIP_EINVAL, "shard_exchange: owner out of range");
+    for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1); ++r) {
+      limbs.push_back({(u64*)(in_arena ? a + (u64)r * stride : a), items[k].root});
+      cnt[items[k].root]++;
+    }
+  }
+  if (limbs.size() < 2) return ACEHIP_OK;  // (a single limb is one broadcast either way, in place)
+  u32 roots = 0, m = 0, single_root = 0;
+  for (u32 r = 0; r < world; ++r) {
+    if (cnt[r]) {
+      roots++;
+      single_root = r;
+    }
+    m = std::max(m, cnt[r]);
+  }
+  const bool gather = roots > 1;
+  if (gather && api->AllGather == nullptr) return ACEHIP_OK;
+  // slots per rank are padded to the largest owner's count: ownership is round robin, so the padding is at most one limb per rank
+  const size_t need = (gather ? (size_t)world * m : (size_t)m) * N;
+  if (rc->stage_used + need > rc->stage_words) {
+    // (exchanges in flight use the block: this one goes limb by limb.  Decided by stage_used alone, which every rank advances alike:
+    //  all ranks must take the same form of every exchange)
+    if (rc->stage_used != 0) return ACEHIP_OK;
+    HIP_TRY(hipStreamSynchronize(s));  // the block grows a few times at most while a program warms up
+    HIP_TRY(hipStreamSynchronize(rc->xs));
+    if (rc->stage) (void)hipFree(rc->stage);
+    rc->stage = nullptr;
+    rc->stage_words = 0;
+    const size_t want = std::max(need * 2, (size_t)4 * (c->hp.L + c->hp.K) * N);
+    HIP_TRY(hipMalloc((void**)&rc->stage, want * sizeof(u64)));
+    rc->stage_words = want;
+  }
+  u64* blk = rc->stage + rc->stage_used;
+  rc->stage_used += need;
+  std::vector<std::pair<u64*, const u64*>> pack;
+  std::vector<u32> slot(world, 0);
+  for (const auto& lb : limbs) {
+    const u32 root = lb.second;
+    u64* st = blk + ((gather ? (size_t)root * m : 0) + slot[root]++) * N;
+    if (root == rc->rank) pack.push_back({st, lb.first});
+    else {
+      rc->unpack.push_back({lb.first, st});
+      c->xchg_bytes += N * 8;
+    }
+  }
+  c->xchg_calls++;
+  c->xchg_collectives++;
+  copy_limbs_abs(c, pack, s);
+  HIP_TRY(hipEventRecord(rc->before, s));
+  HIP_TRY(hipStreamWaitEvent(rc->xs, rc->before, 0));
+  int e;
+  if (gather) e = api->AllGather(blk + (size_t)rc->rank * m * N, blk, (size_t)m * N, kNcclUint64, rc->comm, rc->xs);  // in place
+  else        e = api->Broadcast(blk, blk, (size_t)m * N, kNcclUint64, (int)single_root, rc->comm, rc->xs);
+  HIP_TRY(hipEventRecord(rc->after, rc->xs));
+  rc->pending = true;
+  *done = true;
+  if (e) return fail(ACEHIP_EHIP, std::string(gather ? "RCCL all-gather: " : "RCCL broadcast: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  return ACEHIP_OK;
+}
 
 // An exchange in two halves, so that a pipeline can put independent launches between them: begin() orders the broadcasts after
 // everything issued on s so far and enqueues them on the exchange stream, end() makes s wait for every exchange begun since the
@@ -515,6 +624,11 @@ int shard_exchange_begin(acehip_ctx* c, const XItem* items, size_t n, hipStream_
   if (c->rccl == nullptr) return shard_exchange(c, items, n, s);
   const size_t N = c->hp.N;
   const u64 lo = c->dc.rep_lo, span = c->dc.rep_span, stride = c->dc.rep_stride;
+  {
+    bool done = false;
+    const int e = shard_exchange_begin_packed(c, items, n, s, &done);
+    if (e || done) return e;
+  }
   c->xchg_calls++;
   RcclComm* rc = (RcclComm*)c->rccl;
   RcclApi* api = rccl_api();
@@ -527,6 +641,7 @@ int shard_exchange_begin(acehip_ctx* c, const XItem* items, size_t n, hipStream_
     for (u32 r = c->sel0; r < c->sel0 + (in_arena ? c->seln : 1) && e == 0; ++r) {
       void* p = (void*)(in_arena ? a + (u64)r * stride : a);
       e = api->Broadcast(p, p, N, kNcclUint64, (int)items[k].root, rc->comm, rc->xs);
+      c->xchg_collectives++;
       if (items[k].root != rc->rank) c->xchg_bytes += N * 8;
     }
   }
@@ -543,6 +658,11 @@ int shard_exchange_end(acehip_ctx* c, hipStream_t s) {
   if (!rc->pending) return ACEHIP_OK;
   rc->pending = false;
   HIP_TRY(hipStreamWaitEvent(s, rc->after, 0));  // (the exchange stream is in order: the last recorded event covers every begin())
+  if (!rc->unpack.empty()) {  // packed exchanges: the other ranks' limbs go from the staging block to where the pipelines read them
+    copy_limbs_abs(c, rc->unpack, s);
+    rc->unpack.clear();
+  }
+  rc->stage_used = 0;  // (the next begin() packs on s, behind these copies; its collective waits for that)
   return ACEHIP_OK;
 }
 
@@ -599,6 +719,7 @@ void shard_release(acehip_ctx* c) {
   if (rc->before) (void)hipEventDestroy(rc->before);
   if (rc->after) (void)hipEventDestroy(rc->after);
   if (rc->xs) (void)hipStreamDestroy(rc->xs);
+  if (rc->stage) (void)hipFree(rc->stage);
   delete rc;
   c->rccl = nullptr;
 }
@@ -719,9 +840,10 @@ uint64_t acehip_shard_traffic(const acehip_ctx* c_, uint64_t* steps, int reset) 
     steps[0] = c->xchg_calls;
     steps[1] = b / (8ull * c->hp.N);
   }
-  if (reset) c->xchg_bytes = c->xchg_calls = 0;
+  if (reset) c->xchg_bytes = c->xchg_calls = c->xchg_collectives = 0;
   return b;
 }
+uint64_t acehip_shard_collectives(const acehip_ctx* c) { return c ? c->xchg_collectives : 0; }
 
 // which limbs meet where: the exchange steps of the pipelines in api_ops.cpp, stated once more as data so that the schedule
 // can be checked against the CPU oracle without a GPU (tests/test_dist_gloo.py runs it over gloo with two processes)

@@ -237,6 +237,8 @@ static std::string shard_job_identity() {
   const char* run = getenv("TORCHELASTIC_RUN_ID");
   const char *addr = getenv("MASTER_ADDR"), *port = getenv("MASTER_PORT"), *world = getenv("WORLD_SIZE");
   if (run && *run && strcmp(run, "none") != 0) job += std::string(run) + "_";
+  // (a restarted worker group of the same elastic run is another launch: its ranks must not pick up the previous group's record)
+  if (const char* rc = getenv("TORCHELASTIC_RESTART_COUNT")) if (*rc && strcmp(rc, "0") != 0) job += std::string("r") + rc + "_";
   if (port && *port) job += std::string(addr && *addr ? addr : "localhost") + "_" + port + "_w" + (world ? world : "1");
   else if (job.empty()) job = "ppid" + std::to_string((long)getppid());
   for (char& ch : job)
@@ -278,7 +280,38 @@ void shard_connect_if_asked() {
   } rec;
   memset(&rec, 0, sizeof rec);
   unsigned char id[128];
-  static const time_t process_start = time(nullptr);  // (first use: Prepare_context, seconds after the process began)
+  // when THIS process began (/proc/self/stat field 22 + the boot time of /proc/stat; the clock at first use -- Prepare_context -- where
+  // those are unreadable).  The ranks of
+  // one launch start within seconds of each other, so a record written more than a few seconds before a reader BEGAN belongs to an
+  // earlier launch on the same address and port that died between publishing and joining: refused, the reader keeps waiting for its
+  // own rank 0 (which unlinks the stale file first thing).
+  static const time_t process_start = [] {
+    const time_t now = time(nullptr);
+    long long btime = -1, ticks = -1;
+    if (FILE* f = fopen("/proc/stat", "r")) {
+      char line[256];
+      while (fgets(line, sizeof line, f))
+        if (sscanf(line, "btime %lld", &btime) == 1) break;
+      fclose(f);
+    }
+    if (FILE* f = fopen("/proc/self/stat", "r")) {
+      char buf[2048];
+      const size_t n = fread(buf, 1, sizeof buf - 1, f);
+      fclose(f);
+      buf[n] = 0;
+      if (const char* p = strrchr(buf, ')')) {  // (the command name may hold spaces: fields are counted behind its closing bracket)
+        int field = 2;
+        for (++p; *p && field < 22; ++p)
+          if (*p == ' ' && p[1] != ' ') ++field;
+        if (field == 22) ticks = atoll(p);
+      }
+    }
+    const long hz = sysconf(_SC_CLK_TCK);
+    if (btime <= 0 || ticks < 0 || hz <= 0) return now;
+    const time_t t = (time_t)(btime + ticks / hz);
+    return t > now || now - t > 7 * 24 * 3600 ? now : t;
+  }();
+  constexpr int64_t kRecordSlackS = 10;
   if (rank == 0) {
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
     unlink(path.c_str());  // (left behind by a run that died between publishing and joining)
@@ -304,10 +337,10 @@ void shard_connect_if_asked() {
       const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
       if (fd >= 0) {  // (an older file, another user's, or another job's token: not this run's -- keep waiting for rank 0)
         struct stat st;
-        // (a record written more than two minutes before THIS process started belongs to an earlier launch that died before joining)
+        // (a record written more than kRecordSlackS before THIS process started belongs to an earlier launch that died before joining)
         if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && time(nullptr) - st.st_mtime < 300 &&
             read(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && memcmp(rec.magic, "ACEHRCC2", 8) == 0 && rec.token == token &&
-            rec.created_s >= (int64_t)process_start - 120) {
+            rec.created_s >= (int64_t)process_start - kRecordSlackS) {
           memcpy(id, rec.id, 128);
           got = true;
         }
@@ -322,7 +355,15 @@ void shard_connect_if_asked() {
   }
   shard_connect(rank, world, id, rec.master_key);
   memset(&rec, 0, sizeof rec);
-  if (rank == 0) unlink(path.c_str());  // (every rank has joined: ncclCommInitRank returns only then)
+  if (rank == 0) {  // (every rank has joined: ncclCommInitRank returns only then)  The record held the job's master key: zeros before it goes
+    const int fd = open(path.c_str(), O_WRONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd >= 0) {
+      const bool wiped = write(fd, &rec, sizeof rec) == (ssize_t)sizeof rec && fsync(fd) == 0;  // rec is all zeros here
+      (void)wiped;
+      close(fd);
+    }
+    unlink(path.c_str());
+  }
 }
 
 void generate_keys() {
@@ -494,8 +535,9 @@ void Finalize_context() {
   const size_t total = rot_bytes + key_words * 8 + (size_t)(c.L + c.K) * c.N * 8 + 2ull * c.L * c.N * 8;
   printf("Total memory size for keys: rot_key_cnt = %ld, rot_key_size = %ld bytes, total_key_size = %ld bytes\n",
          (long)rot_cnt, (long)rot_bytes, (long)total);
-  printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)c.weight_plain_cnt,
-         (long)c.weight_plain_bytes);
+  size_t wp_cnt = 0, wp_bytes = 0;
+  weight_plain_totals(&wp_cnt, &wp_bytes, true);  // every image thread's encodes, once per image served (count_weight_plain)
+  printf("Total memory size for weight plain: cnt = %ld, size = %ld bytes\n", (long)wp_cnt, (long)wp_bytes);
   if (c.profile) {
     printf("[ACEHIP] host seconds: encode (launch side) %.3f, Main_graph issue %.3f (until the last call returns), Main_graph %.3f\n",
            c.t_encode, c.t_issue, c.t_main);
@@ -506,7 +548,8 @@ void Finalize_context() {
     if (c.shard_world > 1) {
       uint64_t steps[2] = {0, 0};
       const uint64_t b = acehip_shard_traffic(c.hip, steps, 0);
-      printf("[ACEHIP] limb exchanges: %llu steps, %llu limbs, %.3f GB received\n", (unsigned long long)steps[0], (unsigned long long)steps[1], b / 1e9);
+      printf("[ACEHIP] limb exchanges: %llu steps, %llu limbs, %.3f GB received, %llu collectives\n", (unsigned long long)steps[0],
+             (unsigned long long)steps[1], b / 1e9, (unsigned long long)acehip_shard_collectives(c.hip));
     }
     hw_stats_print();
     hw_flush_sites_print();

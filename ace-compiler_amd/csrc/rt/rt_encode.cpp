@@ -412,8 +412,7 @@ void Encode_plain_from_float(PLAIN plain, float* input, size_t len, uint32_t sc_
     return;
   }
   encode_device(plain, stage_to_device(input, len * sizeof(float)), 0, len, level, 0, sc_degree, 0);
-  ctx().weight_plain_cnt++;
-  ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+  count_weight_plain(plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8);
 }
 void Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t sc_degree, uint32_t level) {
   RtmScope rtm(RTM_PT_ENCODE);
@@ -422,8 +421,7 @@ void Encode_plain_from_double(PLAIN plain, double* input, size_t len, uint32_t s
     return;
   }
   encode_device(plain, stage_to_device(input, len * sizeof(double)), 1, len, level, 0, sc_degree, 0);
-  ctx().weight_plain_cnt++;
-  ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+  count_weight_plain(plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8);
 }
 
 CIPHER Encrypt(CIPHER res, PLAIN plain) {

@@ -127,7 +127,7 @@ struct Context {
   std::vector<cplx> fft_rou;      // e^{2 pi i k / 2N}
   std::vector<u32> rot_group;     // 5^i mod 2N
   // statistics
-  size_t weight_plain_cnt = 0, weight_plain_bytes = 0;
+  // (the weight-plaintext statistics of Finalize_context's report are process-wide: count_weight_plain below)
   bool keys_loaded = false, keys_strict = false;  // key set came from a container / a key missing from it is an error
   std::string keys_save_path;                    // Finalize_context writes the key set here (ACEHIP_KEYS_FILE, rt_serial.cpp)
   bool secondary = false;         // a thread's view of the primary context (shares its keys, owns its acehip_ctx)
@@ -187,6 +187,13 @@ size_t arena_live_peak_bytes();   // most bytes in live blocks so far
 size_t arena_bytes();
 // ---- which replicas of the arena the launches of this thread cover (image batches) ----
 u32 batch_size();
+// One weight plaintext of `bytes` bytes was encoded (or served from the prefetch / the cache) for the images of the calling thread's
+// launch.  The reference keeps ONE counter in its encoder, shared by all image threads (Append_weight_plain ckks_encoder.h:48-52, called
+// per image: plain_eval.c:21), and prints it at Finalize_context (context.c:111-117; parsed by scripts/perf.py:247-250): the figure is
+// per PROCESS and per IMAGE.  Here a call serves every image of the stream's batch and image streams are threads with contexts of their
+// own, so the counters are process-wide atomics and a call counts once per image it serves.
+void count_weight_plain(size_t bytes);
+void weight_plain_totals(size_t* cnt, size_t* bytes, bool reset);
 bool uniform_alloc_on();      // allocations of this thread currently come from the shared pool
 u32 current_rep0();
 u32 current_nrep();

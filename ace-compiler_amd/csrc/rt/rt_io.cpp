@@ -406,8 +406,7 @@ static PtMgr::PtEntry& pt_load(uint32_t index) {
   }
   rt::sync();  // complete before another thread's stream may read it
   poly._data = (int64_t*)ent.data;
-  c.weight_plain_cnt++;
-  c.weight_plain_bytes += words * 8;
+  rt::count_weight_plain(words * 8);
   return g_pt.pt_dev[index] = ent;
 }
 void Pt_prefetch(uint32_t pt_idx) {
@@ -594,8 +593,7 @@ static void pt_encode(PLAIN plain, uint32_t index, size_t len, uint32_t scale, u
       rt::encode_device(plain, pt_entry_dev(index, len), 0, len, level, 0, scale, 0);
     }
   }
-  rt::ctx().weight_plain_cnt++;
-  rt::ctx().weight_plain_bytes += plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8;
+  rt::count_weight_plain(plain->_poly._num_alloc_primes * (size_t)plain->_poly._ring_degree * 8);
 }
 // provider-level debug aids (rt_seal.h:90-92)
 void Dump_ciph(CIPHER ct, size_t start, size_t len) {

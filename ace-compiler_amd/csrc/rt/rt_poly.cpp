@@ -2,6 +2,7 @@
 // rt_ant API (reference: include/poly/poly_eval.h, src/poly/{poly_eval,poly_arith}.c,
 // src/ckks/cipher_eval.c:18-123, include/util/{polynomial,ciphertext}.h).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <ctime>
 #include <set>
@@ -40,7 +41,6 @@ static void attach_thread() {
   // encryption noise of this thread: its own ChaCha20 stream of the master key (test mode: a seed from seed_rng; both under shared_mu)
   if (p->drbg) c->rng.key(p->master_key, 'E', ++p->enc_streams);
   else c->rng.seed(p->seed_rng() ^ (u64)(uintptr_t)c);
-  c->weight_plain_cnt = c->weight_plain_bytes = 0;
   c->t_encode = c->t_main = c->t_issue = c->t_bootstrap = 0;
   c->n_bootstrap = 0;
   g_ctx = c;
@@ -221,6 +221,16 @@ bool uniform_alloc_on() { return g_alloc_uniform > 0; }
 u32 current_rep0() { return g_mode_rep0; }
 u32 current_nrep() { return g_mode_nrep; }
 u32 batch_size() { return g_ctx ? g_ctx->batch : 1; }
+static std::atomic<size_t> g_weight_plain_cnt{0}, g_weight_plain_bytes{0};
+void count_weight_plain(size_t bytes) {
+  const size_t images = (g_ctx && !g_ctx->shard_sim) ? g_ctx->batch : 1;  // (simulated ranks are replicas of ONE image)
+  g_weight_plain_cnt.fetch_add(images, std::memory_order_relaxed);
+  g_weight_plain_bytes.fetch_add(images * bytes, std::memory_order_relaxed);
+}
+void weight_plain_totals(size_t* cnt, size_t* bytes, bool reset) {
+  *cnt = reset ? g_weight_plain_cnt.exchange(0) : g_weight_plain_cnt.load();
+  *bytes = reset ? g_weight_plain_bytes.exchange(0) : g_weight_plain_bytes.load();
+}
 u32 selected_image() { return g_image; }
 static bool g_batch_aware = false;  // the program addresses images itself (Acehip_rt_set_batch / Acehip_rt_select_image were called)
 bool batch_aware() { return g_batch_aware; }

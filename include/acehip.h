@@ -212,7 +212,9 @@ int acehip_rescale2(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const u
 /* ---- key-switch core of the generated Rotate()/Relinearize()
  * (dataset/resnet20_cifar10_pre.onnx.inc:6972-7146; Fast_switch_key ckks_evaluator.c:391-416):
  *   out0 = Mod_down(sum_d key0[d] * Decomp_modup(in, d)),  out1 likewise with key1.
- * d_key: [num_q_parts][2][L+K][N] (Pk0_at/Pk1_at key_gen.h:66-73); d_in: level limbs; outs: level limbs. */
+ * d_key: [num_q_parts][2][L+K][N] (Pk0_at/Pk1_at key_gen.h:66-73); d_in: level limbs; outs: level limbs.
+ * d_out0 / d_out1 may be d_in (an output that overlaps the input takes the pipeline with stored accumulators, which has read the
+ * input completely before it writes); they must not overlap each other or the key. */
 int acehip_key_switch(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* d_in,
                       const uint64_t* d_key, uint32_t level, acehip_stream stream);
 
@@ -293,7 +295,9 @@ int acehip_key_inner_product(acehip_ctx* ctx, uint64_t* d_acc0, uint64_t* d_acc1
  * (*) ext[d] ), `level` limbs each.  h_ext, h_key: HOST arrays of n_digits (<= 8) device pointers -- raised digit d (level + K limbs,
  * NTT domain) and key part d ([2][L+K][N], as acehip_key_inner_product's d_key + d*2*(L+K)*N).  Results are those of
  * acehip_key_inner_product + acehip_mod_down2; at N = 2^16 the accumulators are never stored (the Mod_down passes form the sums where
- * they would load them).  acehip_keymac_fusable: 1 when that form will be used for (level, n_digits) under the current replica selection. */
+ * they would load them).  acehip_keymac_fusable: 1 when that form will be used for (level, n_digits) under the current replica selection.
+ * No aliasing: the outputs must not overlap each other, a raised digit or a key part (the last pass reads the digits while it writes
+ * the outputs): ACEHIP_EINVAL. */
 int acehip_keymac_mod_down2(acehip_ctx* ctx, uint64_t* d_out0, uint64_t* d_out1, const uint64_t* const* h_ext, const uint64_t* const* h_key,
                             uint32_t n_digits, uint32_t level, acehip_stream stream);
 int acehip_keymac_fusable(const acehip_ctx* ctx, uint32_t level, uint32_t n_digits);
@@ -404,8 +408,9 @@ int acehip_shard_encode_limbs(acehip_shard* shard, uint64_t* d_q_own, const int6
  * inside the call: every rank runs the same call sequence (SPMD), results are bit-identical to the unsharded library.
  *   acehip_ctx_shard_sim:  `world` simulated ranks in this process; rank r's limbs live in replica r of the arena
  *                          (acehip_ctx_set_arena with n_replicas >= world), exchanges are device copies.  For tests on one GPU.
- *   acehip_ctx_shard_rccl: this process is rank `rank` of `world`, one GPU each; exchanges are RCCL broadcasts from the owning
- *                          rank on the launch stream (grouped; xGMI on a node).  unique_id: the 128 bytes of acehip_rccl_unique_id()
+ *   acehip_ctx_shard_rccl: this process is rank `rank` of `world`, one GPU each; an exchange is ONE RCCL collective on a stream of
+ *                          its own (the owned limbs packed into a staging block, ncclAllGather over xGMI, unpacked on arrival;
+ *                          ACEHIP_SHARD_PACKED=0: one grouped ncclBroadcast per limb, in place).  unique_id: the 128 bytes of acehip_rccl_unique_id()
  *                          of rank 0, handed to every rank by the caller (a file, torch.distributed, MPI ...).
  * acehip_shard_gather: limbs [pos0, pos0 + n_limbs) of a polynomial become valid on every rank (decode, serialisation). */
 int      acehip_ctx_shard_sim(acehip_ctx* ctx, uint32_t world);
@@ -417,6 +422,9 @@ uint32_t acehip_shard_rank(const acehip_ctx* ctx);                  /* first hos
 uint32_t acehip_shard_owned_limbs(const acehip_ctx* ctx, uint32_t rank);   /* limbs of the full chain (L + K) rank owns */
 /* exchange statistics of this context: steps[0] = exchange steps, steps[1] = limbs moved to this process, returns bytes moved */
 uint64_t acehip_shard_traffic(const acehip_ctx* ctx, uint64_t* steps, int reset);
+/* RCCL collectives issued for the exchange steps since the last reset of acehip_shard_traffic: one per step (the limbs of a step
+ * travel packed: one ncclAllGather, or one ncclBroadcast when a single rank owns them all), one per limb with ACEHIP_SHARD_PACKED=0 */
+uint64_t acehip_shard_collectives(const acehip_ctx* ctx);
 /* The exchange schedule of one operation, for checking it without a GPU (works on a host-only context): which limb positions
  * are exchanged at each step and which rank sends them.  op: 0 ModUp of all digits, 1 ModDown, 2 Rescale, 3 ModRaise.
  * Writes up to cap entries {step, position, root rank}; returns the number of entries. */

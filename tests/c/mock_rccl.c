@@ -5,6 +5,7 @@
  * than one rank there.  This library implements the handful of entry points the product dlopen()s -- same names, same
  * signatures (rccl.h) -- on top of POSIX shared memory, so that N processes that share one GPU can act as N ranks:
  *   ncclBroadcast(root)  root: stream sync, device -> shared slot, publish;   others: wait, shared slot -> device
+ *   ncclAllGather        one such broadcast per rank and slot-sized chunk of its contribution, in rank order
  * Operations are matched by their sequence number on the communicator, exactly what RCCL requires of its callers (every rank
  * issues the same collectives in the same order with the same root and count): a rank that issues a different sequence makes
  * the test fail (root / count mismatch is checked) or time out.  Selected with ACEHIP_RCCL_LIB=<this .so>
@@ -156,5 +157,22 @@ int ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, int dataty
     if (hipMemcpy(recvbuff, s->data[slot], bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("shared -> device copy failed");
     atomic_fetch_add(&s->acks[slot], 1);
   }
+  return 0;
+}
+
+/* every rank's sendcount elements land at recvbuff + rank * sendcount on every rank (in place when sendbuff already points there):
+ * the ranks' contributions one after the other, each cut into chunks a shared slot holds */
+int ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream) {
+  Comm* c = comm;
+  const size_t bytes = sendcount * dtype_bytes(datatype);
+  if (bytes == 0) return fail("payload size not supported by the mock");
+  for (int r = 0; r < c->world; ++r)
+    for (size_t off = 0; off < bytes; off += SLOT_BYTES) {
+      const size_t n = bytes - off < SLOT_BYTES ? bytes - off : SLOT_BYTES;
+      char* dst = (char*)recvbuff + (size_t)r * bytes + off;
+      const void* src = r == c->rank ? (const char*)sendbuff + off : dst;
+      const int e = ncclBroadcast(src, dst, n, 1 /* ncclUint8 */, r, comm, stream);
+      if (e) return e;
+    }
   return 0;
 }

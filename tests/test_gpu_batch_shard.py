@@ -118,26 +118,39 @@ def _run_ranks(exe, args, world, env_extra, tmp, tag, timeout=1500, one_gpu_per_
     return outs
 
 
-@pytest.mark.parametrize("name,world", [("rotate", 2), ("relin", 3), ("bootstrap", 2), ("bootstrap_02", 3)])
-def test_reference_example_sharded_over_processes_is_bit_identical(name, world, tmp_path):
+def _exchange_counts(out):
+    """(steps, limbs, collectives) of the '[ACEHIP] limb exchanges:' line of a profiled run"""
+    line = [ln for ln in out.splitlines() if "limb exchanges:" in ln]
+    assert line, out[-2000:]
+    w = line[0].split("limb exchanges:")[1].replace(",", " ").split()
+    return int(w[0]), int(w[2]), int(w[w.index("collectives") - 1])
+
+
+@pytest.mark.parametrize("name,world,packed", [("rotate", 2, "1"), ("relin", 3, "1"), ("bootstrap", 2, "1"), ("bootstrap_02", 3, "1"), ("rotate", 2, "0"),
+                                               ("bootstrap", 3, "0")])
+def test_reference_example_sharded_over_processes_is_bit_identical(name, world, packed, tmp_path):
     """The multi-process form (one rank per process, what `torchrun` starts per GPU): ACEHIP_SHARD=1, rank 0 publishes the
     communicator id, every rank joins and the exchanges of Decomp_modup / Mod_down / Rescale / ModRaise / decode go through the
-    RCCL entry points (ncclGroupStart, ncclBroadcast from the owner, ncclGroupEnd on the exchange stream).  A test box has one
-    GPU and RCCL refuses two ranks on one device, so the entry points are served by tests/c/mock_rccl.c (shared memory; ranks
-    must issue identical sequences or the run fails).  Every rank's output ciphertext equals the unsharded run's, byte for byte."""
+    RCCL entry points on the exchange stream.  Round 6: every exchange step is ONE collective -- the owned limbs packed into a staging
+    block, one ncclAllGather (one ncclBroadcast when a single rank owns the step's limbs), the other ranks' limbs copied out on arrival
+    (packed = "1", the default; asserted: collectives == steps); packed = "0" keeps the round-5 form, one grouped ncclBroadcast per limb
+    in place (collectives == limbs moved, sent or received).  A test box has one GPU and RCCL refuses two ranks on one device, so the entry points
+    are served by tests/c/mock_rccl.c (shared memory; ranks must issue identical sequences or the run fails).  Every rank's output
+    ciphertext equals the unsharded run's, byte for byte."""
     exe = os.path.join(EX_DIR, "eg_" + name)
     _need(exe)
     mock = _mock_rccl(tmp_path)
     out0, plain = _run(exe, [], {}, tmp_path, "plain")
-    ranks = _run_ranks(exe, [], world, {"ACEHIP_RCCL_LIB": mock}, tmp_path, "mp%d" % world)
+    ranks = _run_ranks(exe, [], world, {"ACEHIP_RCCL_LIB": mock, "ACEHIP_SHARD_PACKED": packed}, tmp_path, "mp%d" % world)
     for r, (out, dumps) in enumerate(ranks):
         assert "SUCESS!" in out, out[-2000:]
         assert dumps.keys() == plain.keys()
         for k in plain:
             assert dumps[k] == plain[k], "rank %d of %d: output ciphertext %s differs from the unsharded run" % (r, world, k)
         assert "limb-sharded world %d" % world in out and "(simulated)" not in out
-        line = [ln for ln in out.splitlines() if "limb exchanges:" in ln]
-        assert line and int(line[0].split("limb exchanges:")[1].split()[0]) > 0, out[-2000:]
+        steps, limbs, coll = _exchange_counts(out)
+        assert steps > 0 and limbs > 0
+        assert (coll == steps) if packed == "1" else (coll > steps and coll >= limbs), (steps, limbs, coll)
 
 
 def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
@@ -151,6 +164,8 @@ def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
     ranks = _run_ranks(exe, ["1"], 2, dict(env, ACEHIP_RCCL_LIB=mock), tmp_path, "mp2")
     for r, (out, dumps) in enumerate(ranks):
         assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 output differs from the unsharded run" % r
+        steps, limbs, coll = _exchange_counts(out)
+        assert coll == steps and limbs > 3 * steps, (steps, limbs, coll)  # one collective per exchange step, several limbs per step
     # sharded AND batched: two images per launch on every rank (every exchange then moves both images' limbs)
     ranks = _run_ranks(exe, ["2"], 2, dict(env, ACEHIP_RCCL_LIB=mock, MODEL_BATCH="2"), tmp_path, "mp2b2")
     for r, (out, dumps) in enumerate(ranks):

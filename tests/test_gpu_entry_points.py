@@ -391,6 +391,10 @@ def test_keymac_mod_down2_matches_inner_product_then_mod_down(env):
     finally:
         rt.lib.acehip_debug_set_kmac_fuse(old)
     assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r0.ptr, h_ext, h_key, nd, level, None) < 0
+    # no aliasing (include/acehip.h): the last pass reads the digits while it writes the outputs
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r0.at(N), h_ext, h_key, nd, level, None) < 0          # outputs overlap
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, de[0].ptr, r1.ptr, h_ext, h_key, nd, level, None) < 0         # out0 = a raised digit
+    assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, de[nd - 1].at(K * N), h_ext, h_key, nd, level, None) < 0  # out1 inside a digit
     assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, 0, level, None) < 0
     assert rt.lib.acehip_keymac_mod_down2(rt.h, r0.ptr, r1.ptr, h_ext, h_key, nd, o.L + 1, None) < 0
     for d in [dk, pad, r0, r1] + de:
@@ -410,6 +414,21 @@ def test_key_switch_with_the_inner_product_inside_mod_down(env):
             rt.lib.acehip_debug_set_kmac_fuse(mode)
             g0, g1 = rt.key_switch(a, key, level)
             assert np.array_equal(g0, w0) and np.array_equal(g1, w1), mode
+            # in place (d_out0 or d_out1 = d_in, allowed by include/acehip.h): the fused last pass reads the input while it writes the
+            # outputs, so an aliased call must take the pipeline with stored accumulators -- same bits
+            N = o.N
+            dk = rt.to_device(key)
+            for which in (0, 1):
+                da, other = rt.to_device(a), rt.buf(level * N)
+                outs = (da.ptr, other.ptr) if which == 0 else (other.ptr, da.ptr)
+                rt.check(rt.lib.acehip_key_switch(rt.h, outs[0], outs[1], da.ptr, dk.ptr, level, None))
+                got = (da.download((level, N)), other.download((level, N)))
+                if which == 1:
+                    got = got[::-1]
+                assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), (mode, which)
+                da.free()
+                other.free()
+            dk.free()
     finally:
         rt.lib.acehip_debug_set_kmac_fuse(old)
 
@@ -462,3 +481,74 @@ def test_key_inner_products_over_the_same_digits(env):
             dk.free()
     de.free()
     dc.free()
+
+
+@pytest.mark.parametrize("cfg", [(4096, 6, 60, 50, 3, 6), (65536, 5, 51, 50, 2, 4)], ids=["n4096", "n65536"])
+def test_key_inner_products_with_key_sets_inside_the_replicated_arena(cfg):
+    """acehip_key_inner_products walks several rotation keys over one set of raised digits and reads every key part ONCE for all images of a
+    launch -- right for keys outside the replicated arena (shared by all images; every caller of the shim allocates them there).  A key set
+    INSIDE the arena is a different key per replica: such launches must take the single-key kernels, which rebase the key per replica
+    (round-5 review: this used to give wrong sums silently).  Two replicas, three rotations, every block (digits, keys, outputs) inside the
+    arena with different contents per replica; expected = the no-arena calls on plain buffers."""
+    from ace_compiler_amd.binding import ArenaCfg
+
+    N, L, q0, sf, dnum, level = cfg
+    o = O.Oracle(N, L, q0, sf, dnum)
+    rt = A.AceHip(N, L, q0, sf, dnum)
+    try:
+        K = o.K
+        nd = o.num_decomp(level)
+        E, T = level + K, L + K
+        n_keys, n_rep = 3, 2
+        key_words, ext_words, acc_words = nd * 2 * T * N, nd * E * N, E * N
+        ext = [np.stack([o.uniform(E, level, 1760 + 10 * r + d) for d in range(nd)]) for r in range(n_rep)]
+        keys = [[o.make_key(1800 + 100 * r + 10 * j) for j in range(n_keys)] for r in range(n_rep)]
+        # expected: plain buffers, one call per key (the single-key entry point is checked against the oracle in test_key_inner_product)
+        want = []
+        for r in range(n_rep):
+            de = rt.to_device(ext[r])
+            a0, a1 = rt.buf(acc_words), rt.buf(acc_words)
+            row = []
+            for j in range(n_keys):
+                dk = rt.to_device(keys[r][j])
+                rt.check(rt.lib.acehip_key_inner_product(rt.h, a0.ptr, a1.ptr, dk.ptr, de.ptr, level, None))
+                row.append((a0.download((E, N)), a1.download((E, N))))
+                dk.free()
+            want.append(row)
+            for d in (de, a0, a1):
+                d.free()
+        rt.lib.acehip_workspace_words.restype = C.c_size_t
+        ws_words = rt.lib.acehip_workspace_words(rt.h)
+        gran = lambda w: (w + 31) // 32 * 32  # noqa: E731
+        off, cur = {}, 0
+        for name, words in [("ws", ws_words), ("sc", 2 * N), ("ext", ext_words)] + [("key%d" % j, key_words) for j in range(n_keys)] + \
+                [("a0_%d" % j, acc_words) for j in range(n_keys)] + [("a1_%d" % j, acc_words) for j in range(n_keys)]:
+            off[name] = cur
+            cur += gran(words)
+        rep_words = cur
+        arena = rt.buf(rep_words * n_rep)
+        for r in range(n_rep):
+            base = r * rep_words
+            rt.check(rt.lib.acehip_memcpy_h2d(arena.at(base + off["ext"]), np.ascontiguousarray(ext[r]).ctypes.data, ext_words * 8, None))
+            for j in range(n_keys):
+                kk = np.ascontiguousarray(keys[r][j])
+                rt.check(rt.lib.acehip_memcpy_h2d(arena.at(base + off["key%d" % j]), kk.ctypes.data, key_words * 8, None))
+        acfg = ArenaCfg(arena.ptr, rep_words * 8, rep_words * 8, n_rep, arena.at(off["ws"]), arena.at(off["sc"]), 2)
+        rt.check(rt.lib.acehip_ctx_set_arena(rt.h, C.byref(acfg)))
+        rt.check(rt.lib.acehip_ctx_select(rt.h, 0, n_rep))
+        h0 = (C.c_void_p * n_keys)(*[arena.at(off["a0_%d" % j]) for j in range(n_keys)])
+        h1 = (C.c_void_p * n_keys)(*[arena.at(off["a1_%d" % j]) for j in range(n_keys)])
+        hk = (C.c_void_p * n_keys)(*[arena.at(off["key%d" % j]) for j in range(n_keys)])
+        rt.check(rt.lib.acehip_key_inner_products(rt.h, h0, h1, hk, n_keys, arena.at(off["ext"]), level, None, None, None))
+        got = arena.download((n_rep, rep_words))
+        for r in range(n_rep):
+            for j in range(n_keys):
+                g0 = got[r, off["a0_%d" % j]:off["a0_%d" % j] + acc_words].reshape(E, N)
+                g1 = got[r, off["a1_%d" % j]:off["a1_%d" % j] + acc_words].reshape(E, N)
+                assert np.array_equal(g0, want[r][j][0]), (r, j)
+                assert np.array_equal(g1, want[r][j][1]), (r, j)
+        rt.check(rt.lib.acehip_ctx_select(rt.h, 0, 1))
+        arena.free()
+    finally:
+        rt.close()
+        o.close()

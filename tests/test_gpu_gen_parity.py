@@ -153,9 +153,13 @@ def test_resnet20_batches_of_3_and_12_and_three_threads_match_the_reference(tmp_
     (tools/model_main_omp.c, the reference's own main structure, resnet_cifar.main.inc:77-116), each running that image: three times
     the reference's digest."""
     env = _model_env()
-    _, d1 = _run(MODEL_EXE, ["12"], env, tmp_path, "b1", timeout=1500)
-    _, d3 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="3"), tmp_path, "b3", timeout=1500)
-    _, d12 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="12"), tmp_path, "b12", timeout=1500)
+    o1, d1 = _run(MODEL_EXE, ["12"], env, tmp_path, "b1", timeout=1500)
+    o3, d3 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="3"), tmp_path, "b3", timeout=1500)
+    o12, d12 = _run(MODEL_EXE, ["12"], dict(env, MODEL_BATCH="12"), tmp_path, "b12", timeout=1500)
+    # the reference's stdout contract in the benchmarked mode (context.c:103-116, parsed by scripts/perf.py:242-250): one counter per
+    # process, one count per image and weight plaintext -- 12 images x 6 044 whatever carries them (one by one, batches, prefetch)
+    for out in (o1, o3, o12):
+        assert "rot_key_cnt = 227," in out and "Total memory size for weight plain: cnt = %d," % (12 * 6044) in out, out[-1500:]
     assert d1["0.0"] == MODEL["outputs"]["0.0"]
     assert len(set(d1.values())) == 12
     for i in range(12):
@@ -168,6 +172,7 @@ def test_resnet20_batches_of_3_and_12_and_three_threads_match_the_reference(tmp_
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     files = sorted(glob.glob(prefix + ".img*"))
     assert len(files) == 3 and all(_sha(f) == MODEL["outputs"]["0.0"] for f in files)
+    assert "Total memory size for weight plain: cnt = %d," % (3 * 6044) in r.stdout, r.stdout[-1500:]  # image THREADS: still one counter
 
 
 def test_resnet20_batch_issued_in_replica_groups_matches_the_reference(tmp_path):
@@ -180,22 +185,30 @@ def test_resnet20_batch_issued_in_replica_groups_matches_the_reference(tmp_path)
     assert grouped == plain and len(set(plain.values())) == 12
 
 
-def test_resnet20_logits_with_independent_keys_agree_to_ckks_precision(tmp_path):
+def test_resnet20_logits_with_independent_keys_agree_to_ckks_precision(tmp_path, capsys):
     """the tolerance-level check, with digits: OUR fresh keys and encryption randomness (no seed: a new ChaCha20 master key from the OS
     every run), same weights and image -- the logits agree with the reference's to 2.5e-2 of the largest one.  Independent keys mean
     independent CKKS noise: every one of the 19 bootstraps adds about 1.2e-3 at this parameter set on either runtime
     (profiles/r01m_bootstrap_precision.md), i.e. 5e-3 absolute as a random walk and 2.3e-2 at worst on logits up to 0.44; measured on
     single draws 2.3e-3 (round 4) and 7.2e-3 (round 5) of the largest logit.  The bound has to hold for EVERY draw of the keys, so it sits
     at five times the random-walk figure -- and a single wrong rotation misses it by more than a factor of ten (asserted by the next test).  The bit-level statement
-    is the test above."""
+    is the test above.  Round 6 (review of round 5): the worst-case bound alone would let a bias or noise regression of the ChaCha20-keyed
+    samplers pass until it reached 2.5e-2, so THREE independent draws are made and their MEDIAN error must also stay within 1.5e-2 -- about
+    twice the largest single draw measured so far; the three figures are printed into the test log."""
     env = dict(os.environ, **_model_env())
     env.pop("MODEL_ENC_SEED")
     env.pop("ACEHIP_SEED", None)
-    r = subprocess.run([MODEL_EXE, "1"], capture_output=True, text=True, timeout=1200, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = [float(x) for x in _logits9(r.stdout)[0]]
     scale = max(abs(v) for v in MODEL["logits9"])
-    assert max(abs(a - b) for a, b in zip(got, MODEL["logits9"])) <= 2.5e-2 * scale, (got, MODEL["logits9"])
+    errs = []
+    for _ in range(3):
+        r = subprocess.run([MODEL_EXE, "1"], capture_output=True, text=True, timeout=1200, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got = [float(x) for x in _logits9(r.stdout)[0]]
+        errs.append(max(abs(a - b) for a, b in zip(got, MODEL["logits9"])) / scale)
+    with capsys.disabled():
+        print("\n[independent keys] max |logit - reference| / largest logit over three draws: %s" % " ".join("%.2e" % e for e in errs))
+    assert max(errs) <= 2.5e-2, errs
+    assert sorted(errs)[1] <= 1.5e-2, errs
 
 
 def test_a_single_changed_rotation_is_caught(tmp_path, capsys):

@@ -203,3 +203,19 @@ def test_matrix_core_conversion_tables_reproduce_the_exact_sums(params):
                     assert all(off[j * 9 + b] == 0 for b in range(9))
     finally:
         rt.close()
+
+
+def test_library_fingerprint_covers_the_compile_flags(monkeypatch):
+    """The fingerprint both libraries embed is the staleness gate of needs_build / load_library / Prepare_context.  It covers the sources AND
+    the effective compile flags: a library an experiment script built with ACEHIP_EXTRA_HIPCC_FLAGS (kernels that give wrong results:
+    -DNTT_EXP, -DACEHIP_ABLATION ...) must not pass for a clean build of the same sources in a process that does not carry those flags."""
+    import sys
+
+    bmod = sys.modules["ace_compiler_amd.build"]
+    monkeypatch.delenv("ACEHIP_EXTRA_HIPCC_FLAGS", raising=False)
+    clean = bmod.source_fingerprint()
+    assert bmod.embedded_fingerprint(bmod.LIB) == clean and not bmod.needs_build()
+    assert A.load_library().acehip_source_fingerprint().decode() == clean
+    monkeypatch.setenv("ACEHIP_EXTRA_HIPCC_FLAGS", "-DNTT_EXP=1")
+    assert bmod.source_fingerprint() != clean
+    assert bmod.needs_build()  # the clean library in the tree is stale for a process that asks for experiment flags, and vice versa

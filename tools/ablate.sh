@@ -1,7 +1,7 @@
 #!/bin/bash
 # Throughput sensitivity of the headline workload to each kernel family: run on the GPU box after building
 # an ablation library on the dev container:
-#   ACEHIP_EXTRA_HIPCC_FLAGS=-DACEHIP_ABLATION python ace-compiler_amd/build.py --force && cp ace-compiler_amd/lib/libacehip.so gpurun_exp/libacehip_ablate.so
+#   . tools/exp_build.sh; exp_build -DACEHIP_ABLATION   (the flags are part of the library fingerprint: keep them exported for the runs)
 #   python ace-compiler_amd/build.py --force        # restore the product library
 #   gpurun -- 'bash tools/ablate.sh'
 # $ACEHIP_ABLATE is the bit mask of families whose launches are skipped (kernels.hpp AblateFamily): results are wrong by

@@ -6,10 +6,11 @@ set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
+. tools/exp_build.sh
 export ACEHIP_BENCH_NO_VERIFY=1
 OUT=gpurun_out/${TAG}_ablate.txt
 : > $OUT
-ACEHIP_EXTRA_HIPCC_FLAGS="-DACEHIP_ABLATION" python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1 || { echo "build failed"; exit 1; }
+exp_build "-DACEHIP_ABLATION" || { echo "build failed"; exit 1; }
 for m in "$@"; do
   ACEHIP_ABLATE=$m timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-verify --no-shard-leg --steps 2 --warmup 1 ${AB_ARGS:-} > gpurun_out/${TAG}_abl$m.json 2> gpurun_out/${TAG}_abl$m.err
   python3 -c "
@@ -18,5 +19,5 @@ d=json.load(open('gpurun_out/${TAG}_abl$m.json'))
 print('ABLATE $m:', 'images/s', d['value'], 'ms/step', d['ms_per_step'])" >> $OUT 2>&1
   echo "mask $m done"
 done
-python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1
+exp_restore
 cat $OUT

@@ -5,12 +5,13 @@ set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
+. tools/exp_build.sh
 OUT=gpurun_out/${TAG}_flag_ab.txt
 : > $OUT
 i=0
 for flags in "$@"; do
   i=$((i + 1))
-  ACEHIP_EXTRA_HIPCC_FLAGS="$flags" python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1 || { echo "[$flags] build failed" >> $OUT; continue; }
+  exp_build "$flags" || { echo "[$flags] build failed" >> $OUT; continue; }
   timeout -k 10 400 python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/${TAG}_flag$i.json 2> gpurun_out/${TAG}_flag$i.err
   python3 -c "
 import json
@@ -18,5 +19,5 @@ d=json.load(open('gpurun_out/${TAG}_flag$i.json'))
 print('[$flags]', 'images/s', d['value'], 'ms/step', d['ms_per_step'])" >> $OUT 2>&1
   echo "variant $i done"
 done
-python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1
+exp_restore
 cat $OUT

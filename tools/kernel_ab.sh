@@ -7,12 +7,13 @@ set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
+. tools/exp_build.sh
 OUT=gpurun_out/${TAG}_kernel_ab.txt
 : > $OUT
 i=0
 for flags in "$@"; do
   i=$((i + 1))
-  ACEHIP_EXTRA_HIPCC_FLAGS="$flags" python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1 || { echo "[$flags] build failed" >> $OUT; continue; }
+  exp_build "$flags" || { echo "[$flags] build failed" >> $OUT; continue; }
   bash tools/prof_model.sh ${TAG}_v$i 24 12 > /dev/null 2>&1
   python3 - "$flags" gpurun_out/${TAG}_v${i}_model_kernel_stats.csv >> $OUT <<'PY'
 import csv, sys
@@ -26,5 +27,5 @@ print("[%s]" % sys.argv[1], " ".join("%s %.3f" % kv for kv in sorted(fam.items()
 PY
   echo "variant $i done"
 done
-python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1
+exp_restore
 cat $OUT

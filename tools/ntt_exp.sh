@@ -6,15 +6,16 @@ set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
+. tools/exp_build.sh
 OUT=gpurun_out/${TAG}_ntt_exp.txt
 : > $OUT
 for e in 0 "$@"; do
-  ACEHIP_EXTRA_HIPCC_FLAGS="-DNTT_EXP=$e" python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1 || { echo "build failed for $e" >> $OUT; continue; }
+  exp_build "-DNTT_EXP=$e" || { echo "build failed for $e" >> $OUT; continue; }
   ACEHIP_BENCH_NO_VERIFY=1 python3 bench.py --roofline-only --no-cpu-baseline 2> gpurun_out/${TAG}_exp$e.err | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('NTT_EXP=$e', 'fwd_ms', r.get('launch_ms'), 'inv_ms', r.get('inverse_launch_ms'), 'achieved', r.get('achieved'), 'frac', r.get('frac'))" >> $OUT 2>&1
   echo "variant $e done"
 done
-python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1
+exp_restore
 cat $OUT

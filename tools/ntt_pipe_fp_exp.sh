@@ -6,6 +6,7 @@ set -u
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
+. tools/exp_build.sh
 OUT=gpurun_out/${TAG}_ntt_pipe_fp_exp.txt
 : > $OUT
 run() {  # label, env...
@@ -19,9 +20,9 @@ print('$label', 'fwd_ms', r.get('launch_ms'), 'inv_ms', r.get('inverse_launch_ms
 }
 run "product PIPE=0" ACEHIP_NTT_PIPE=0
 for wg in 4 3; do
-  ACEHIP_EXTRA_HIPCC_FLAGS="-DNTT_PIPE_T4=1 -DNTT_PIPE_FP_ONLY -DNTT_PIPE_WG=$wg" python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1 || echo "build failed" >> $OUT
+  exp_build "-DNTT_PIPE_T4=1 -DNTT_PIPE_FP_ONLY -DNTT_PIPE_WG=$wg" || echo "build failed" >> $OUT
   run "fp-only WG=$wg PIPE=2" ACEHIP_NTT_PIPE=2
   run "fp-only WG=$wg PIPE=4" ACEHIP_NTT_PIPE=4
 done
-python3 -c "import ace_compiler_amd as A; A.build(force=True)" > /dev/null 2>&1
+exp_restore
 cat $OUT
