@@ -727,8 +727,13 @@ void launch_bsgs_inner(const DevCtx& c, const BsgsArgs& a, u32 level, hipStream_
     for (u32 t = 0; t < a.g * a.b && shared; ++t) shared = !((u64)a.pt[t] - c.rep_lo < c.rep_span);
     if (shared) {
       dim3 grid((c.N / 64) * (level + c.K));
-      for (u32 r0 = 0; r0 < c.nrep; r0 += 16) {
-        const u32 cnt = std::min(16u, c.nrep - r0);
+      // ACEHIP_BSGS_WG_IMAGES: images (= waves) per workgroup, default 16 = the whole batch in one workgroup.  A 12-wave workgroup needs
+      // three wave slots with 128 registers on EVERY SIMD of one CU at once: next to the kernels of other image streams it waits for a CU
+      // to drain (8.3 x its standalone time in the three-stream trace of round 5); smaller groups fit sooner and stage the diagonals
+      // once per group.  Measured: profiles/r06g_*.
+      static const u32 wg_images = [] { const char* e = getenv("ACEHIP_BSGS_WG_IMAGES"); const u32 v = e ? (u32)atoi(e) : 16u; return v >= 1 && v <= 16 ? v : 16u; }();
+      for (u32 r0 = 0; r0 < c.nrep; r0 += wg_images) {
+        const u32 cnt = std::min(wg_images, c.nrep - r0);
         hipLaunchKernelGGL((bsgs_inner_reps_kernel<16>), grid, dim3(64 * cnt), 0, s, c, a, level, r0);
       }
       return;
