@@ -40,6 +40,8 @@ SYMBOLS = [
     ("acehip_memcpy_d2h", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_memcpy_d2d", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     ("acehip_memset", C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
+    ("acehip_malloc_limbs", _vp, [_vp, _vp, C.c_size_t]),
+    ("acehip_limb_memory", None, [_vp, _vp]),
     ("acehip_malloc_host", _vp, [C.c_size_t]),
     ("acehip_free_host", C.c_int, [_vp]),
     ("acehip_memcpy_h2d_async", C.c_int, [_vp, _vp, C.c_size_t, _vp]),

@@ -393,6 +393,152 @@ int acehip_copy(acehip_ctx* c, void* d, const void* src, size_t n, acehip_stream
   });
 }
 
+// ---- owner-only limb memory (limb-sharded execution, one process per rank) -------------------------------------------------------------
+// Switch keys are 77 % of a rank's HBM (227 keys x 135 MiB for the generated ResNet-20) and a rank of G only ever touches the limbs
+// whose prime it owns (gi % G == rank) -- but generated code addresses key limbs itself (`Coeffs(key, i, degree)` = base + i * N), so the
+// full reference layout must stay ADDRESSABLE.  HIP's virtual memory management gives exactly that: the whole block is one reserved
+// address range, every owned limb gets physical memory of its own, and every other limb position is a mapping of ONE shared "sink"
+// limb -- a stray access to a limb the rank does not own lands there (garbage, as in the simulated ranks' replicas, never a fault).
+// Falls back to a plain allocation where the driver lacks the feature or a limb is not a multiple of its granularity.
+// ACEHIP_SHARD_OWNER_LIMBS=1 switches it on (default: plain allocations; see owner_only_on for what the driver charges).
+namespace {
+struct LimbBlock {
+  size_t bytes = 0, limb_bytes = 0, n_limbs = 0;
+  std::vector<hipMemGenericAllocationHandle_t> own;
+};
+std::mutex g_limb_mu;
+std::map<void*, LimbBlock> g_limb_blocks;
+struct SinkKey {
+  int dev;
+  size_t bytes;
+  bool operator<(const SinkKey& o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
+};
+std::map<SinkKey, hipMemGenericAllocationHandle_t> g_limb_sinks;  // one per device and limb size, for the life of the process
+std::map<void*, size_t> g_limb_plain;  // acehip_malloc_limbs blocks that are plain allocations (statistics only)
+std::atomic<u64> g_limb_backed{0}, g_limb_addressed{0};
+bool owner_only_on() {
+  // opt-in: on ROCm 7.2 / MI355X a mapping cannot start inside a physical handle (hipMemMap with an offset: invalid argument), so every
+  // owned limb needs a handle of its own, and a 512 KiB handle occupies 2 MiB and takes 0.2-0.6 ms to map (tools/ubench_vmm.hip,
+  // profiles/r06m_vmm_probe.txt): a rank of 8 holds half of the key bytes instead of an eighth, a rank of 4 saves nothing
+  static const bool on = [] { const char* e = getenv("ACEHIP_SHARD_OWNER_LIMBS"); return e && atoi(e) != 0; }();
+  return on;
+}
+// true: p was one of ours and is gone
+bool limb_block_free(void* p) {
+  LimbBlock b;
+  {
+    std::lock_guard<std::mutex> lk(g_limb_mu);
+    auto pl = g_limb_plain.find(p);
+    if (pl != g_limb_plain.end()) {  // a plain allocation: only the statistics are ours
+      g_limb_backed -= pl->second;
+      g_limb_addressed -= pl->second;
+      g_limb_plain.erase(pl);
+      return false;
+    }
+    auto it = g_limb_blocks.find(p);
+    if (it == g_limb_blocks.end()) return false;
+    b = std::move(it->second);
+    g_limb_blocks.erase(it);
+  }
+  (void)hipDeviceSynchronize();  // (hipFree synchronises too: nothing may still run on the range)
+  for (size_t k = 0; k < b.n_limbs; ++k) (void)hipMemUnmap((char*)p + k * b.limb_bytes, b.limb_bytes);
+  for (auto h : b.own) (void)hipMemRelease(h);
+  (void)hipMemAddressFree(p, b.bytes);
+  g_limb_backed -= (u64)b.own.size() * b.limb_bytes;
+  g_limb_addressed -= b.bytes;
+  return true;
+}
+void* limb_block_alloc(const acehip_ctx* c, const uint32_t* gi, size_t n_limbs) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  int vmm = 0;
+  if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess || !vmm) return nullptr;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  const size_t limb = (size_t)c->hp.N * sizeof(u64);
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0 || limb % gran) return nullptr;
+  std::lock_guard<std::mutex> lk(g_limb_mu);
+  hipMemGenericAllocationHandle_t sink;
+  auto st = g_limb_sinks.find(SinkKey{dev, limb});
+  if (st != g_limb_sinks.end()) sink = st->second;
+  else {
+    if (hipMemCreate(&sink, limb, &prop, 0) != hipSuccess) return nullptr;
+    g_limb_sinks[SinkKey{dev, limb}] = sink;
+  }
+  void* base = nullptr;
+  const size_t bytes = limb * n_limbs;
+  if (hipMemAddressReserve(&base, bytes, 0, nullptr, 0) != hipSuccess) return nullptr;
+  LimbBlock b;
+  b.bytes = bytes;
+  b.limb_bytes = limb;
+  b.n_limbs = n_limbs;
+  size_t mapped = 0;
+  bool ok = true;
+  for (; mapped < n_limbs && ok; ++mapped) {
+    void* at = (char*)base + mapped * limb;
+    if (gi[mapped] % c->sh_world == c->sh_hosted[0]) {  // (one process per rank: the one hosted rank)
+      hipMemGenericAllocationHandle_t h;
+      ok = hipMemCreate(&h, limb, &prop, 0) == hipSuccess;
+      if (ok) {
+        b.own.push_back(h);
+        ok = hipMemMap(at, limb, 0, h, 0) == hipSuccess;
+      }
+    } else {
+      ok = hipMemMap(at, limb, 0, sink, 0) == hipSuccess;
+    }
+    if (!ok) break;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  ok = ok && hipMemSetAccess(base, bytes, &acc, 1) == hipSuccess;
+  if (!ok) {  // undo: the caller falls back to a plain allocation
+    (void)hipGetLastError();
+    for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap((char*)base + k * limb, limb);
+    for (auto h : b.own) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(base, bytes);
+    return nullptr;
+  }
+  g_limb_backed += (u64)b.own.size() * limb;
+  g_limb_addressed += bytes;
+  g_limb_blocks[base] = std::move(b);
+  return base;
+}
+}  // namespace
+
+extern "C" void* acehip_malloc_limbs(acehip_ctx* c, const uint32_t* h_gi, size_t n_limbs) {
+  if (!c || !h_gi || n_limbs == 0) {
+    acehip_err_slot() = "acehip_malloc_limbs: bad arguments";
+    return nullptr;
+  }
+  for (size_t k = 0; k < n_limbs; ++k)
+    if (h_gi[k] >= c->hp.L + c->hp.K) {
+      acehip_err_slot() = "acehip_malloc_limbs: prime index out of range";
+      return nullptr;
+    }
+  const size_t bytes = (size_t)c->hp.N * sizeof(u64) * n_limbs;
+  if (c->on_device && c->sh_world > 1 && c->rccl != nullptr && owner_only_on()) {
+    if (void* p = limb_block_alloc(c, h_gi, n_limbs)) return p;
+    static std::atomic<bool> told{false};
+    if (!told.exchange(true)) fprintf(stderr, "[acehip] owner-only limb memory is not available here (HIP virtual memory management / granularity): full allocations\n");
+  }
+  void* p = acehip_malloc(bytes);
+  if (p) {
+    g_limb_backed += bytes;
+    g_limb_addressed += bytes;
+    std::lock_guard<std::mutex> lk(g_limb_mu);
+    g_limb_plain[p] = bytes;
+  }
+  return p;
+}
+extern "C" void acehip_limb_memory(uint64_t* backed_bytes, uint64_t* addressed_bytes) {
+  if (backed_bytes) *backed_bytes = g_limb_backed.load();
+  if (addressed_bytes) *addressed_bytes = g_limb_addressed.load();
+}
+
 // ---- memory helpers ----
 void* acehip_malloc(size_t bytes) {
   void* p = nullptr;
@@ -406,6 +552,7 @@ void* acehip_malloc(size_t bytes) {
   return p;
 }
 int acehip_free(void* p) {
+  if (limb_block_free(p)) return ACEHIP_OK;  // memory of acehip_malloc_limbs (below)
   HIP_TRY(hipFree(p));
   return ACEHIP_OK;
 }

@@ -628,20 +628,37 @@ __device__ __forceinline__ void strided_inv_body_fp(u64* __restrict__ X, const d
 // arithmetic instead of under the other workgroups' of the CU.  Same butterflies in the same order on the same values as the
 // one-tile bodies above: bit-identical results (tests force both forms).  Costs 3 instead of 4 workgroups per CU in registers.
 // ------------------------------------------------------------------------------------------------
+// keeps the compiler from hoisting the twiddle re-derivation (tw_of) out of the tile walk: the derived twiddles are loop invariant, and
+// kept resident they are the 60 registers the companion-only form is there to avoid
+__device__ __forceinline__ void pin_tp(Tp15& t) {
+  ACEHIP_PIN(t.p0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ACEHIP_PIN(t.p1[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ACEHIP_PIN(t.p2[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ACEHIP_PIN(t.p3[i]);
+}
+#ifndef NTT_PIPE_PREFETCH
+#define NTT_PIPE_PREFETCH 1  // 0 (experiment): the walk keeps the twiddles but loads every tile when its turn comes -- no second register set
+#endif
+// (integer classes: the per-lane twiddles of stages 4..7 stay resident in their companion-only form -- 30 registers instead of 60, the
+//  twiddle re-derived where it is used, radix16_fwd_p -- or they would not fit beside round A's temporaries at four workgroups per CU)
 template <bool SMALL, int T>
-__device__ __forceinline__ void strided_fwd_pipe_body(const StridedArgs& a) {
+__device__ __forceinline__ void strided_fwd_pipe_body(const StridedArgs& a, const u64* __restrict__ TP) {
   const BfK bk = bf_consts<SMALL>(a.q);
   u64 x[16], xn[16];
-  Tw u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  Tw u0, u1[2], u2[4], u3[8];
+  Tp15 tp;
   asm volatile("" ::: "memory");
   const u32 vld = (a.hg << 11) + a.col * 8, vst = (a.hg << 15) + a.col * 8;
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = bld(a.buf, vld, (u32)k << 15);
   load_tw_uniform<SMALL>(a.TW, u0, u1, u2, u3);
-  load_tw<SMALL>(a.TW, 4, a.hg, t0, t1, t2, t3);
+  load_tp(TP, 4, a.hg, tp);
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) {
+    if (NTT_PIPE_PREFETCH && t + 1 < T) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) xn[k] = bld(a.buf, vld + 128u * (u32)(t + 1), (u32)k << 15);
     }
@@ -652,12 +669,13 @@ __device__ __forceinline__ void strided_fwd_pipe_body(const StridedArgs& a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = a.lds[(16 * a.hg + k) * kRowPitch + a.cc];
     if (t + 1 < T) __syncthreads();  // the next tile's round A writes the LDS tile again
-    radix16_fwd<SMALL>(x, t0, t1, t2, t3, bk);
+    pin_tp(tp);
+    radix16_fwd_p<SMALL>(x, tp, bk);
 #pragma unroll
     for (int k = 0; k < 16; ++k) bst(a.buf, vst + 128u * (u32)t, (u32)k << 11, x[k]);
     if (t + 1 < T) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = xn[k];
+      for (int k = 0; k < 16; ++k) x[k] = NTT_PIPE_PREFETCH ? xn[k] : bld(a.buf, vld + 128u * (u32)(t + 1), (u32)k << 15);
     }
   }
   asm volatile("" ::: "memory");
@@ -677,7 +695,7 @@ __device__ __forceinline__ void strided_fwd_pipe_body_fp(const StridedArgs& a) {
   for (int t = 0; t < T; ++t) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = fp_from_u64(xn[i]);  // canonical residues
-    if (t + 1 < T) {
+    if (NTT_PIPE_PREFETCH && t + 1 < T) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) xn[i] = bld(a.buf, vld + 128u * (u32)(t + 1), (u32)i << 15);
     }
@@ -691,23 +709,31 @@ __device__ __forceinline__ void strided_fwd_pipe_body_fp(const StridedArgs& a) {
     fp_radix16_fwd(x, t0, t1, t2, t3, k);
 #pragma unroll
     for (int i = 0; i < 16; ++i) bst(a.buf, vst + 128u * (u32)t, (u32)i << 11, fp_bits(x[i]));
+    if (!NTT_PIPE_PREFETCH && t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = bld(a.buf, vld + 128u * (u32)(t + 1), (u32)i << 15);
+    }
   }
   asm volatile("" ::: "memory");
 }
 
 // inverse, pipelined: tiles walked like the forward form; X = the limb, col = the first tile's column of this lane
 template <bool SMALL, int T>
-__device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const ulong2* __restrict__ TW, u64* lds, const DevPrime& P,
-                                                      const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
-  constexpr u32 log_s = 8;
+__device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const ulong2* __restrict__ TW, const u64* __restrict__ TP, u64* lds,
+                                                      const DevPrime& P, const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
   const u64 q = P.q;
   const BfK bk = bf_consts<SMALL>(q);
   u64 x[16], xn[16];
-  Tw u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
+  Tw u0, u1[2], u2[4], u3[8];
+  Tp15 tp;
   asm volatile("" ::: "memory");
+  // (buffer addressing like the forward pass: one address register for the 16 rows of a lane instead of 16 pointer pairs -- which a loop
+  //  over tiles would keep resident)
+  const LimbBuf buf = limb_buf(X, 8u << 16);
+  const u32 vld = (hg << 15) + col * 8, vst = (hg << 11) + col * 8;  // rows 16 hg + k (2 KiB apart) / rows 16 k + hg (32 KiB apart)
 #pragma unroll
-  for (int k = 0; k < 16; ++k) x[k] = ntld(&X[((size_t)(16 * hg + k) << log_s) + col]);
-  load_tw<SMALL>(TW, 4, hg, t0, t1, t2, t3);
+  for (int k = 0; k < 16; ++k) x[k] = bld(buf, vld, (u32)k << 11);
+  load_tp(TP, 4, hg, tp);
   load_tw_uniform<SMALL>(TW, u0, u1, u2, u3);
   Tw tn{P.n_inv, P.n_inv_prec}, tw{P.inv_w1_ninv, P.inv_w1_ninv_prec};
   if (f.inv_scale) {
@@ -715,14 +741,16 @@ __device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const
     tn = Tw{sc[0], sc[1]};
     tw = Tw{sc[2], sc[3]};
   }
+  tn = Tw{uniform64(tn.w), uniform64(tn.p)};  // (the same for every lane: scalar registers over the walk)
+  tw = Tw{uniform64(tw.w), uniform64(tw.p)};
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) {
+    if (NTT_PIPE_PREFETCH && t + 1 < T) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) xn[k] = ntld(&X[((size_t)(16 * hg + k) << log_s) + col + 16u * (u32)(t + 1)]);
+      for (int k = 0; k < 16; ++k) xn[k] = bld(buf, vld + 128u * (u32)(t + 1), (u32)k << 11);
     }
-    radix16_inv_321<SMALL>(x, t1, t2, t3, bk);
-    radix16_inv_0<SMALL>(x, t0, bk);
+    pin_tp(tp);
+    radix16_inv_p<SMALL>(x, tp, bk);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[(16 * hg + k) * kRowPitch + cc] = x[k];
     __syncthreads();
@@ -744,10 +772,10 @@ __device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const
       for (int k = 0; k < 16; ++k) x[k] = x[k] > half ? x[k] - q : x[k];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) ntst(&X[((size_t)(16 * k + hg) << log_s) + col + 16u * (u32)t], x[k]);
+    for (int k = 0; k < 16; ++k) bst(buf, vst + 128u * (u32)t, (u32)k << 15, x[k]);
     if (t + 1 < T) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = xn[k];
+      for (int k = 0; k < 16; ++k) x[k] = NTT_PIPE_PREFETCH ? xn[k] : bld(buf, vld + 128u * (u32)(t + 1), (u32)k << 11);
     }
   }
   asm volatile("" ::: "memory");
@@ -755,14 +783,15 @@ __device__ __forceinline__ void strided_inv_pipe_body(u64* __restrict__ X, const
 template <int T>
 __device__ __forceinline__ void strided_inv_pipe_body_fp(u64* __restrict__ X, const double* __restrict__ TWD, u64* lds, const DevPrime& P,
                                                          const NttFuse& f, u32 pos, u32 cc, u32 hg, u32 col) {
-  constexpr u32 log_s = 8;
   const u64 q = P.q;
   const FpK k = fp_consts(q);
   u64 xn[16];
   double x[16], u0, u1[2], u2[4], u3[8], t0, t1[2], t2[4], t3[8];
   asm volatile("" ::: "memory");
+  const LimbBuf buf = limb_buf(X, 8u << 16);
+  const u32 vld = (hg << 15) + col * 8, vst = (hg << 11) + col * 8;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) xn[i] = ntld(&X[((size_t)(16 * hg + i) << log_s) + col]);
+  for (int i = 0; i < 16; ++i) xn[i] = bld(buf, vld, (u32)i << 11);
   fp_load_tw(TWD, 4, hg, t0, t1, t2, t3);
   fp_load_tw_uniform(TWD, u0, u1, u2, u3);
   u64 un = P.n_inv, uw = P.inv_w1_ninv;
@@ -777,9 +806,9 @@ __device__ __forceinline__ void strided_inv_pipe_body_fp(u64* __restrict__ X, co
   for (int t = 0; t < T; ++t) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = fp_of_bits(xn[i]);
-    if (t + 1 < T) {
+    if (NTT_PIPE_PREFETCH && t + 1 < T) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) xn[i] = ntld(&X[((size_t)(16 * hg + i) << log_s) + col + 16u * (u32)(t + 1)]);
+      for (int i = 0; i < 16; ++i) xn[i] = bld(buf, vld + 128u * (u32)(t + 1), (u32)i << 11);
     }
     fp_radix16_inv_321(x, t1, t2, t3, k);
     fp_radix16_inv_0(x, t0, k);
@@ -806,7 +835,11 @@ __device__ __forceinline__ void strided_inv_pipe_body_fp(u64* __restrict__ X, co
       u64 v;
       if (f.center_out) v = (u64)(int64_t)x[i];
       else              v = fp_to_u64(x[i]);
-      ntst(&X[((size_t)(16 * i + hg) << log_s) + col + 16u * (u32)t], v);
+      bst(buf, vst + 128u * (u32)t, (u32)i << 15, v);
+    }
+    if (!NTT_PIPE_PREFETCH && t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = bld(buf, vld + 128u * (u32)(t + 1), (u32)i << 11);
     }
   }
   asm volatile("" ::: "memory");
@@ -883,7 +916,10 @@ __global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_strided_kernel(De
 #define NTT_PIPE_T4 0  // 1: also compile the four-tile walk (experiments; measured slower than two tiles on every batch, profiles/r06a_*)
 #endif
 #ifndef NTT_PIPE_WG
-#define NTT_PIPE_WG 3  // workgroups per CU the pipelined kernels are compiled for
+#define NTT_PIPE_WG 4  // workgroups per CU the strided walk is compiled for (121 / 128 VGPRs with the companion-only resident twiddles)
+#endif
+#ifndef NTT_PIPE_CONTIG_WG
+#define NTT_PIPE_CONTIG_WG 3  // ... and the contiguous walk (it needs the registers: its twiddles change with the tile)
 #endif
 #ifdef NTT_PIPE_FP_ONLY  // experiment: the pipelined kernels carry the FP class only (register allocation of that class alone)
 #define NTT_PIPE_INT(x) (void)0  // (results of the integer classes are wrong: timing experiment)
@@ -904,6 +940,7 @@ __global__ __launch_bounds__(256, NTT_PIPE_WG) void ntt8_strided_pipe_kernel(Dev
   const u64 q = uniform64(P.q);
   u64* __restrict__ X = reb(c, f.polyz[0] ? f.polyz[w.z] : poly + w.z * poly_stride, w.rep) + (size_t)(w.pos - pos_off) * c.N;
   const ulong2* __restrict__ TW = (INVERSE ? c.tw_inv : c.tw_fwd) + (size_t)w.gi * c.N;
+  const u64* __restrict__ TP = (INVERSE ? c.twp_inv : c.twp_fwd) + (size_t)w.gi * c.N;  // (the launcher checks that the tables exist)
   const u32 tid = threadIdx.x, cc = tid & 15, hg = tid >> 4;
   const u32 col = w.tile * 16 + cc;
   const double* __restrict__ TWD = c.twd_fwd ? (INVERSE ? c.twd_inv : c.twd_fwd) + (size_t)w.gi * c.N : nullptr;
@@ -911,12 +948,12 @@ __global__ __launch_bounds__(256, NTT_PIPE_WG) void ntt8_strided_pipe_kernel(Dev
   if (!INVERSE) {
     const StridedArgs a{limb_buf(X, c.N * 8), TW, TWD, lds, cc, hg, col, q};
     if (fp)                       strided_fwd_pipe_body_fp<T>(a);
-    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_fwd_pipe_body<true, T>(a)));
-    else                          NTT_PIPE_INT((strided_fwd_pipe_body<false, T>(a)));
+    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_fwd_pipe_body<true, T>(a, TP)));
+    else                          NTT_PIPE_INT((strided_fwd_pipe_body<false, T>(a, TP)));
   } else {
     if (fp)                       strided_inv_pipe_body_fp<T>(X, TWD, lds, P, f, w.pos, cc, hg, col);
-    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_inv_pipe_body<true, T>(X, TW, lds, P, f, w.pos, cc, hg, col)));
-    else                          NTT_PIPE_INT((strided_inv_pipe_body<false, T>(X, TW, lds, P, f, w.pos, cc, hg, col)));
+    else if (q <= kSmallPrimeMax) NTT_PIPE_INT((strided_inv_pipe_body<true, T>(X, TW, TP, lds, P, f, w.pos, cc, hg, col)));
+    else                          NTT_PIPE_INT((strided_inv_pipe_body<false, T>(X, TW, TP, lds, P, f, w.pos, cc, hg, col)));
   }
 }
 
@@ -1301,7 +1338,7 @@ __global__ __launch_bounds__(256, ACEHIP_NTT_MIN_WG) void ntt8_contig_kernel(Dev
 // tile like in the one-tile form (they come from the XCD's L2: the polynomials of a launch share them).  FUSE as in contig_pass
 // (forward: 0..3; inverse: 0 / 1; the key inner product as the inverse's source keeps the one-tile form).
 template <bool INVERSE, int FUSE, bool TW8, int T>
-__global__ __launch_bounds__(256, NTT_PIPE_WG) void ntt8_contig_pipe_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
+__global__ __launch_bounds__(256, NTT_PIPE_CONTIG_WG) void ntt8_contig_pipe_kernel(DevCtx c, u64* __restrict__ poly, size_t poly_stride, u32 level, u32 pos0,
                                                                u32 pos_off, u32 skip_alpha, NttFuse f, u32 n_limbs, u32 n_polys) {
   __shared__ u64 lds[16 * kBlkPitch];
   constexpr u32 logT = T == 2 ? 1 : (T == 4 ? 2 : 3);
@@ -1718,26 +1755,54 @@ static bool launch_ntt_pipe_t(const DevCtx& c, u64* poly, u32 level, u32 pos0, u
     if (tw8) hipLaunchKernelGGL((ntt8_contig_pipe_kernel<INV, FUSE, true, T>), ACEHIP_NP_ARGS);                   \
     else     hipLaunchKernelGGL((ntt8_contig_pipe_kernel<INV, FUSE, false, T>), ACEHIP_NP_ARGS);                  \
   } while (0)
+  // ACEHIP_NTT_PIPE_CONTIG=1: the contiguous pass walks tiles too (its twiddles depend on the tile: measured slower); default: only the strided pass
+  static const bool contig_too = [] { const char* e = getenv("ACEHIP_NTT_PIPE_CONTIG"); return e && atoi(e) != 0; }();
+  // ACEHIP_NTT_PIPE_INV=1: the inverse strided pass walks too (measured 5-8 % slower than one tile per workgroup, profiles/r06k_*)
+  static const bool inverse_too = [] { const char* e = getenv("ACEHIP_NTT_PIPE_INV"); return e && atoi(e) != 0; }();
+  if (inverse && !inverse_too && !contig_too) return false;
+  dim3 grid1((c.N >> 12) * n_limbs * n_polys * c.nrep);
+#define ACEHIP_N1_ARGS grid1, block, 0, s, c, poly, poly_stride, level, pos0, pos_off, skip_alpha, f, n_limbs, n_polys
+#define ACEHIP_N1_CONTIG(INV, CANON, FUSE)                                                                        \
+  do {                                                                                                            \
+    if (tw8) hipLaunchKernelGGL((ntt8_contig_kernel<INV, CANON, FUSE, true, true>), ACEHIP_N1_ARGS);              \
+    else     hipLaunchKernelGGL((ntt8_contig_kernel<INV, CANON, FUSE, false, true>), ACEHIP_N1_ARGS);             \
+  } while (0)
   if (!inverse) {
     if (f.msg || f.conv) return false;
     hipLaunchKernelGGL((ntt8_strided_pipe_kernel<false, T>), ACEHIP_NP_ARGS);
-    if (f.epi == 1)      ACEHIP_NP_CONTIG(false, 1);
-    else if (f.epi == 2) ACEHIP_NP_CONTIG(false, 2);
-    else if (f.epi == 3) ACEHIP_NP_CONTIG(false, 3);
-    else                 ACEHIP_NP_CONTIG(false, 0);
+    if (contig_too) {
+      if (f.epi == 1)      ACEHIP_NP_CONTIG(false, 1);
+      else if (f.epi == 2) ACEHIP_NP_CONTIG(false, 2);
+      else if (f.epi == 3) ACEHIP_NP_CONTIG(false, 3);
+      else                 ACEHIP_NP_CONTIG(false, 0);
+    } else {
+      if (f.epi == 1)      ACEHIP_N1_CONTIG(false, true, 1);
+      else if (f.epi == 2) ACEHIP_N1_CONTIG(false, true, 2);
+      else if (f.epi == 3) ACEHIP_N1_CONTIG(false, true, 3);
+      else                 ACEHIP_N1_CONTIG(false, true, 0);
+    }
   } else {
-    if (f.km.nd) return false;
-    if (f.src0) ACEHIP_NP_CONTIG(true, 1);
-    else        ACEHIP_NP_CONTIG(true, 0);
-    hipLaunchKernelGGL((ntt8_strided_pipe_kernel<true, T>), ACEHIP_NP_ARGS);
+    if (f.km.nd && contig_too) return false;
+    if (contig_too) {
+      if (f.src0) ACEHIP_NP_CONTIG(true, 1);
+      else        ACEHIP_NP_CONTIG(true, 0);
+    } else {
+      if (f.km.nd)     ACEHIP_N1_CONTIG(true, false, 2);
+      else if (f.src0) ACEHIP_N1_CONTIG(true, false, 1);
+      else             ACEHIP_N1_CONTIG(true, false, 0);
+    }
+    if (inverse_too) hipLaunchKernelGGL((ntt8_strided_pipe_kernel<true, T>), ACEHIP_NP_ARGS);
+    else             hipLaunchKernelGGL((ntt8_strided_kernel<true, SRC_MEM>), ACEHIP_N1_ARGS);
   }
+#undef ACEHIP_N1_CONTIG
+#undef ACEHIP_N1_ARGS
 #undef ACEHIP_NP_CONTIG
 #undef ACEHIP_NP_ARGS
   return true;
 }
 static bool launch_ntt_pipe(const DevCtx& c, u64* poly, u32 level, u32 pos0, u32 n_limbs, bool inverse, hipStream_t s, u32 pos_off,
                             u32 n_polys, size_t poly_stride, u32 skip_alpha, const NttFuse& f, bool tw8, u32 T) {
-  if (c.logN != 16) return false;
+  if (c.logN != 16 || c.twp_fwd == nullptr || c.twp_inv == nullptr) return false;  // (the walk keeps companion-only twiddles)
 #if NTT_PIPE_T4
   if (T == 4) return launch_ntt_pipe_t<4>(c, poly, level, pos0, n_limbs, inverse, s, pos_off, n_polys, poly_stride, skip_alpha, f, tw8);
 #endif

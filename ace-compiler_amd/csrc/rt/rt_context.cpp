@@ -119,7 +119,7 @@ SwitchKeyStore* make_switch_key(const u64* new_key_ntt, const u64* old_key_ntt, 
   const u32 T = c.L + c.K;
   const size_t N = c.N, poly_words = (size_t)T * N;
   auto* sk = new SwitchKeyStore();
-  sk->data = shared_alloc((size_t)c.dnum * 2 * poly_words, false);  // outlives the generating thread
+  sk->data = shared_alloc_key((size_t)c.dnum * 2);  // outlives the generating thread; a sharded rank backs only the limbs it owns
   sk->parts.resize(c.dnum);
   POLYNOMIAL e{};
   poly_alloc(&e, c.N, c.L, c.K);
@@ -545,6 +545,13 @@ void Finalize_context() {
     printf("[ACEHIP] %zu encodes, %zu of them launched ahead of the per-limb queue\n", c.n_encode, c.n_encode_ahead);
     printf("[ACEHIP] pool arena: %.0f MB per replica, %.1f MB live at most; batch %u, limb-sharded world %u%s\n", arena_bytes() / 1048576.0,
            arena_live_peak_bytes() / 1048576.0, c.batch, c.shard_world, c.shard_sim ? " (simulated)" : "");
+    {
+      uint64_t backed = 0, addressed = 0;
+      acehip_limb_memory(&backed, &addressed);
+      if (addressed) printf("[ACEHIP] switch-key memory on this rank: %.1f MB of limbs backed of %.1f MB addressed%s\n", backed / 1e6, addressed / 1e6,
+                            backed < addressed ? " (owner-only limbs: the other ranks' limb positions map one shared scratch limb; the driver rounds every "
+                                                 "limb's handle up to 2 MiB)" : "");
+    }
     if (c.shard_world > 1) {
       uint64_t steps[2] = {0, 0};
       const uint64_t b = acehip_shard_traffic(c.hip, steps, 0);

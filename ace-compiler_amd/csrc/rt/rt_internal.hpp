@@ -167,6 +167,7 @@ extern Context* g_primary;           // the context Prepare_context built: owner
 std::recursive_mutex& shared_mu();
 // device memory that outlives the allocating thread (keys, bootstrap plaintexts): not from the thread's pool
 u64* shared_alloc(size_t words, bool zero);
+u64* shared_alloc_key(size_t n_polys);  // a switch key's memory: owner-only limbs on a rank of limb-sharded execution (rt_poly.cpp)
 struct SharedAllocScope {  // every dalloc of this thread inside the scope is a shared_alloc
   SharedAllocScope();
   ~SharedAllocScope();

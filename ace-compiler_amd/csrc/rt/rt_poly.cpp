@@ -67,6 +67,19 @@ u64* shared_alloc(size_t words, bool zero) {
   if (zero) HIPCHK(acehip_memset(p, 0, words * sizeof(u64), nullptr));
   return p;
 }
+// a switch key (n_polys polynomials of L + K limbs, reference layout): on a rank of limb-sharded execution over RCCL only the limbs it
+// owns are physically backed (acehip_malloc_limbs, include/acehip.h); elsewhere a plain shared allocation
+u64* shared_alloc_key(size_t n_polys) {
+  Context& c = ctx();
+  const u32 T = c.L + c.K;
+  std::vector<uint32_t> gi(n_polys * T);
+  for (size_t k = 0; k < gi.size(); ++k) gi[k] = (uint32_t)(k % T);
+  u64* p = (u64*)acehip_malloc_limbs(c.hip, gi.data(), gi.size());
+  RT_ASSERT(p != nullptr, "device allocation of a switch key (%zu limbs) failed: %s", gi.size(), acehip_last_error());
+  std::lock_guard<std::mutex> lk(g_shared_alloc_mu);
+  g_shared_allocs[p] = gi.size() * (size_t)c.N;
+  return p;
+}
 static bool shared_free(u64* p) {
   {
     std::lock_guard<std::mutex> lk(g_shared_alloc_mu);

@@ -87,7 +87,17 @@ thread_local std::vector<u64> g_stage;
 bool put_device(File& f, const u64* d, u32 n_limbs, u32 level, u32 pos0) {
   Context& c = ctx();
   const size_t words = (size_t)n_limbs * c.N;
-  if (c.shard_world > 1) HIPCHK(acehip_shard_gather(c.hip, const_cast<u64*>(d) - (size_t)pos0 * c.N, level, pos0, n_limbs, nullptr));
+  if (c.shard_world > 1) {
+    // limb by limb: a rank's switch keys back only the limbs it owns, every other limb position is the same scratch limb
+    // (acehip_malloc_limbs) -- a gathered limb must be written out before the next one arrives
+    g_stage.resize(c.N);
+    for (u32 l = 0; l < n_limbs; ++l) {
+      HIPCHK(acehip_shard_gather(c.hip, const_cast<u64*>(d) - (size_t)pos0 * c.N, level, pos0 + l, 1, nullptr));
+      HIPCHK(acehip_download(c.hip, g_stage.data(), d + (size_t)l * c.N, (size_t)c.N * 8, nullptr));
+      if (!f.put(g_stage.data(), (size_t)c.N * 8)) return false;
+    }
+    return true;
+  }
   g_stage.resize(std::min(words, kChunkWords));
   for (size_t off = 0; off < words; off += kChunkWords) {
     const size_t n = std::min(kChunkWords, words - off);
@@ -274,7 +284,7 @@ int load_keys(const char* path) {
   }
   n.pk0 = shared_alloc((size_t)c.L * c.N, false);
   n.pk1 = shared_alloc((size_t)c.L * c.N, false);
-  n.relin = shared_alloc(key_words(c), false);
+  n.relin = shared_alloc_key((size_t)c.dnum * 2);
   ok = ok && get_device(f, n.pk0, c.L, c.L, 0) && get_device(f, n.pk1, c.L, c.L, 0) && get_key(n.relin);
   for (u32 i = 0; ok && i < h[5]; ++i) {
     int32_t rot;
@@ -287,7 +297,7 @@ int load_keys(const char* path) {
     ok = f.get(e, 8) && (e[0] & 1) == 1 && e[0] < 2 * c.N && n.auto_keys.find(e[0]) == n.auto_keys.end();
     if (!ok) break;
     auto* sk = new SwitchKeyStore();
-    sk->data = shared_alloc(key_words(c), false);
+    sk->data = shared_alloc_key((size_t)c.dnum * 2);
     n.auto_keys[e[0]] = sk;
     ok = get_key(sk->data);
     if (ok) adopt_key(c, sk);

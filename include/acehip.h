@@ -87,6 +87,15 @@ int   acehip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, acehip_str
 int   acehip_memset(void* d_ptr, int value, size_t bytes, acehip_stream stream);
 /* pinned host memory + a copy that does not wait (the source must stay untouched until an event recorded
  * after it has completed: acehip_event_sync) */
+/* Device memory for n_limbs limbs in the reference layout (limb k at base + k * N words; h_gi[k] = prime index of limb k) -- the memory
+ * of switch keys.  On a context in limb-sharded mode over RCCL (acehip_ctx_shard_rccl) only the limbs this rank owns
+ * (h_gi[k] % world == rank) get physical memory of their own; every other limb position maps ONE shared scratch limb, so the whole
+ * layout stays addressable (generated code indexes key limbs itself: key_gen.h:28-75) and a rank of G holds 1/G of the key bytes.
+ * HIP virtual memory management, opt-in with ACEHIP_SHARD_OWNER_LIMBS=1 (on ROCm 7.2 every owned limb needs a physical handle of its own,
+ * which occupies 2 MiB: it pays from 8 ranks on); a plain allocation otherwise.  Freed with
+ * acehip_free.  acehip_limb_memory: bytes physically backed / bytes addressed over all live acehip_malloc_limbs blocks of the process. */
+void* acehip_malloc_limbs(acehip_ctx* ctx, const uint32_t* h_gi, size_t n_limbs);
+void  acehip_limb_memory(uint64_t* backed_bytes, uint64_t* addressed_bytes);
 void* acehip_malloc_host(size_t bytes);
 int   acehip_free_host(void* h_ptr);
 int   acehip_memcpy_h2d_async(void* d_dst, const void* h_pinned_src, size_t bytes, acehip_stream stream);

@@ -126,10 +126,10 @@ static size_t dtype_bytes(int dt) {
   }
 }
 
-int ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, int datatype, int root, void* comm, hipStream_t stream) {
+/* one payload of at most a slot */
+static int bcast_chunk(const void* sendbuff, void* recvbuff, size_t bytes, int root, void* comm, hipStream_t stream) {
   Comm* c = comm;
   Shm* s = c->shm;
-  const size_t bytes = count * dtype_bytes(datatype);
   if (bytes == 0 || bytes > SLOT_BYTES) return fail("payload size not supported by the mock");
   if (root < 0 || root >= c->world) return fail("root out of range");
   const uint64_t op = c->op++;
@@ -160,6 +160,18 @@ int ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, int dataty
   return 0;
 }
 
+/* any size: slot-sized pieces one after the other (every rank cuts the same count the same way) */
+int ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, int datatype, int root, void* comm, hipStream_t stream) {
+  const size_t bytes = count * dtype_bytes(datatype);
+  if (bytes == 0) return fail("payload size not supported by the mock");
+  for (size_t off = 0; off < bytes; off += SLOT_BYTES) {
+    const size_t n = bytes - off < SLOT_BYTES ? bytes - off : SLOT_BYTES;
+    const int e = bcast_chunk((const char*)sendbuff + off, (char*)recvbuff + off, n, root, comm, stream);
+    if (e) return e;
+  }
+  return 0;
+}
+
 /* every rank's sendcount elements land at recvbuff + rank * sendcount on every rank (in place when sendbuff already points there):
  * the ranks' contributions one after the other, each cut into chunks a shared slot holds */
 int ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream) {
@@ -171,7 +183,7 @@ int ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, int da
       const size_t n = bytes - off < SLOT_BYTES ? bytes - off : SLOT_BYTES;
       char* dst = (char*)recvbuff + (size_t)r * bytes + off;
       const void* src = r == c->rank ? (const char*)sendbuff + off : dst;
-      const int e = ncclBroadcast(src, dst, n, 1 /* ncclUint8 */, r, comm, stream);
+      const int e = bcast_chunk(src, dst, n, r, comm, stream);
       if (e) return e;
     }
   return 0;

@@ -166,6 +166,17 @@ def test_resnet20_sharded_over_two_processes_is_bit_identical(tmp_path):
         assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 output differs from the unsharded run" % r
         steps, limbs, coll = _exchange_counts(out)
         assert coll == steps and limbs > 3 * steps, (steps, limbs, coll)  # one collective per exchange step, several limbs per step
+    # owner-only key limbs (opt-in, ACEHIP_SHARD_OWNER_LIMBS=1: HIP virtual memory management, include/acehip.h acehip_malloc_limbs): every
+    # switch key keeps the reference's full layout in ADDRESSES, but only the limbs a rank owns are backed by memory of their own --
+    # same bytes out, and the rank reports about half of the key limbs backed (two ranks)
+    ranks = _run_ranks(exe, ["1"], 2, dict(env, ACEHIP_RCCL_LIB=mock, ACEHIP_SHARD_OWNER_LIMBS="1"), tmp_path, "mp2own")
+    for r, (out, dumps) in enumerate(ranks):
+        assert dumps["0.0"] == plain["0.0"], "rank %d: ResNet-20 output differs with owner-only key limbs" % r
+        line = [ln for ln in out.splitlines() if "switch-key memory on this rank:" in ln]
+        assert line, out[-2000:]
+        w = line[0].split("rank:")[1].split()
+        backed, addressed = float(w[0]), float(w[6])
+        assert "owner-only" in line[0] and 0.4 * addressed < backed < 0.6 * addressed, line[0]
     # sharded AND batched: two images per launch on every rank (every exchange then moves both images' limbs)
     ranks = _run_ranks(exe, ["2"], 2, dict(env, ACEHIP_RCCL_LIB=mock, MODEL_BATCH="2"), tmp_path, "mp2b2")
     for r, (out, dumps) in enumerate(ranks):

@@ -454,18 +454,22 @@ def test_fp_class_ntt_n65536(cfg):
         o.close()
 
 
-@pytest.mark.parametrize("rows,tw8,fp", [("0", "65535", "1"), ("100000", "65535", "1"), ("0", "0", "1"), ("0", "65535", "0"), ("16", "65535", "0")],
-                         ids=["wide_only", "narrow_always", "wide_16byte_twiddles", "wide_only_integer_classes", "default_widths_integer_classes"])
-def test_ntt_tile_width_variants_match(rows, tw8, fp):
+@pytest.mark.parametrize("rows,tw8,fp,pipe", [("0", "65535", "1", "0"), ("100000", "65535", "1", "0"), ("0", "0", "1", "0"), ("0", "65535", "0", "0"),
+                                              ("16", "65535", "0", "0"), ("0", "65535", "1", "2"), ("0", "0", "0", "2")],
+                         ids=["wide_only", "narrow_always", "wide_16byte_twiddles", "wide_only_integer_classes", "default_widths_integer_classes",
+                              "pipelined_two_tiles", "pipelined_two_tiles_integer_classes_16byte_twiddles"])
+def test_ntt_tile_width_variants_match(rows, tw8, fp, pipe):
     """N = 2^16 transforms run as narrow passes (1024-coefficient tiles, ntt_fast.hip ntt4_*) up to ACEHIP_NTT_NARROW limb rows
     and as wide passes (4096-coefficient tiles) above: both must reproduce the reference-generated golden vectors and the
     fused-neighbour paths bit for bit whatever the size, so the N = 2^16 tests run again with each form forced -- once with
     the contiguous passes on the 16-byte twiddle tables (ACEHIP_NTT_TW8_POLYS=0) instead of the companion-only stream, and with the
-    FP64 butterflies of the small primes switched off (ACEHIP_NTT_FP=0: every limb on the integer classes)."""
+    FP64 butterflies of the small primes switched off (ACEHIP_NTT_FP=0: every limb on the integer classes).  Round 6: the pipelined
+    passes (ACEHIP_NTT_PIPE=2: a workgroup walks two tiles of a limb with the second tile's loads in flight during the first's
+    butterflies; off by default -- measured slower, profiles/r06_ntt_pipelined_passes.txt -- but kept correct: same bits)."""
     import subprocess
     import sys
 
-    env = dict(os.environ, ACEHIP_NTT_NARROW=rows, ACEHIP_NTT_TW8_POLYS=tw8, ACEHIP_NTT_FP=fp)
+    env = dict(os.environ, ACEHIP_NTT_NARROW=rows, ACEHIP_NTT_TW8_POLYS=tw8, ACEHIP_NTT_FP=fp, ACEHIP_NTT_PIPE=pipe)
     tests = [os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_encode.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + tests + ["-k",
                         "(test_against_reference_golden and n65536) or test_fused_ntt_paths_n65536 or test_fp_class_ntt_n65536 or "
