@@ -197,6 +197,145 @@ __global__ __launch_bounds__(1024) void hw_batch_ew_kernel(DevCtx c, HwBatchArgs
   }
 }
 
+// Round 6: IM images of a batch in ONE LANE (ACEHIP_HW_IMAGES_PER_LANE = 2 .. 4).  The images of a batch run the same op list on their own
+// replicas of the arena; an operand OUTSIDE the arena -- a weight plaintext above all -- is the same limb for all of them.  One workgroup per
+// image leaves that sharing to L2 (which holds for one stream and not next to the kernels of other image streams: those loads redirected to
+// 4 KiB are worth 3.2 % of the headline, profiles/r05aq_*); the images as waves of a workgroup paid more in barriers than they saved
+// (profiles/r05at_*, r05aw_*).  Here a lane keeps its coefficients of IM images: a shared operand is loaded ONCE and multiplied into all of
+// them, the op list is decoded once per IM images, nothing is synchronised.  Same interpreter, same register-cache rule per image
+// (the host's RegCache replay does not change): same bits.
+template <int CAP, int IM>
+__global__ __launch_bounds__(256) void hw_batch_ew_im_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * kHwLanes;
+  if (i >= c.N) return;
+  const u32 rl0 = blockIdx.z * IM;  // first image of this lane within the launch
+  const u32 beg = args.seg_start[blockIdx.y], end = args.seg_start[blockIdx.y + 1];
+  const u64 *r0 = nullptr, *r1 = nullptr, *rb = nullptr;
+  V4 v0[IM], v1[IM], vbc[IM];
+#pragma unroll
+  for (int m = 0; m < IM; ++m) v0[m] = v1[m] = vbc[m] = V4{{0, 0}, {0, 0}};
+  bool on[IM];
+#pragma unroll
+  for (int m = 0; m < IM; ++m) on[m] = rl0 + (u32)m < c.nrep;  // (the last group of a batch may be short: wave-uniform)
+  auto in_arena = [&](const u64* p) { return (u64)p - c.rep_lo < c.rep_span; };
+  // operand `real` (list address `key`) for every image: registers, or memory -- once if all images share it
+  auto load_all = [&](const u64* real, V4 (&out)[IM]) {
+    if (!in_arena(real)) {
+      const V4 t = ld4(real + i);
+#pragma unroll
+      for (int m = 0; m < IM; ++m) out[m] = t;
+    } else {
+#pragma unroll
+      for (int m = 0; m < IM; ++m)
+        if (on[m]) out[m] = ld4((const u64*)((u64)real + (u64)(c.rep0 + rl0 + (u32)m) * c.rep_stride) + i);
+    }
+  };
+  for (u32 k = beg; k < end; ++k) {
+    const HwBatchOp op = args.op[k];
+    const u32 kind = op.kind & HW_OP_KIND_MASK;
+    const u64 *const res0 = op.res, *const a0 = op.a, *const b0 = op.b;
+    const bool keep_in_regs = (op.kind & HW_OP_NOSTORE) || (k + 1 < end && args.op[k + 1].res == res0);
+    V4 vr[IM];
+    if (kind == HW_OP_ZERO) {
+#pragma unroll
+      for (int m = 0; m < IM; ++m) vr[m] = V4{{0, 0}, {0, 0}};
+    } else {
+      V4 va[IM];
+      if (a0 == r0) {
+#pragma unroll
+        for (int m = 0; m < IM; ++m) va[m] = v0[m];
+      } else if (a0 == r1) {
+#pragma unroll
+        for (int m = 0; m < IM; ++m) va[m] = v1[m];
+      } else if (a0 == rb) {
+#pragma unroll
+        for (int m = 0; m < IM; ++m) va[m] = vbc[m];
+      } else {
+        load_all(op.a, va);
+      }
+      if (kind == HW_OP_COPY) {
+#pragma unroll
+        for (int m = 0; m < IM; ++m) vr[m] = va[m];
+      } else {
+        const u64 q = c.primes[op.gi].q, mu = c.primes[op.gi].barrett_mu;
+        const u32 nb = c.primes[op.gi].nbits;
+        V4 vb[IM];
+        if (kind == HW_OP_MULC || kind == HW_OP_ADDC) {
+          const u64 imm = (u64)(uintptr_t)op.b;
+#pragma unroll
+          for (int m = 0; m < IM; ++m) vb[m] = V4{{imm, imm}, {imm, imm}};
+        } else if (b0 == r0) {
+#pragma unroll
+          for (int m = 0; m < IM; ++m) vb[m] = v0[m];
+        } else if (b0 == r1) {
+#pragma unroll
+          for (int m = 0; m < IM; ++m) vb[m] = v1[m];
+        } else {
+          if (b0 != rb) {
+            load_all(op.b, vbc);
+            rb = b0;
+          }
+#pragma unroll
+          for (int m = 0; m < IM; ++m) vb[m] = vbc[m];
+        }
+        V4 acc[IM];
+        if (kind == HW_OP_MULADD) {
+          if (res0 == r0) {
+#pragma unroll
+            for (int m = 0; m < IM; ++m) acc[m] = v0[m];
+          } else if (res0 == r1) {
+#pragma unroll
+            for (int m = 0; m < IM; ++m) acc[m] = v1[m];
+          } else if (res0 == rb) {
+#pragma unroll
+            for (int m = 0; m < IM; ++m) acc[m] = vbc[m];
+          } else {
+            load_all(op.res, acc);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < IM; ++m) {
+          switch (kind) {
+            case HW_OP_ADD:
+            case HW_OP_ADDC:
+              vr[m] = map2(va[m], vb[m], [q](u64 x, u64 y) { return add_mod(x, y, q); });
+              break;
+            case HW_OP_SUB:
+              vr[m] = map2(va[m], vb[m], [q](u64 x, u64 y) { return sub_mod(x, y, q); });
+              break;
+            case HW_OP_MULADD: {
+              const V4 pr = map2(va[m], vb[m], [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
+              vr[m] = map2(acc[m], pr, [q](u64 x, u64 y) { return add_mod(x, y, q); });
+              break;
+            }
+            default:  // HW_OP_MUL, HW_OP_MULC
+              vr[m] = map2(va[m], vb[m], [q, mu, nb](u64 x, u64 y) { return mul_mod(x, y, q, mu, nb); });
+              break;
+          }
+        }
+      }
+    }
+    if (!keep_in_regs) {
+      if (!in_arena(op.res)) {  // (a result outside the arena is one limb for all images: they computed the same value)
+        st4(op.res + i, vr[0]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < IM; ++m)
+          if (on[m]) st4((u64*)((u64)op.res + (u64)(c.rep0 + rl0 + (u32)m) * c.rep_stride) + i, vr[m]);
+      }
+    }
+    if (res0 == rb) rb = nullptr;
+    if (res0 != r0) {
+      r1 = r0;
+#pragma unroll
+      for (int m = 0; m < IM; ++m) v1[m] = v0[m];
+    }
+    r0 = res0;
+#pragma unroll
+    for (int m = 0; m < IM; ++m) v0[m] = vr[m];
+  }
+}
+
 // independent gathers r[j] = a[perm[j]] (the host guarantees no result aliases any source of the launch)
 // op.gi != 0: the table op.b is the automorphism X -> X^k of this context (k = op.gi), whose index map in the NTT (bit-reversed)
 // order is perm[i] = rev(((2 rev(i) + 1) k mod 2N) >> 1) (host_params.cpp automorphism_order_ntt): computed here, 4 bytes per
@@ -239,6 +378,26 @@ void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hip
   // workgroup has at least four waves
   static const u32 reps_cap = [] { const char* e = getenv("ACEHIP_HW_REPS_WG"); return e && atoi(e) > 0 ? (u32)atoi(e) : 1u; }();
   static const u32 lockstep = [] { const char* e = getenv("ACEHIP_HW_REPS_SYNC"); return e && atoi(e) > 0 ? 1u : 0u; }();
+  // ACEHIP_HW_IMAGES_PER_LANE = 2 .. 4 (default 3; 0 / 1: off): the images-per-lane form (hw_batch_ew_im_kernel) for launches that cover
+  // several images.  Same-box A/B of the headline (profiles/r06o_ab_bench_hw_images_per_lane.txt): 2.823 images/s with one image per
+  // workgroup, 2.931 / 2.942 / 2.920 with 2 / 3 / 4 images per lane; bit-identical (the batch digests of tests/test_gpu_gen_parity.py)
+  static const u32 im = [] { const char* e = getenv("ACEHIP_HW_IMAGES_PER_LANE"); const u32 v = e ? (u32)atoi(e) : 3u; return v >= 2 && v <= 4 ? v : 0u; }();
+  if (im && c.nrep >= 2 && reps_cap == 1) {
+    const u32 n_ops = args.seg_start[n_seg];
+    const u32 per_wg = 256 * kHwLanes;
+#define ACEHIP_HW_IM_LAUNCH(IMV)                                                                                                          \
+  do {                                                                                                                                    \
+    dim3 grid((c.N + per_wg - 1) / per_wg, n_seg, (c.nrep + IMV - 1) / IMV), block(256);                                                  \
+    if (n_ops <= 16) hipLaunchKernelGGL((hw_batch_ew_im_kernel<16, IMV>), grid, block, 0, s, c, shrink<16>(args, n_ops, n_seg));          \
+    else if (n_ops <= 48) hipLaunchKernelGGL((hw_batch_ew_im_kernel<48, IMV>), grid, block, 0, s, c, shrink<48>(args, n_ops, n_seg));     \
+    else hipLaunchKernelGGL((hw_batch_ew_im_kernel<HW_BATCH_MAX, IMV>), grid, block, 0, s, c, args);                                      \
+  } while (0)
+    if (im == 2) ACEHIP_HW_IM_LAUNCH(2);
+    else if (im == 3) ACEHIP_HW_IM_LAUNCH(3);
+    else ACEHIP_HW_IM_LAUNCH(4);
+#undef ACEHIP_HW_IM_LAUNCH
+    return;
+  }
   const u32 R = std::min(std::min(c.nrep, reps_cap), 16u), C = R >= 4 ? 1u : (R == 3 ? 1u : (R == 2 ? 2u : 4u));
   const u32 per_wg = 64 * kHwLanes * C;  // coefficients of a limb per workgroup
   dim3 grid((c.N + per_wg - 1) / per_wg, n_seg, (c.nrep + R - 1) / R), block(64 * R * C);
