@@ -363,6 +363,37 @@ __global__ __launch_bounds__(256) void hw_batch_rotate_kernel(DevCtx c, HwBatchA
   *reinterpret_cast<ulong2*>(op.res + i) = v;
 }
 
+// the same gathers for IM images of a batch in one lane: the index pair is computed (or loaded) once, the 2 * IM gathered loads are in
+// flight together (ACEHIP_HW_IMAGES_PER_LANE, see hw_batch_ew_im_kernel)
+template <int CAP, int IM>
+__global__ __launch_bounds__(256) void hw_batch_rotate_im_kernel(DevCtx c, HwBatchArgsT<CAP> args) {
+  const u32 N = c.N;
+  const u32 i = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= N) return;
+  const HwBatchOp op = args.op[blockIdx.y];
+  uint2 p;
+  if (op.gi != 0) {  // uniform for the workgroup
+    const u32 sh = __builtin_clz(N) + 1;  // 32 - log2(N)
+    const u32 j0 = __brev(i) >> sh, j1 = __brev(i + 1) >> sh;
+    p.x = __brev((((2 * j0 + 1) * op.gi) & (2 * N - 1)) >> 1) >> sh;
+    p.y = __brev((((2 * j1 + 1) * op.gi) & (2 * N - 1)) >> 1) >> sh;
+  } else {
+    p = *reinterpret_cast<const uint2*>(reinterpret_cast<const u32*>(op.b) + i);
+  }
+  const u32 rl0 = blockIdx.z * IM;
+  ulong2 v[IM];
+#pragma unroll
+  for (int m = 0; m < IM; ++m)
+    if (rl0 + (u32)m < c.nrep) {
+      const u64* a = reb(c, op.a, c.rep0 + rl0 + (u32)m);
+      v[m].x = a[p.x];
+      v[m].y = a[p.y];
+    }
+#pragma unroll
+  for (int m = 0; m < IM; ++m)
+    if (rl0 + (u32)m < c.nrep) *reinterpret_cast<ulong2*>(reb(c, op.res, c.rep0 + rl0 + (u32)m) + i) = v[m];
+}
+
 template <int CAP>
 static HwBatchArgsT<CAP> shrink(const HwBatchArgs& a, u32 n_ops, u32 n_seg) {
   HwBatchArgsT<CAP> r;
@@ -410,6 +441,20 @@ void launch_hw_batch_ew(const DevCtx& c, const HwBatchArgs& args, u32 n_seg, hip
 void launch_hw_batch_rotate(const DevCtx& c, const HwBatchArgs& args, u32 n_ops, hipStream_t s) {
   ACEHIP_ABLATE(ABL_ROTATE);
   if (n_ops == 0) return;
+  static const u32 im = [] { const char* e = getenv("ACEHIP_HW_ROTATE_IMAGES_PER_LANE"); const u32 v = e ? (u32)atoi(e) : 0u; return v == 2 || v == 3 ? v : 0u; }();
+  if (im && c.nrep >= 2) {
+    dim3 gim((c.N / 2 + 255) / 256, n_ops, (c.nrep + im - 1) / im), block(256);
+    if (im == 2) {
+      if (n_ops <= 16) hipLaunchKernelGGL((hw_batch_rotate_im_kernel<16, 2>), gim, block, 0, s, c, shrink<16>(args, n_ops, 0));
+      else if (n_ops <= 48) hipLaunchKernelGGL((hw_batch_rotate_im_kernel<48, 2>), gim, block, 0, s, c, shrink<48>(args, n_ops, 0));
+      else hipLaunchKernelGGL((hw_batch_rotate_im_kernel<HW_BATCH_MAX, 2>), gim, block, 0, s, c, args);
+    } else {
+      if (n_ops <= 16) hipLaunchKernelGGL((hw_batch_rotate_im_kernel<16, 3>), gim, block, 0, s, c, shrink<16>(args, n_ops, 0));
+      else if (n_ops <= 48) hipLaunchKernelGGL((hw_batch_rotate_im_kernel<48, 3>), gim, block, 0, s, c, shrink<48>(args, n_ops, 0));
+      else hipLaunchKernelGGL((hw_batch_rotate_im_kernel<HW_BATCH_MAX, 3>), gim, block, 0, s, c, args);
+    }
+    return;
+  }
   dim3 grid((c.N / 2 + 255) / 256, n_ops, c.nrep), block(256);
   if (n_ops <= 16) hipLaunchKernelGGL(hw_batch_rotate_kernel<16>, grid, block, 0, s, c, shrink<16>(args, n_ops, 0));
   else if (n_ops <= 48) hipLaunchKernelGGL(hw_batch_rotate_kernel<48>, grid, block, 0, s, c, shrink<48>(args, n_ops, 0));

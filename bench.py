@@ -19,7 +19,13 @@ barrier and the max-reduce of the timing.
 Same JSON line:
   roofline      the dominant kernel family (forward NTT, its two 8-stage pass kernels), HIP events on the
                 launch stream over a 1024-limb batch (512 MiB > Infinity Cache): algorithmic 16*N B/limb
-  key_switch    C3 key-switch, HIP-event timed
+                (+ key_switch_ms / key_switch_frac / key_switch_batched_per_s: the C3 figures inside this object as well)
+  key_switch    C3 key-switch, HIP-event timed (single operation, and 12 ciphertexts per launch set)
+  latency_s_single_image / single_image_latency
+                one image alone (B = 1, one stream) after the throughput run, verified against the reference's digest
+  cpu_baseline.measured_pair (+ measured_program_s, gpu_program_s)
+                a MEASURED like-for-like pair: tests/c/ct_parity.c (operator script + two bootstraps at the headline's ring) built
+                against the reference rtlib (one core of this host) and against this runtime (the GPU), each side's own clock
   cpu_baseline  reference rtlib (oracle/_ref/ref_dump, kind "reference") on this host before the GPU is touched:
                 one process per usable physical core of ONE socket, all at once (cores = how many; a cgroup CPU quota
                 below the socket size is reported and the full socket given as an ideal-scaling extrapolation), with

@@ -271,3 +271,72 @@ def test_bad_arguments_fail_loudly(env):
     with pytest.raises(A.AceHipError, match="null operand"):
         rt.hw_batch([(B.HW_MUL, 0, d.at(0), d.at(0), None)])
     d.free()
+
+
+@pytest.mark.parametrize("images,per_lane", [(2, "3"), (5, "3"), (5, "2"), (4, "4"), (3, "0")])
+def test_random_programs_over_image_replicas(images, per_lane):
+    """Image batches: one launch covers several replicas of the arena; operands outside the arena (weight plaintexts) are shared by all
+    images.  Round 6: the per-limb kernel keeps several images of a batch in ONE lane (ACEHIP_HW_IMAGES_PER_LANE, default 3: a shared
+    operand is loaded once for them; hw_batch.hip hw_batch_ew_im_kernel) -- every image must still get exactly what the sequential host
+    program gives on ITS data, for batches that are not a multiple of the group (5 = 3 + 2, 2 < 3) and with the form off ("0").  The
+    switch is read once per process: the case runs in a child."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import _oracle as O, ace_compiler_amd as A
+from ace_compiler_amd import binding as B
+from ace_compiler_amd.binding import ArenaCfg
+from test_gpu_hw_batch import _apply_host, N, L, Q0, SF, DNUM
+R = %d
+o = O.Oracle(N, L, Q0, SF, DNUM); rt = A.AceHip(N, L, Q0, SF, DNUM, device=0)
+T = o.L + o.K; rows = 3
+rng = np.random.default_rng(77)
+rt.lib.acehip_workspace_words.restype = C.c_size_t
+ws = (rt.lib.acehip_workspace_words(rt.h) + 31) // 32 * 32
+off_sc, off_data = ws, ws + 2 * N
+rep_words = off_data + rows * T * N
+shared = np.stack([rng.integers(0, o.primes[g], size=N, dtype=np.uint64) for g in range(T)])
+dsh = rt.to_device(shared)
+data = [np.stack([rng.integers(0, o.primes[s %% T], size=N, dtype=np.uint64) for s in range(rows * T)]) for _ in range(R)]
+arena = rt.buf(rep_words * R)
+for r in range(R):
+    rt.check(rt.lib.acehip_memcpy_h2d(arena.at(r * rep_words + off_data), np.ascontiguousarray(data[r]).ctypes.data, rows * T * N * 8, None))
+cfg = ArenaCfg(arena.ptr, rep_words * 8, rep_words * 8, R, arena.at(0), arena.at(off_sc), 2)
+rt.check(rt.lib.acehip_ctx_set_arena(rt.h, C.byref(cfg)))
+rt.check(rt.lib.acehip_ctx_select(rt.h, 0, R))
+# a program of multiply-accumulate chains against shared operands, plain ops between the image's own limbs, copies, immediates
+prog = []
+for _ in range(400):
+    gi = int(rng.integers(0, T))
+    r_, a_ = (int((gi + T * rng.integers(0, rows)) * N) for _ in range(2))
+    op = int(rng.choice([B.HW_ADD, B.HW_MUL, B.HW_MUL, B.HW_MULADD, B.HW_MULADD, B.HW_SUB, B.HW_COPY, B.HW_MULC, B.HW_ZERO]))
+    if op == B.HW_MULC:
+        b_ = ("imm", int(rng.integers(0, o.primes[gi])))
+    elif rng.random() < 0.5:
+        b_ = ("shared", gi)
+    else:
+        b_ = ("own", int((gi + T * rng.integers(0, rows)) * N))
+    prog.append((op, gi, r_, a_, b_))
+ops = []
+for op, gi, r_, a_, b_ in prog:
+    bp = b_[1] if b_[0] == "imm" else (dsh.at(b_[1] * N) if b_[0] == "shared" else arena.at(off_data + b_[1]))
+    if op in (B.HW_COPY, B.HW_ZERO):
+        bp = None
+    ops.append((op, gi, arena.at(off_data + r_), arena.at(off_data + a_) if op != B.HW_ZERO else None, bp))
+rt.hw_batch(ops)
+got = arena.download((R, rep_words))
+for r in range(R):
+    # host: the image's rows followed by the shared row block, so that every operand is an offset into one array
+    both = np.concatenate([data[r], shared]).copy()
+    hp = [(op, gi, r_, a_, (b_[1] if b_[0] == "imm" else (rows * T * N + b_[1] * N if b_[0] == "shared" else b_[1]))) for op, gi, r_, a_, b_ in prog]
+    _apply_host(o, B, both, hp, {})
+    assert np.array_equal(got[r, off_data:off_data + rows * T * N].reshape(rows * T, N), both[:rows * T]), "image %%d" %% r
+    assert np.array_equal(both[rows * T:], shared)
+print("replicas ok")
+''' % (os.path.dirname(os.path.abspath(__file__)), images)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ACEHIP_HW_IMAGES_PER_LANE=per_lane), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "replicas ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
