@@ -406,15 +406,27 @@ struct LimbBlock {
   size_t bytes = 0, limb_bytes = 0, n_limbs = 0;
   std::vector<hipMemGenericAllocationHandle_t> own;
 };
-std::mutex g_limb_mu;
-std::map<void*, LimbBlock> g_limb_blocks;
 struct SinkKey {
   int dev;
   size_t bytes;
   bool operator<(const SinkKey& o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
 };
-std::map<SinkKey, hipMemGenericAllocationHandle_t> g_limb_sinks;  // one per device and limb size, for the life of the process
-std::map<void*, size_t> g_limb_plain;  // acehip_malloc_limbs blocks that are plain allocations (statistics only)
+// The registries are never destroyed: acehip_free consults them, and callers free device memory from destructors that run at process
+// exit in no particular order relative to this library's statics (a destroyed std::map here was a crash at exit, found by the GPU suite).
+struct LimbRegistry {
+  std::mutex mu;
+  std::map<void*, LimbBlock> blocks;
+  std::map<SinkKey, hipMemGenericAllocationHandle_t> sinks;  // one per device and limb size, for the life of the process
+  std::map<void*, size_t> plain;                             // acehip_malloc_limbs blocks that are plain allocations (statistics only)
+};
+LimbRegistry& limb_reg() {
+  static LimbRegistry* r = new LimbRegistry;
+  return *r;
+}
+#define g_limb_mu (limb_reg().mu)
+#define g_limb_blocks (limb_reg().blocks)
+#define g_limb_sinks (limb_reg().sinks)
+#define g_limb_plain (limb_reg().plain)
 std::atomic<u64> g_limb_backed{0}, g_limb_addressed{0};
 bool owner_only_on() {
   // opt-in: on ROCm 7.2 / MI355X a mapping cannot start inside a physical handle (hipMemMap with an offset: invalid argument), so every

@@ -13,6 +13,8 @@
 #include <sys/random.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <execinfo.h>
+#include <signal.h>
 
 // Programs generated for the CKKS-level provider interface (rt_seal examples) do not define this callback: it is an
 // optional (weak) reference here, a missing definition means "no weight data file".
@@ -410,8 +412,42 @@ using namespace rt;
 
 extern "C" {
 
+// A crash inside the runtime (or under it) must not be silent: a program whose stdout is a pipe loses everything it has printed when it
+// dies of a signal, and an empty report is all a caller gets.  The first SIGSEGV / SIGBUS / SIGFPE / SIGILL of the process writes the
+// signal and a backtrace to stderr (async-signal-safe calls only), flushes nothing else, and then dies of the same signal with the
+// default action -- exit status and core behaviour are what they would have been.  ACEHIP_NO_CRASH_REPORT=1 leaves the handlers alone;
+// a handler the program installed itself is never replaced.
+static void crash_report(int sig) {
+  static const char head[] = "\n[acehip] fatal signal -- backtrace of the faulting thread (libFHErt_ant / libacehip frames resolve with addr2line):\n";
+  ssize_t w = write(2, head, sizeof head - 1);
+  (void)w;
+  void* frames[48];
+  const int n = backtrace(frames, 48);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+static void install_crash_report() {
+  static bool done = false;
+  if (done || getenv("ACEHIP_NO_CRASH_REPORT") != nullptr) return;
+  done = true;
+  void* warm[2];
+  (void)backtrace(warm, 2);  // (loads libgcc's unwinder now: not from inside a signal handler)
+  for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL}) {
+    struct sigaction old;
+    if (sigaction(sig, nullptr, &old) != 0 || old.sa_handler != SIG_DFL || (old.sa_flags & SA_SIGINFO)) continue;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = crash_report;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_flags = SA_RESETHAND | SA_NODEFER;
+    (void)sigaction(sig, &sa, nullptr);
+  }
+}
+
 void Prepare_context() {
   if (g_ctx != nullptr) return;
+  install_crash_report();
   RtmScope rtm(RTM_PREPARE_CONTEXT, false);
   std::lock_guard<std::recursive_mutex> prep_lock(shared_mu());
   if (g_primary != nullptr) {  // another thread prepared already: this one becomes a view of that context
