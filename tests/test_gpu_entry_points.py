@@ -552,3 +552,31 @@ def test_key_inner_products_with_key_sets_inside_the_replicated_arena(cfg):
     finally:
         rt.close()
         o.close()
+
+
+def test_malloc_limbs_outside_sharded_mode_is_a_plain_allocation(env):
+    """acehip_malloc_limbs (the memory of switch keys): on a context that is not a rank of limb-sharded execution the whole block is backed
+    like any allocation, usable by every kernel, counted by acehip_limb_memory and released by acehip_free.  (The owner-only form of a
+    sharded rank is exercised over two processes in tests/test_gpu_batch_shard.py.)"""
+    o, rt, level = env
+    N, T = o.N, o.L + o.K
+    n = 2 * T
+    gi = (C.c_uint32 * n)(*[k % T for k in range(n)])
+    b0, a0 = C.c_uint64(0), C.c_uint64(0)
+    rt.lib.acehip_limb_memory(C.byref(b0), C.byref(a0))
+    p = rt.lib.acehip_malloc_limbs(rt.h, gi, n)
+    assert p
+    b1, a1 = C.c_uint64(0), C.c_uint64(0)
+    rt.lib.acehip_limb_memory(C.byref(b1), C.byref(a1))
+    assert b1.value - b0.value == n * N * 8 and a1.value - a0.value == n * N * 8
+    x = o.uniform(T, o.L, 4242)
+    rt.check(rt.lib.acehip_memcpy_h2d(p, x.ctypes.data, T * N * 8, None))
+    rt.check(rt.lib.acehip_memcpy_d2d(p + T * N * 8, p, T * N * 8, None))
+    back = np.empty_like(x)
+    rt.check(rt.lib.acehip_memcpy_d2h(back.ctypes.data, p + T * N * 8, T * N * 8, None))
+    assert np.array_equal(back, x)
+    bad = (C.c_uint32 * 1)(T)  # a prime index outside the chain
+    assert not rt.lib.acehip_malloc_limbs(rt.h, bad, 1)
+    rt.check(rt.lib.acehip_free(p))
+    rt.lib.acehip_limb_memory(C.byref(b1), C.byref(a1))
+    assert b1.value == b0.value and a1.value == a0.value
